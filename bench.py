@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: VQA train samples/s (VL-T5-base, 36 regions, 20 question tokens, 5 answer tokens).
+
+One "step" = VLT5VQA.train_step forward + backward + clip_grad_norm(5) + AdamW on one synthetic batch of 80 samples
+per GPU (BASELINE.json configs[1]; batch 80 is what the reference's launch scripts use), dropout 0.1 ON, bf16 MFMA
+compute with fp32 accumulation / fp32 master weights, inputs already resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0): metric/value (whole-job samples/s), roofline of the dominant kernel (HIP-event timed
+inside this process) and the CPU baseline (the oracle restatement timed on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_BWD_GFLOP_PER_SAMPLE = 37.90          # 2*M*N*K per GEMM/bmm, L=20 V=36 T=5
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+
+
+def gemm_schedule(cfg, B, L, V, T):
+    """Every GEMM launch of one train step as (count, M, N, K, a_kmajor, b_kmajor, out_f32): mirrors csrc/engine.hip."""
+    d, inner, ff, Le, Ld, vocab, fd = cfg.d_model, cfg.num_heads * cfg.d_kv, cfg.d_ff, cfg.num_layers, cfg.num_decoder_layers, cfg.vocab_size, cfg.feat_dim
+    S, Sx = L + V, L + V + 2
+    M, Mx, Md = B * S, B * Sx, B * T
+    sch = []
+
+    def lin(count, rows, n_out, k_in, dgrad_f32=True):
+        sch.append((count, rows, n_out, k_in, 0, 0, 0))            # forward
+        sch.append((count, rows, k_in, n_out, 0, 1, int(dgrad_f32)))   # dgrad
+        sch.append((count, n_out, k_in, rows, 1, 1, 1))            # wgrad
+    lin(Le, M, 3 * inner, d)
+    lin(Le, M, d, inner, False)
+    lin(Le, M, ff, d)
+    lin(Le, M, d, ff, False)
+    lin(Ld, Md, 3 * inner, d)
+    lin(Ld, Md, d, inner, False)
+    lin(Ld, Md, inner, d)
+    lin(Ld, Md, d, inner, False)
+    lin(Ld, Md, ff, d)
+    lin(Ld, Md, d, ff, False)
+    lin(1, Mx, Ld * 2 * inner, d)
+    lin(1, Md, vocab, d)
+    sch.append((1, B * V, d, fd, 0, 0, 1))
+    sch.append((1, d, fd, B * V, 1, 1, 1))
+    return sch
+
+
+def time_gemms(cfg, B, L, V, T, dev, reps=10):
+    """HIP-event timing of each distinct GEMM launch shape on the current stream; returns per-instantiation totals."""
+    from vqacl_amd import ops
+    BF = torch.bfloat16
+    rows = []
+    for count, M, N, K, akm, bkm, of32 in gemm_schedule(cfg, B, L, V, T):
+        A = torch.randn((K, M) if akm else (M, K), device=dev).to(BF)
+        Bm = torch.randn((K, N) if bkm else (N, K), device=dev).to(BF)
+        out = torch.empty(M, N, device=dev, dtype=torch.float32 if of32 else BF)
+        kw = dict(a_kmajor=bool(akm), b_kmajor=bool(bkm), out=out)
+        for _ in range(2):
+            ops.gemm(A, Bm, M, N, K, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.gemm(A, Bm, M, N, K, **kw)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        rows.append(dict(count=count, M=M, N=N, K=K, akm=akm, bkm=bkm, ms=ms, gflop=2.0 * M * N * K / 1e9))
+        del A, Bm, out
+    return rows
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference path) timed on the host: fwd + bwd + clip + AdamW, dropout on."""
+    from oracle import ref_cpu as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = R.Cfg(dropout=0.1)
+    Bc = 8
+    model = R.OracleModel(cfg, seed=0)
+    opt = R.HFAdamW(model.used, lr=1e-4, eps=1e-6, weight_decay=0.01)
+    batch = R.synthetic_batch(cfg, B=Bc, L=20, V=36, T=5, seed=66666)
+    times = []
+    t_start = time.time()
+    for it in range(3):
+        t0 = time.time()
+        model.zero_grad()
+        out = model.train_step(batch, 0, 0.5, 0.3, training=True)
+        out["loss"].backward()
+        R.clip_grad_norm(list(model.used.values()), 5.0)
+        opt.step()
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget:
+            break
+    t = min(times[1:]) if len(times) > 1 else times[0]
+    return dict(value=round(Bc / t, 3), unit="samples/s", cores=cores, kind="port",
+                sample=f"{len(times)} train steps of batch {Bc} (L=20,V=36,T=5, dropout on, fp32 torch-CPU oracle), best of steps 2+")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from oracle.ref_cpu import synthetic_batch, Cfg          # only the synthetic-input recipe and (rank 0) the cpu_baseline leg
+    from vqacl_amd import VLT5VQA, VLT5Config, FusedAdamW, reference_param_groups
+    cfg = VLT5Config(dropout_rate=0.1)
+    torch.manual_seed(66666)
+    model = VLT5VQA(cfg, device=dev)
+    model.train()
+    handle = model
+    if distributed:
+        from vqacl_amd.parallel import DataParallelVLT5
+        handle = DataParallelVLT5(model)
+    opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-4, eps=1e-6, max_grad_norm=5.0)
+    B, L, V, T = args.batch, 20, 36, 5
+    batch = synthetic_batch(Cfg(), B=B, L=L, V=V, T=T, seed=66666 + rank, task_id=0)
+    batch = {k: v.to(dev) for k, v in batch.items()}          # inputs resident in HBM before the timed region
+
+    def step():
+        res = handle.train_step(batch, 0, 0.5, 0.3)
+        res["loss"].backward()
+        opt.step()
+        for p in model.parameters():
+            p.grad = None
+        return res["loss"]
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    final_loss = float(loss)
+    ms = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    out = {"metric": "vqa_train_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "VL-T5-base VQA v2 train step (fwd+bwd+clip+AdamW), 36x2048 regions, 20 question tokens, "
+                                  "5 answer tokens, dropout 0.1", "batch_per_gpu": B, "global_batch": B * world,
+                      "parallelism": f"dp{world}"},
+           "samples_per_sec_per_gpu": round(value / world, 2), "final_loss": round(final_loss, 4),
+           "step_tflops_per_gpu": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms, 2),
+           "step_frac_of_mfma_peak": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
+    if rank == 0 and world == 1 and not args.no_roofline:
+        rows = time_gemms(cfg, B, L, V, T, dev)
+        launches = sum(r["count"] for r in rows)
+        tot_ms = sum(r["count"] * r["ms"] for r in rows)
+        tot_gflop = sum(r["count"] * r["gflop"] for r in rows)
+        achieved = tot_gflop / tot_ms                      # GFLOP/ms == TFLOP/s
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<BM,BN,AKM,BKM> (all instantiations)",
+                           "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": launches, "avg_launch_us": round(tot_ms / launches * 1e3, 2),
+                           "gflop_per_launch": round(tot_gflop / launches, 3), "gemm_ms_per_step": round(tot_ms, 3)}
+        worst = sorted(rows, key=lambda r: -r["count"] * r["ms"])[:6]
+        out["roofline"]["top_shapes"] = [dict(M=r["M"], N=r["N"], K=r["K"], akm=r["akm"], bkm=r["bkm"], count=r["count"],
+                                              us=round(r["ms"] * 1e3, 1), tflops=round(r["gflop"] / r["ms"], 1)) for r in worst]
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

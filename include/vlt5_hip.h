@@ -1,0 +1,237 @@
+/* vlt5_hip.h -- C ABI of libvlt5_hip.so, the MI355X (gfx950) kernels for the VQACL VL-T5 hot path.
+ *
+ * The reference (zhangxi1997/VQACL) is pure Python and has no FFI of its own: every entry point
+ * here replaces the eager PyTorch op sequence named next to it (paths relative to the reference's
+ * VL-T5/ directory; "HF" = transformers 4.2.1 models/t5/modeling_t5.py, the pinned dependency).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (the engine never allocates); `stream` is a hipStream_t passed as void*.
+ *   - all functions are stream-ordered and re-entrant; no global state; one stream per calling thread.
+ *   - return 0 on success, VLT5_ERR_* for argument errors, otherwise the hipError_t of the launch.
+ *     Nothing throws across the ABI.
+ *   - "bf16" tensors are raw 16-bit bfloat16; contiguous (feature) dimensions must be multiples of 8.
+ */
+#ifndef VLT5_HIP_H
+#define VLT5_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLT5_OK 0
+#define VLT5_ERR_ARG 1001
+#define VLT5_ERR_ALIGN 1002
+#define VLT5_ABI_VERSION 1
+
+int vlt5_abi_version(void);
+
+/* ---- GEMM: C[M,N] = epi(alpha * sum_k A[m,k] B[n,k]) -------------------------------------------
+ * replaces nn.Linear in T5Attention q/k/v/o (HF T5Attention.forward), T5DenseReluDense wi/wo,
+ * VisualEmbedding.feat_embedding[0] (src/modeling_t5_our.py:107), lm_head (:671) and, with the
+ * k-major flags, their autograd dgrad / wgrad matmuls (src/vqacl.py:461 loss.backward()). */
+typedef struct {
+    const void* A; const void* B; void* C;   /* A,B bf16; C bf16 or f32 (out_f32) */
+    int M, N, K;
+    int lda, ldb, ldc;                       /* leading dimensions in elements */
+    int a_kmajor, b_kmajor;                  /* 0: element (r,k) at r*ld+k ; 1: at k*ld+r */
+    float alpha;
+    const float* bias;                       /* [N] or NULL */
+    const float* resid; int ldr;             /* f32 [M,ldr] added after dropout, or NULL */
+    const void* gate; int ldg; float gate_scale; /* bf16 [M,ldg]: v = gate>0 ? v*gate_scale : 0 */
+    float drop_p; uint32_t drop_seed;        /* inverted dropout on element index m*N+n */
+    int relu, out_f32, accum;                /* accum: C += (f32 only) */
+    int split_k; void* workspace;            /* split_k>1: f32 slabs [split_k][M*ldc], plain epilogue, ldc==N */
+    int tile_m, tile_n;                      /* 0 = heuristic; else 64 or 128 */
+} vlt5_gemm_desc;
+int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream);
+long long vlt5_gemm_workspace_bytes(int M, int ldc, int split_k);
+
+/* ---- T5LayerNorm (RMS, no mean, no bias): HF T5LayerNorm.forward ------------------------------
+ * y = x * rsqrt(mean(x^2)+eps) * w, statistics in f32.  Optional inverted dropout on y
+ * (encoder/decoder final norm, src/modeling_t5_our.py:314-315).  Output row r is written at row
+ * (r / out_group) * out_group_stride + r % out_group  (out_group = 0: same row). */
+int vlt5_layernorm_fwd(const float* x, const float* w, void* y_bf16, float* y_f32, float* rstd,
+                       int rows, int d, float eps, float drop_p, uint32_t drop_seed,
+                       int out_group, int out_group_stride, void* stream);
+/* dx (+)= d/dx, dw = sum_rows; dy row r is read at the remapped row as above (in_group*).
+ * dw_partial: scratch f32 [vlt5_layernorm_bwd_blocks(rows)][d]. */
+int vlt5_layernorm_bwd(const float* dy, const float* x, const float* w, const float* rstd,
+                       float* dx, float* dw, float* dw_partial, int rows, int d,
+                       int accum_dx, int accum_dw, float drop_p, uint32_t drop_seed,
+                       int in_group, int in_group_stride, void* stream);
+int vlt5_layernorm_bwd_blocks(int rows);
+
+/* ---- attention core: softmax(q k^T + bias + masks) v ------------------------------------------
+ * replaces the matmul/softmax/dropout/matmul of HF T5Attention.forward (NO 1/sqrt(d) scaling;
+ * softmax in f32) for the encoder self-attention (src/modeling_t5_our.py:258-293), the decoder
+ * causal self-attention and the decoder cross-attention over the 58 encoder tokens (:641-655).
+ * One workgroup per (batch, head); Tq, Tk <= 64, dk <= 64. */
+typedef struct {
+    const void *q, *k, *v;                   /* bf16; head h of token t of sample b at b*sb + t*st + h*dk */
+    long long q_sb, q_st, k_sb, k_st, v_sb, v_st;
+    void* ctx; long long o_sb, o_st;         /* bf16 out (fwd) */
+    float* lse;                              /* f32 [B,H,Tq]: row max + log row sum (saved for bwd) */
+    const float* bias; int bias_q, bias_k;   /* f32 [H,bias_q,bias_k] added where i<bias_q && j<bias_k; NULL = none */
+    const float* key_mask; float mask_value; /* f32 [B,Tk] 1=keep 0=pad -> adds (1-m)*mask_value (-1e4 / -1e9) */
+    int causal;                              /* adds -1e4 where j > i (HF 4.2.1 extended causal mask) */
+    int B, H, Tq, Tk, dk;
+    float drop_p; uint32_t drop_seed;        /* dropout on the probabilities */
+    /* backward only */
+    const void* d_ctx; long long do_sb, do_st;
+    void *dq, *dk_, *dv; long long dq_sb, dq_st, dk_sb, dk_st, dv_sb, dv_st;
+    float* dbias;                            /* f32 [B,H,bias_q,bias_k] (per-sample dS block) or NULL */
+} vlt5_attn_desc;
+int vlt5_attn_fwd(const vlt5_attn_desc* d, void* stream);
+int vlt5_attn_bwd(const vlt5_attn_desc* d, void* stream);
+
+/* ---- relative position bias: HF T5Attention.compute_bias / _relative_position_bucket ---------
+ * The integer bucket table lut[Lq*Lk] is computed on the host (vqacl_amd/buckets.py, bit-exact
+ * with the library); the kernel gathers table[lut[i,j], h] into bias[h,i,j]. */
+int vlt5_relbias_build(const float* table, const int* lut, float* bias, int H, int Lq, int Lk, int nbuckets, void* stream);
+/* dtable[bucket,h] (+)= sum over nmat matrices and positions of dS[mat,h,i,j];  scratch f32 [H*Lq*Lk] */
+int vlt5_relbias_bwd(const float* dS, const int* lut, float* dtable, float* scratch, int nmat, int H, int Lq, int Lk,
+                     int nbuckets, int accum, void* stream);
+
+/* ---- embeddings --------------------------------------------------------------------------------
+ * token gather: embed_tokens(input_ids) (src/modeling_t5_our.py:196) / decoder embed of the
+ * shifted labels, plus the stack's input dropout (:247).  Row (b,t) goes to out + b*out_sb + t*out_st;
+ * the dropout index is ((b*drop_rows + drop_row0 + t)*d + c). */
+int vlt5_embed_fwd(const long long* ids, const float* table, float* out, long long out_sb, long long out_st,
+                   int B, int T, int d, int vocab, float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* stream);
+int vlt5_embed_bwd(const long long* ids, const float* dout, long long sb, long long st, float* dtable,
+                   int B, int T, int d, int vocab, float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* stream);
+/* labels -> decoder input ids (HF _shift_right, called at src/modeling_t5_our.py:620) */
+int vlt5_shift_right(const long long* labels, long long* out, int B, int T, int start_id, int pad_id, void* stream);
+/* f32 [B,S] encoder mask: 1 where input_ids != pad for the L text columns, 1 for the rest (:225-232, :631-638) */
+int vlt5_build_mask(const long long* ids, float* mask, int B, int L, int S, int pad_id, void* stream);
+
+/* ---- VisualEmbedding.forward (src/modeling_t5_our.py:93-143) after the 2048->d projection ------
+ * out[b, row0+i] = drop( LN(G[b,i]) + LN(Wp [box,area] + bp) + img_order[0] + shared[vocab-1-i] )
+ * "area" reads the box columns as (x1,x2,y1,y2) exactly like get_area (:78-90). */
+int vlt5_vis_embed_fwd(const float* G, const float* boxes, const float* Wp, const float* bp, const float* lnf_w,
+                       const float* lnp_w, const float* img0, const float* shared, float* out, long long out_sb,
+                       long long out_st, float* rstd_f, float* rstd_p, int B, int V, int d, int vocab, float eps,
+                       float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* stream);
+/* dG bf16 [B*V,d] (input of the projection's wgrad GEMM); parameter grads via per-split partials:
+ * partial f32 [nsplit = vlt5_vis_embed_bwd_blocks(B*V)][10*d] laid out per split as
+ * [dlnf_w d | dlnp_w d | dbp d | dWp d*5 (row-major [d][5]) | dimg0 d | dbf d], followed by 2*B*V floats of scratch;
+ * reduce with vlt5_colsum(partial, out, nsplit, 10*d).  dshared rows vocab-1-i are accumulated (+=) in a fixed order. */
+int vlt5_vis_embed_bwd(const float* dout, long long sb, long long st, const float* G, const float* boxes, const float* Wp,
+                       const float* bp, const float* lnf_w, const float* lnp_w, const float* rstd_f, const float* rstd_p,
+                       void* dG_bf16, float* partial, float* dshared, int B, int V, int d, int vocab,
+                       float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* stream);
+int vlt5_vis_embed_bwd_blocks(int rows);
+/* out[c] (+)= sum_blk partial[blk*row_stride + c], c < width  (fixed summation order) */
+int vlt5_colsum(const float* partial, float* out, int nblk, int width, int row_stride, int accum, void* stream);
+
+/* ---- lm_head cross-entropy (src/modeling_t5_our.py:680-686) and the train_step reduction
+ *      (src/vqa_model.py:46-54) ----------------------------------------------------------------- */
+int vlt5_ce_fwd(const float* logits, const long long* labels, float* loss_tok, float* lse, int R, int V, void* stream);
+/* loss = mean_b( score_b * sum_t CE_bt m_bt / max(sum_t m_bt,1) );  row_w[b,t] = d loss / d CE_bt */
+int vlt5_loss_reduce(const float* loss_tok, const long long* labels, const float* scores, float* loss, float* row_w,
+                     int B, int T, void* stream);
+/* dlogits[r,:] = (softmax(logits[r]) - onehot(label_r)) * row_w[r] * (*gout or 1), bf16, 0 for ignored rows */
+int vlt5_ce_bwd(const float* logits, const long long* labels, const float* lse, const float* row_w, const float* gout,
+                void* dlogits_bf16, int R, int V, void* stream);
+
+/* ---- SS/SI prototype head (src/modeling_t5_our.py:434-511, :583-615) -------------------------- */
+/* mean over tokens [0,min(split,S)) -> poolQ, [split,S) -> poolV   (hidden f32, sample b at hidden + b*sb, rows of d) */
+int vlt5_proto_pool(const float* hidden, long long sb, int B, int S, int d, int split, float* poolQ, float* poolV, void* stream);
+/* calculate_current_prototype: proto[c] = sum_b onehot[b,c] pool[b] / max(cnt_c,1), cnt = sum_b onehot */
+int vlt5_proto_class_mean(const float* pool, const float* onehot, float* proto, float* cnt, int B, int C, int d, void* stream);
+/* update_prototype state machine, all branches; see vqacl_amd/prototype.py for the host side.
+ * first: 1 on the first batch of `task`.  qmem: this task's memory tensor [CQ,d] (NULL when task==0). */
+int vlt5_proto_update(const float* curQ, const float* curV, const float* numQ, const float* numV, float* Qproto,
+                      float* Vproto, float* Qnum, float* Vnum, float* qmem, int qmem_initialised, int first, int task,
+                      float alpha, float beta, int CQ, int CV, int d, void* stream);
+/* cosine_similarity_multi + gather: idx[b] = argmax_c cos(tanh P_c, tanh pool_b) (first max wins);
+ * the selected row is written as f32 (out_f32 + b*sb, may be NULL) and bf16 (out_bf16 + b*sb_bf16, may be NULL) */
+int vlt5_proto_retrieve(const float* protos, const float* pool, long long* idx, float* out_f32, long long sb,
+                        void* out_bf16, long long sb_bf16, int B, int C, int d, void* stream);
+/* memory_loss (nextqa/modeling_t5_nextqa.py:544-555): out[0] = mean_b ||pool_b - (onehot P)_b||^2 */
+int vlt5_proto_memory_loss(const float* pool, const float* onehot, const float* protos, float* out, int B, int C, int d, void* stream);
+
+/* ---- optimizer: clip_grad_norm_(5) + HF AdamW (src/vqacl.py:466-487, src/trainer_base.py:187-190) */
+int vlt5_sqnorm(const float* g, long long n, float* partial, float* total_sq, int accum_total, void* stream);
+int vlt5_sqnorm_blocks(long long n);
+/* p,m,v f32; optional bf16 shadow of p.  clip coefficient = min(1, max_norm / (sqrt(*total_sq) + 1e-6)) when
+ * total_sq != NULL.  hf_mode 1: transformers AdamW (eps outside bias correction, decay after the update, on the
+ * updated value); 0: torch.optim.AdamW ordering. */
+int vlt5_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, const float* total_sq, float max_norm,
+                    int hf_mode, void* stream);
+int vlt5_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);
+int vlt5_scale_add(float* dst, const float* src, float a, float b, long long n, void* stream); /* dst = a*dst + b*src */
+
+/* dst_bf16 = dropout(src) (inverted, element index r*cols+c) cast to bf16; the bf16 operand of the backward GEMMs */
+int vlt5_drop_cast(const float* src, void* dst_bf16, long long rows, int cols, float drop_p, uint32_t drop_seed, void* stream);
+
+/* ================================================================================================
+ * Whole-path engine: VLT5.forward / backward (src/modeling_t5_our.py:514-713, src/vqacl.py:461)
+ * composed from the kernels above, one C call per phase so the host does O(1) work per step.
+ *
+ *   vlt5_encoder_fwd   JointEncoder.forward (:175-339)            -> enc_out f32 [B,S,d], enc_ext bf16 rows 0..S-1
+ *   (host: SS/SI prototype head, vqacl_amd/prototype.py, writes rows S, S+1 of enc_ext)
+ *   vlt5_decoder_fwd   shift-right, decoder T5Stack (:641-655), rescale + lm_head + CE (:661-686),
+ *                      train_step loss reduction (src/vqa_model.py:46-54)
+ *   vlt5_decoder_bwd / vlt5_encoder_bwd   the autograd backward of the above into the flat grad buffer
+ *
+ * Parameters live in ONE flat f32 buffer (+ a bf16 shadow with identical offsets, + a flat f32 gradient
+ * buffer); vlt5_layout_* describes it with the reference's state_dict names, ordered so that gradients
+ * complete front-to-back during backward (contiguous all-reduce buckets for data parallelism).
+ * ================================================================================================ */
+typedef struct {
+    int d_model, d_kv, num_heads, d_ff, num_layers, num_decoder_layers, vocab;
+    int rel_buckets, feat_dim, n_images;
+    int pad_id, dec_start_id;
+    int n_ques, n_cate;            /* prototype classes (10 question types, 80 categories) */
+    float eps, dropout;
+} vlt5_config;
+
+typedef struct {
+    int B, L, V, T;                /* batch, text tokens, visual tokens, answer tokens */
+    int training;                  /* 1: dropout active */
+    uint32_t seed;                 /* dropout base seed of this step */
+    const float* params;           /* flat f32 master parameters */
+    const void* params_bf16;       /* flat bf16 shadow, same element offsets */
+    float* grads;                  /* flat f32 gradients (backward only) */
+    void* workspace; long long workspace_bytes;
+    const float* vis_feats;        /* [B,V,feat_dim] */
+    const float* boxes;            /* [B,V,4] */
+    const long long* input_ids;    /* [B,L] */
+    const long long* labels;       /* [B,T], -100 = ignore */
+    const float* scores;           /* [B] answer scores, or NULL: skip the fused train_step reduction */
+    const int* enc_lut;            /* [L*L] bidirectional bucket ids */
+    const int* dec_lut;            /* [T*T] causal bucket ids */
+    const float* gout;             /* [1] upstream gradient of the reduced loss or NULL (=1); used when d_loss_tok == NULL */
+    const float* d_loss_tok;       /* [B*T] upstream gradient of the per-token loss (generic VLT5.forward path) or NULL */
+    void** events; int n_events;   /* optional hipEvent_t recorded when a gradient bucket is complete (backward) */
+} vlt5_step;
+
+/* parameter layout */
+int vlt5_layout_count(const vlt5_config* c);
+/* name_cap >= 128.  bucket: index of the gradient bucket (0 = first complete in backward); decay: 1 if the
+ * reference's optimizer grouping applies weight decay (src/trainer_base.py:148-161); used: 0 for prototype_fc* */
+int vlt5_layout_get(const vlt5_config* c, int i, char* name, int name_cap, long long* offset, int* rows, int* cols,
+                    int* bucket, int* decay, int* used);
+long long vlt5_layout_total(const vlt5_config* c);
+int vlt5_layout_buckets(const vlt5_config* c);
+
+/* workspace */
+long long vlt5_workspace_bytes(const vlt5_config* c, int B, int L, int V, int T);
+enum { VLT5_WS_ENC_OUT = 0, VLT5_WS_ENC_EXT = 1, VLT5_WS_LOGITS = 2, VLT5_WS_LOSS_TOK = 3, VLT5_WS_LOSS = 4,
+       VLT5_WS_ENC_MASK_EXT = 5, VLT5_WS_DEC_OUT = 6 };
+long long vlt5_workspace_offset(const vlt5_config* c, int B, int L, int V, int T, int which);   /* byte offset, -1 = unknown */
+
+int vlt5_encoder_fwd(const vlt5_config* c, const vlt5_step* s, void* stream);
+int vlt5_decoder_fwd(const vlt5_config* c, const vlt5_step* s, void* stream);
+int vlt5_decoder_bwd(const vlt5_config* c, const vlt5_step* s, void* stream);
+int vlt5_encoder_bwd(const vlt5_config* c, const vlt5_step* s, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,477 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (vqacl_amd.ops / ctypes).
+
+Checker: the CPU oracle (oracle/ref_cpu.py) and plain fp32 torch math on the same seeded inputs.  bf16 operands are
+rounded BEFORE the reference computation, so the only differences left are accumulation order and the bf16 rounding
+of outputs; tolerances are written next to each check.
+"""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    from vqacl_amd import _lib
+    _lib.lib()                      # fails loudly if libvlt5_hip.so is missing
+    return torch.device("cuda")
+
+
+def rnd(shape, g, scale=1.0):
+    return torch.randn(shape, generator=g) * scale
+
+
+def close(a, b, rtol, atol, what=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max err {float(err.max()):.4g} "
+                                 f"at ref {float(b.flatten()[err.flatten().argmax()]):.4g}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", [(0, 0), (128, 128), (128, 64), (64, 128), (64, 64)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (400, 768, 768), (20, 64, 64), (4480, 768, 768), (136, 2304, 200)])
+def test_gemm_forward_layout(dev, tile, M, N, K):
+    from vqacl_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = rnd((M, K), g).to(BF)
+    # asymmetric B so a transposed C-write cannot pass
+    B = (rnd((N, K), g) + torch.arange(N)[:, None] * 0.01).to(BF)
+    ref = A.float() @ B.float().t()
+    out = ops.gemm(A.to(dev), B.to(dev), M, N, K, out_f32=True, tile=tile)
+    close(out, ref, 2e-3, 2e-2, "gemm NT f32")
+    outb = ops.gemm(A.to(dev), B.to(dev), M, N, K, tile=tile)
+    close(outb, ref, 1e-2, 5e-2, "gemm NT bf16")
+
+
+@pytest.mark.parametrize("tile", [(128, 128), (64, 64), (0, 0)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 256), (400, 768, 2304), (4480, 768, 3072), (24, 64, 128)])
+def test_gemm_dgrad_layout(dev, tile, M, N, K):
+    """dX[M,N] = dY[M,K] W[K,N]: the weight is read k-major."""
+    from vqacl_amd import ops
+    g = torch.Generator().manual_seed(11 + M + N + K)
+    dY = rnd((M, K), g).to(BF)
+    W = (rnd((K, N), g) * 0.1 + torch.arange(N)[None, :] * 0.003).to(BF)
+    ref = dY.float() @ W.float()
+    out = ops.gemm(dY.to(dev), W.to(dev), M, N, K, b_kmajor=True, out_f32=True, tile=tile)
+    close(out, ref, 2e-3, 3e-2, "gemm dgrad")
+
+
+@pytest.mark.parametrize("tile", [(128, 128), (64, 64), (0, 0)])
+@pytest.mark.parametrize("rows,N,K", [(256, 128, 64), (400, 768, 768), (4480, 768, 768), (20, 64, 128), (2880, 768, 2048)])
+def test_gemm_wgrad_layout(dev, tile, rows, N, K):
+    """dW[N,K] = dY[rows,N]^T X[rows,K]: both operands read k-major, reduction over the rows."""
+    from vqacl_amd import ops
+    g = torch.Generator().manual_seed(13 + rows + N + K)
+    dY = (rnd((rows, N), g) + torch.arange(N)[None, :] * 0.01).to(BF)
+    X = rnd((rows, K), g).to(BF)
+    ref = dY.float().t() @ X.float()
+    out = ops.gemm(dY.to(dev), X.to(dev), N, K, rows, a_kmajor=True, b_kmajor=True, out_f32=True, tile=tile)
+    close(out, ref, 3e-3, 0.15 if rows > 1000 else 5e-2, "gemm wgrad")
+    if rows >= 2048:
+        out2 = ops.gemm(dY.to(dev), X.to(dev), N, K, rows, a_kmajor=True, b_kmajor=True, out_f32=True, tile=tile, split_k=4)
+        close(out2, ref, 3e-3, 0.15, "gemm wgrad split-k")
+        acc0 = torch.ones(N, K, device=dev)
+        out3 = ops.gemm(dY.to(dev), X.to(dev), N, K, rows, a_kmajor=True, b_kmajor=True, out=acc0.clone(), accum=True, tile=tile,
+                        split_k=3)
+        close(out3, ref + 1.0, 3e-3, 0.15, "gemm wgrad split-k accumulate")
+
+
+def test_gemm_epilogues(dev):
+    from vqacl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 200, 192, 128
+    A, B = rnd((M, K), g).to(BF), rnd((N, K), g).to(BF)
+    bias, resid = rnd((N,), g), rnd((M, N), g)
+    base = A.float() @ B.float().t()
+    out = ops.gemm(A.to(dev), B.to(dev), M, N, K, out_f32=True, alpha=0.5, bias=bias.to(dev), relu=True, resid=resid.to(dev))
+    close(out, torch.relu(0.5 * base + bias) + resid, 2e-3, 2e-2, "alpha+bias+relu+resid")
+    gate = rnd((M, N), g).to(BF)
+    out = ops.gemm(A.to(dev), B.to(dev), M, N, K, out_f32=True, gate=gate.to(dev), gate_scale=1.25)
+    close(out, torch.where(gate.float() > 0, base * 1.25, torch.zeros_like(base)), 2e-3, 2e-2, "gate")
+    acc = torch.full((M, N), 2.0, device=dev)
+    out = ops.gemm(A.to(dev), B.to(dev), M, N, K, out=acc, accum=True)
+    close(out, base + 2.0, 2e-3, 2e-2, "accumulate")
+
+
+def test_gemm_dropout_epilogue_statistics_and_determinism(dev):
+    from vqacl_amd import ops
+    g = torch.Generator().manual_seed(6)
+    M, N, K = 512, 768, 64
+    A, B = rnd((M, K), g).to(BF).to(dev), rnd((N, K), g).to(BF).to(dev)
+    base = ops.gemm(A, B, M, N, K, out_f32=True)
+    d1 = ops.gemm(A, B, M, N, K, out_f32=True, drop_p=0.1, drop_seed=1234, tile=(128, 128))
+    d2 = ops.gemm(A, B, M, N, K, out_f32=True, drop_p=0.1, drop_seed=1234, tile=(64, 64))
+    d3 = ops.gemm(A, B, M, N, K, out_f32=True, drop_p=0.1, drop_seed=99)
+    assert torch.equal(d1 == 0, d2 == 0), "mask must not depend on the tiling"
+    frac = float((d1 == 0).float().mean())
+    assert abs(frac - 0.1) < 0.005, frac
+    assert float(((d1 == 0) != (d3 == 0)).float().mean()) > 0.1, "different seeds give different masks"
+    kept = d1 != 0
+    close(d1[kept], base[kept] / 0.9, 1e-3, 1e-3, "kept values are scaled by 1/(1-p)")
+
+
+def test_gemm_rejects_bad_arguments(dev):
+    from vqacl_amd import ops, _lib
+    A = torch.zeros(16, 12, dtype=BF, device=dev)
+    with pytest.raises(_lib.Vlt5Error):
+        ops.gemm(A, A, 16, 16, 12)           # K not a multiple of 8
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# layernorm
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,d", [(4480, 768), (400, 768), (37, 64), (128, 1024)])
+def test_layernorm_fwd_bwd(dev, rows, d):
+    from vqacl_amd import ops
+    from oracle import ref_cpu as R
+    g = torch.Generator().manual_seed(rows + d)
+    x = rnd((rows, d), g, 3.0).requires_grad_(True)
+    w = (1.0 + 0.3 * rnd((d,), g)).requires_grad_(True)
+    y = R.t5_layernorm(x, w, 1e-6)
+    gy = rnd((rows, d), g)
+    y.backward(gy)
+    yb, yf, rstd = ops.layernorm_fwd(x.detach().to(dev), w.detach().to(dev), want_f32=True)
+    close(yf, y, 1e-5, 1e-5, "ln f32")
+    close(yb, y, 1e-2, 1e-2, "ln bf16")
+    dx, dw = ops.layernorm_bwd(gy.to(dev), x.detach().to(dev), w.detach().to(dev), rstd)
+    close(dx, x.grad, 1e-4, 1e-5, "ln dx")
+    close(dw, w.grad, 1e-4, 1e-3, "ln dw")
+    dx2, _ = ops.layernorm_bwd(gy.to(dev), x.detach().to(dev), w.detach().to(dev), rstd, dx=torch.ones(rows, d, device=dev))
+    close(dx2, x.grad + 1.0, 1e-4, 1e-5, "ln dx accumulate")
+
+
+def test_layernorm_golden(dev):
+    from vqacl_amd import ops
+    G = load_golden("g3_hf_leaves")
+    x, w = G["ln_x"].reshape(-1, 64), G["ln_w"]
+    yb, yf, rstd = ops.layernorm_fwd(x.to(dev), w.to(dev), want_f32=True)
+    close(yf, G["ln_y"].reshape(-1, 64), 1e-5, 1e-5, "ln vs HF")
+    dx, dw = ops.layernorm_bwd(G["ln_gy"].reshape(-1, 64).to(dev), x.to(dev), w.to(dev), rstd)
+    close(dx, G["ln_gx"].reshape(-1, 64), 1e-4, 1e-5, "ln dx vs HF")
+    close(dw, G["ln_gw"], 1e-4, 1e-4, "ln dw vs HF")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# attention core
+# ---------------------------------------------------------------------------------------------------------------
+def attn_ref(q, k, v, H, dk, bias_full):
+    """fp32 reference on bf16-rounded q,k,v: returns ctx and grads via autograd."""
+    B, Tq = q.shape[:2]
+    Tk = k.shape[1]
+    qh = q.view(B, Tq, H, dk).transpose(1, 2)
+    kh = k.view(B, Tk, H, dk).transpose(1, 2)
+    vh = v.view(B, Tk, H, dk).transpose(1, 2)
+    s = qh @ kh.transpose(2, 3) + bias_full
+    p = torch.softmax(s, dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(B, Tq, H * dk)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,dk,mode", [(3, 12, 56, 56, 64, "enc"), (2, 4, 48, 48, 16, "enc"), (5, 12, 5, 5, 64, "causal"),
+                                               (4, 12, 5, 58, 64, "cross"), (2, 4, 7, 14, 16, "cross"), (2, 16, 64, 64, 64, "enc"),
+                                               (2, 4, 10, 10, 32, "causal")])
+def test_attention_fwd_bwd(dev, B, H, Tq, Tk, dk, mode):
+    from vqacl_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + Tq + Tk + dk)
+    inner = H * dk
+    q = rnd((B, Tq, inner), g, 0.5).to(BF).float().requires_grad_(True)
+    k = rnd((B, Tk, inner), g, 0.5).to(BF).float().requires_grad_(True)
+    v = rnd((B, Tk, inner), g).to(BF).float().requires_grad_(True)
+    bias = key_mask = None
+    bias_full = torch.zeros(B, H, Tq, Tk)
+    mask_value, causal = -10000.0, False
+    if mode == "enc":
+        Lb = min(20, Tq - 4)
+        bias = rnd((H, Lb, Lb), g).requires_grad_(True)
+        pad = torch.zeros(B, H, Tq, Tk)
+        pad[:, :, :Lb, :Lb] = 1
+        bias_full = torch.zeros(B, H, Tq, Tk)
+        bias_full[:, :, :Lb, :Lb] = bias
+        key_mask = torch.ones(B, Tk)
+        key_mask[0, 3:Lb] = 0
+        bias_full = bias_full + (1 - key_mask)[:, None, None, :] * -10000.0
+    elif mode == "causal":
+        bias = rnd((H, Tq, Tk), g).requires_grad_(True)
+        bias_full = bias[None] + (1 - torch.tril(torch.ones(Tq, Tk)))[None, None] * -10000.0
+        causal = True
+    else:
+        key_mask = torch.ones(B, Tk)
+        key_mask[0, 2:5] = 0
+        mask_value = -1e9
+        bias_full = ((1 - key_mask)[:, None, None, :] * -1e9).expand(B, H, Tq, Tk)
+    ref = attn_ref(q, k, v, H, dk, bias_full)
+    go = rnd(ref.shape, g).to(BF).float()
+    ref.backward(go)
+    D = lambda t: None if t is None else t.detach().to(dev)
+    qd, kd, vd = D(q).to(BF), D(k).to(BF), D(v).to(BF)
+    ctx, lse = ops.attn_fwd(qd, kd, vd, H, dk, bias=D(bias), key_mask=D(key_mask), mask_value=mask_value, causal=causal)
+    close(ctx, ref, 1e-2, 1e-2, f"attention fwd {mode}")
+    dq, dk_, dv, dbias = ops.attn_bwd(qd, kd, vd, go.to(BF).to(dev), lse, H, dk, bias=D(bias), key_mask=D(key_mask),
+                                      mask_value=mask_value, causal=causal, want_dbias=True)
+    close(dq, q.grad, 2e-2, 2e-2, f"attention dq {mode}")
+    close(dk_, k.grad, 2e-2, 2e-2, f"attention dk {mode}")
+    close(dv, v.grad, 2e-2, 2e-2, f"attention dv {mode}")
+    if bias is not None:
+        close(dbias.sum(0), bias.grad, 2e-2, 3e-2, f"attention dbias {mode}")
+
+
+def test_attention_strided_qkv_and_dropout(dev):
+    """q,k,v as slices of one fused [B,T,3*inner] projection (the layout the engine uses); dropout mask consistency."""
+    from vqacl_amd import ops
+    g = torch.Generator().manual_seed(77)
+    B, H, T, dk = 4, 12, 56, 64
+    inner = H * dk
+    qkv = rnd((B, T, 3 * inner), g, 0.5).to(BF).to(dev)
+    q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
+    ctx, lse = ops.attn_fwd(q, k, v, H, dk)
+    ref = attn_ref(q.float().cpu().contiguous(), k.float().cpu().contiguous(), v.float().cpu().contiguous(), H, dk, torch.zeros(B, H, T, T))
+    close(ctx, ref, 1e-2, 1e-2, "strided qkv")
+    # dropout: E[ctx_drop] == ctx ; with V = ones every output equals the kept probability mass
+    ones = torch.ones(B, T, inner, dtype=BF, device=dev)
+    c1, _ = ops.attn_fwd(q, k, ones, H, dk, drop_p=0.1, drop_seed=42)
+    c2, _ = ops.attn_fwd(q, k, ones, H, dk, drop_p=0.1, drop_seed=42)
+    assert torch.equal(c1, c2)
+    m = float(c1.float().mean())
+    assert abs(m - 1.0) < 0.02, m
+    assert float(c1.float().std()) > 0.01
+
+
+@pytest.mark.parametrize("case", ["ea", "da", "ca"])
+def test_attention_layer_vs_hf_golden(dev, case):
+    """Whole T5Attention (q/k/v/o GEMMs + core) against the transformers-5.15 module outputs and gradients."""
+    from vqacl_amd import ops
+    from vqacl_amd.buckets import bucket_table
+    G = load_golden("g3_hf_leaves")
+    H, dk, d = 4, 16, 64
+    x = G[case + "_x"]
+    B, Tq, _ = x.shape
+    mem = G["ca_mem"] if case == "ca" else x
+    Tk = mem.shape[1]
+    W = {n: G[f"{case}_{n}"].to(BF).to(dev) for n in "qkvo"}
+    xb, mb = x.reshape(-1, d).to(BF).to(dev), mem.reshape(-1, d).to(BF).to(dev)
+    q = ops.gemm(xb, W["q"], B * Tq, H * dk, d).view(B, Tq, -1)
+    k = ops.gemm(mb, W["k"], B * Tk, H * dk, d).view(B, Tk, -1)
+    v = ops.gemm(mb, W["v"], B * Tk, H * dk, d).view(B, Tk, -1)
+    bias = key_mask = None
+    mask_value, causal = -10000.0, False
+    if case == "ea":
+        Lb = int(G["ea_L"])
+        lut = torch.from_numpy(bucket_table(Lb, Lb, True)).to(dev)
+        bias = ops.relbias_build(G["ea_rel"].to(dev), lut, H, Lb, Lb)
+        key_mask = G["ea_keymask"].to(dev)
+    elif case == "da":
+        lut = torch.from_numpy(bucket_table(Tq, Tq, False)).to(dev)
+        bias = ops.relbias_build(G["da_rel"].to(dev), lut, H, Tq, Tq)
+        causal = True
+    else:
+        key_mask, mask_value = G["ca_kmask"].to(dev), -1e9
+    ctx, lse = ops.attn_fwd(q, k, v, H, dk, bias=bias, key_mask=key_mask, mask_value=mask_value, causal=causal)
+    y = ops.gemm(ctx.view(-1, H * dk), W["o"], B * Tq, d, H * dk, out_f32=True).view(B, Tq, d)
+    close(y, G[case + "_y"], 3e-2, 3e-2, f"{case} layer output vs HF")
+    # backward
+    gy = G[case + "_gy"].reshape(-1, d).to(BF).to(dev)
+    dctx = ops.gemm(gy, W["o"], B * Tq, H * dk, d, b_kmajor=True).view(B, Tq, -1)
+    dWo = ops.gemm(gy, ctx.view(-1, H * dk), d, H * dk, B * Tq, a_kmajor=True, b_kmajor=True, out_f32=True)
+    close(dWo, G[f"{case}_go"], 3e-2, 3e-2, f"{case} dWo vs HF")
+    dq, dk_, dv, dbias = ops.attn_bwd(q, k, v, dctx, lse, H, dk, bias=bias, key_mask=key_mask, mask_value=mask_value,
+                                      causal=causal, want_dbias=True)
+    dWq = ops.gemm(dq.view(-1, H * dk), xb, H * dk, d, B * Tq, a_kmajor=True, b_kmajor=True, out_f32=True)
+    dWk = ops.gemm(dk_.view(-1, H * dk), mb, H * dk, d, B * Tk, a_kmajor=True, b_kmajor=True, out_f32=True)
+    dWv = ops.gemm(dv.view(-1, H * dk), mb, H * dk, d, B * Tk, a_kmajor=True, b_kmajor=True, out_f32=True)
+    close(dWq, G[f"{case}_gq"], 5e-2, 3e-2, f"{case} dWq vs HF")
+    close(dWk, G[f"{case}_gk"], 5e-2, 3e-2, f"{case} dWk vs HF")
+    close(dWv, G[f"{case}_gv"], 5e-2, 3e-2, f"{case} dWv vs HF")
+    if case in ("ea", "da"):
+        dtable = ops.relbias_bwd(dbias, lut, 32)
+        close(dtable, G[f"{case}_grel"], 5e-2, 3e-2, f"{case} rel-bias grad vs HF")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# integer / small kernels
+# ---------------------------------------------------------------------------------------------------------------
+def test_relbias_build_bit_exact(dev):
+    from vqacl_amd import ops
+    from vqacl_amd.buckets import bucket_table
+    from oracle import ref_cpu as R
+    g = torch.Generator().manual_seed(3)
+    table = rnd((32, 12), g)
+    for L, bi in ((20, True), (23, True), (10, False), (5, False)):
+        lut = torch.from_numpy(bucket_table(L, L, bi)).to(dev)
+        bias = ops.relbias_build(table.to(dev), lut, 12, L, L)
+        ref = R.compute_bias(table, L, L, bi, R.Cfg())[0]
+        assert torch.equal(bias.cpu(), ref), "a gather must be bit-exact"
+
+
+def test_shift_right_and_mask_bit_exact(dev):
+    from vqacl_amd._lib import lib, ptr, stream_ptr, check
+    G = load_golden("g4_integer_tables")
+    labels = G["labels"].to(dev)
+    out = torch.empty_like(labels)
+    check(lib().vlt5_shift_right(ptr(labels), ptr(out), labels.shape[0], labels.shape[1], 0, 0, stream_ptr()))
+    assert torch.equal(out.cpu(), G["shifted"])
+    ids = torch.tensor([[5, 6, 0, 0], [7, 0, 0, 0], [1, 2, 3, 4]], device=dev)
+    mask = torch.empty(3, 9, device=dev)
+    check(lib().vlt5_build_mask(ptr(ids), ptr(mask), 3, 4, 9, 0, stream_ptr()))
+    ref = torch.cat([(ids != 0).float().cpu(), torch.ones(3, 5)], dim=1)
+    assert torch.equal(mask.cpu(), ref)
+
+
+def test_cross_entropy_and_loss_reduction(dev):
+    from vqacl_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, T, V = 6, 5, 32200
+    logits = rnd((B * T, V), g, 2.0).requires_grad_(True)
+    labels = torch.randint(0, V, (B, T), generator=g)
+    labels[1, 3:] = -100
+    labels[3, :] = -100
+    scores = torch.tensor([1.0, 0.6, 0.0, 0.9, 0.3, 1.0])
+    ref_tok = torch.nn.functional.cross_entropy(logits, labels.view(-1), ignore_index=-100, reduction="none")
+    from oracle import ref_cpu as R
+    ref_loss = R.train_step_loss(ref_tok, labels, scores)
+    ref_loss.backward()
+    tok, lse = ops.ce_fwd(logits.detach().to(dev), labels.view(-1).to(dev))
+    close(tok, ref_tok, 1e-5, 1e-5, "per-token CE")
+    loss, row_w = ops.loss_reduce(tok, labels.to(dev), scores.to(dev))
+    close(loss, ref_loss.reshape(1), 1e-5, 1e-6, "reduced loss")
+    dl = ops.ce_bwd(logits.detach().to(dev), labels.view(-1).to(dev), lse, row_w)
+    close(dl, logits.grad, 1e-2, 1e-6, "dlogits")
+    G = load_golden("g5_loss_reduction")
+    loss, _ = ops.loss_reduce(G["loss_tok"].to(dev), G["labels"].to(dev), G["scores"].to(dev))
+    assert abs(float(loss) - float(G["expected"])) < 1e-6
+
+
+def test_prototype_head_vs_reference_golden(dev):
+    """The scripted task sequence of the reference's own prototype code: state and INTEGER indices."""
+    from vqacl_amd.prototype import PrototypeHead
+    from vqacl_amd import ops
+    G = load_golden("g2_prototype_sequence")
+    head = PrototypeHead(10, 80, 768, dev)
+    for step, task in enumerate(G["tasks"].tolist()):
+        h = G[f"s{step}_hidden"].to(dev)
+        B, S, d = h.shape
+        ext = torch.zeros(B, S + 2, d, device=dev)
+        ext[:, :S] = h
+        ext16 = torch.zeros(B, S + 2, d, device=dev, dtype=BF)
+        pq, pv = ops.proto_pool(ext, S, 20)
+        close(pq, G[f"s{step}_hidden"][:, :20].mean(1), 1e-6, 1e-6, "poolQ")
+        close(pv, G[f"s{step}_hidden"][:, 20:].mean(1), 1e-6, 1e-6, "poolV")
+        ql, cl = G[f"s{step}_ques"].to(dev), G[f"s{step}_cate"].to(dev)
+        if step > 0:
+            lq, lv = head.memory_loss(pq, pv, ql, cl)
+            close(torch.cat([lq, lv]), G[f"s{step}_memloss"], 1e-5, 1e-5, "memory loss")
+        curQ, curV = head.update(pq, pv, ql, cl, task, float(G["alpha"]), float(G["beta"]))
+        close(curQ, G[f"s{step}_curQ"], 1e-6, 1e-6, "current Q prototypes")
+        close(head.Q_prototype, G[f"s{step}_Qproto"], 1e-6, 1e-6, f"Q_prototype step {step}")
+        close(head.V_prototype, G[f"s{step}_Vproto"], 1e-6, 1e-6, f"V_prototype step {step}")
+        assert torch.equal(head.Q_prototype_num.cpu(), G[f"s{step}_Qnum"])
+        assert torch.equal(head.V_prototype_num.cpu(), G[f"s{step}_Vnum"])
+        iq, iv = head.retrieve(pq, pv, ext, ext16, S)
+        assert torch.equal(iq.cpu(), G[f"s{step}_idxQ"]), f"Q indices step {step}"
+        assert torch.equal(iv.cpu(), G[f"s{step}_idxV"]), f"V indices step {step}"
+        close(ext[:, S], G[f"s{step}_retQ"], 1e-6, 1e-6, "retrieved Q row")
+        close(ext16[:, S + 1], G[f"s{step}_retV"], 1e-2, 1e-2, "retrieved V row bf16")
+
+
+@pytest.mark.parametrize("tag,d,fd,vocab", [("tiny", 64, 64, 400), ("mid", 128, 256, 512)])
+def test_visual_embedding_vs_reference_golden(dev, tag, d, fd, vocab):
+    from vqacl_amd import ops
+    from vqacl_amd._lib import lib, ptr, stream_ptr, check
+    G = load_golden(f"g1_visual_embedding_{tag}")
+    feats, boxes = G["feats"], G["boxes"]
+    B, V, _ = feats.shape
+    Wf, bf_ = G["feat_embedding__0__weight"], G["feat_embedding__0__bias"]
+    P = {k: G[k].to(dev) for k in ("feat_embedding__1__weight", "absolute_vis_pos_embedding__0__weight",
+                                   "absolute_vis_pos_embedding__0__bias", "absolute_vis_pos_embedding__1__weight",
+                                   "img_order_embedding__weight", "shared")}
+    fb = feats.reshape(-1, fd).to(BF).to(dev)
+    Gm = ops.gemm(fb, Wf.to(BF).to(dev), B * V, d, fd, out_f32=True, bias=bf_.to(dev))
+    out = torch.zeros(B, V, d, device=dev)
+    rf, rp = torch.empty(B * V, device=dev), torch.empty(B * V, device=dev)
+    bx = boxes.contiguous().to(dev)
+    check(lib().vlt5_vis_embed_fwd(ptr(Gm), ptr(bx), ptr(P["absolute_vis_pos_embedding__0__weight"]),
+                                   ptr(P["absolute_vis_pos_embedding__0__bias"]), ptr(P["feat_embedding__1__weight"]),
+                                   ptr(P["absolute_vis_pos_embedding__1__weight"]), ptr(P["img_order_embedding__weight"]),
+                                   ptr(P["shared"]), ptr(out), V * d, d, ptr(rf), ptr(rp), B, V, d, vocab, 1e-6, 0.0, 0, V, 0,
+                                   stream_ptr()))
+    close(out, G["out"], 2e-2, 3e-2, "visual embedding vs reference (bf16 projection)")
+    # backward
+    gout = G["gout"].contiguous().to(dev)
+    dG = torch.empty(B * V, d, device=dev, dtype=BF)
+    nsp = lib().vlt5_vis_embed_bwd_blocks(B * V)
+    partial = torch.zeros(nsp * 10 * d + 2 * B * V, device=dev)
+    dshared = torch.zeros(vocab, d, device=dev)
+    check(lib().vlt5_vis_embed_bwd(ptr(gout), V * d, d, ptr(Gm), ptr(bx), ptr(P["absolute_vis_pos_embedding__0__weight"]),
+                                   ptr(P["absolute_vis_pos_embedding__0__bias"]), ptr(P["feat_embedding__1__weight"]),
+                                   ptr(P["absolute_vis_pos_embedding__1__weight"]), ptr(rf), ptr(rp), ptr(dG), ptr(partial),
+                                   ptr(dshared), B, V, d, vocab, 0.0, 0, V, 0, stream_ptr()))
+    red = torch.empty(10 * d, device=dev)
+    check(lib().vlt5_colsum(ptr(partial), ptr(red), nsp, 10 * d, 10 * d, 0, stream_ptr()))
+    close(dshared, G["grad_shared"], 1e-4, 1e-4, "obj-order rows of d shared")
+    close(red[:d], G["grad__feat_embedding__1__weight"], 3e-2, 3e-2, "d feat-LN weight")
+    close(red[d:2 * d], G["grad__absolute_vis_pos_embedding__1__weight"], 1e-3, 1e-3, "d pos-LN weight")
+    close(red[2 * d:3 * d], G["grad__absolute_vis_pos_embedding__0__bias"], 1e-3, 1e-3, "d pos bias")
+    close(red[3 * d:8 * d].view(d, 5), G["grad__absolute_vis_pos_embedding__0__weight"], 1e-3, 1e-3, "d pos weight")
+    close(red[8 * d:9 * d], G["grad__img_order_embedding__weight"][0], 1e-4, 1e-4, "d img-order row 0")
+    close(red[9 * d:10 * d], G["grad__feat_embedding__0__bias"], 3e-2, 3e-2, "d feat bias")
+    dWf = ops.gemm(dG, fb, d, fd, B * V, a_kmajor=True, b_kmajor=True, out_f32=True)
+    close(dWf, G["grad__feat_embedding__0__weight"], 5e-2, 5e-2, "d feat weight")
+
+
+def test_embedding_gather_and_scatter(dev):
+    from vqacl_amd._lib import lib, ptr, stream_ptr, check
+    g = torch.Generator().manual_seed(21)
+    B, T, d, vocab = 5, 7, 64, 100
+    table = rnd((vocab, d), g)
+    ids = torch.randint(0, vocab, (B, T), generator=g)
+    ids[:, -2:] = 0
+    out = torch.zeros(B, T + 3, d, device=dev)
+    check(lib().vlt5_embed_fwd(ptr(ids.to(dev)), ptr(table.to(dev)), ptr(out), (T + 3) * d, d, B, T, d, vocab, 0.0, 0, T + 3, 0,
+                               stream_ptr()))
+    assert torch.equal(out[:, :T].cpu(), table[ids]), "gather is bit-exact"
+    dout = rnd((B, T + 3, d), g)
+    dt = torch.zeros(vocab, d, device=dev)
+    check(lib().vlt5_embed_bwd(ptr(ids.to(dev)), ptr(dout.to(dev)), (T + 3) * d, d, ptr(dt), B, T, d, vocab, 0.0, 0, T + 3, 0,
+                               stream_ptr()))
+    ref = torch.zeros(vocab, d).index_add_(0, ids.view(-1), dout[:, :T].reshape(-1, d))
+    close(dt, ref, 1e-5, 1e-5, "scatter-add")
+
+
+def test_fused_adamw_matches_reference_optimizer(dev):
+    """clip_grad_norm_(5) + HF AdamW restatement (oracle) vs the fused kernels, 3 steps."""
+    from vqacl_amd._lib import lib, ptr, stream_ptr, check
+    from oracle import ref_cpu as R
+    g = torch.Generator().manual_seed(31)
+    n = 100003
+    p0 = rnd((n,), g)
+    P = {"w.weight": p0[:60000].clone().requires_grad_(True), "b.bias": p0[60000:].clone().requires_grad_(True)}
+    opt = R.HFAdamW(P, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    p = p0.clone().to(dev)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pb = torch.zeros(n, device=dev, dtype=BF)
+    part = torch.empty(lib().vlt5_sqnorm_blocks(n), device=dev)
+    tot = torch.zeros(1, device=dev)
+    for step in range(1, 4):
+        grad = rnd((n,), g, 0.05 * step)
+        P["w.weight"].grad, P["b.bias"].grad = grad[:60000].clone(), grad[60000:].clone()
+        norm = R.clip_grad_norm(list(P.values()), 5.0)
+        opt.step()
+        gd = grad.to(dev)
+        check(lib().vlt5_sqnorm(ptr(gd), n, ptr(part), ptr(tot), 0, stream_ptr()))
+        close(tot.sqrt(), norm.reshape(1), 1e-5, 1e-6, "grad norm")
+        for a, b, wd in ((0, 60000, 0.01), (60000, n, 0.0)):
+            check(lib().vlt5_adamw_step(ptr(p[a:b]), ptr(gd[a:b]), ptr(m[a:b]), ptr(v[a:b]), ptr(pb[a:b]), b - a, 1e-3, 0.9, 0.999,
+                                        1e-6, wd, step, ptr(tot), 5.0, 1, stream_ptr()))
+    ref = torch.cat([P["w.weight"].detach(), P["b.bias"].detach()])
+    close(p, ref, 1e-5, 1e-6, "parameters after 3 fused steps")
+    close(pb, ref, 1e-2, 1e-3, "bf16 shadow")

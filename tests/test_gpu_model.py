@@ -1,0 +1,320 @@
+"""GPU parity tests of the whole path: VLT5VQA.train_step (forward, backward, optimizer) on the HIP engine against
+the CPU oracle and the committed golden fixture, through the drop-in boundary the reference's Trainer uses.
+
+Tolerances (bf16 compute with fp32 accumulation against an fp32 oracle):
+  logits ....... max |err| <= 3e-2 * max |logits|  (BASELINE north_star: "answer-token logits within stated fp tol")
+  loss ......... 2e-2 absolute
+  gradients .... cosine similarity >= 0.98 per tensor and norm ratio within 10 %
+  integer prototype indices: bit-exact whenever the oracle's top-2 cosine margin exceeds 1e-2
+"""
+import copy
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from vqacl_amd import _lib
+    _lib.lib()
+    return torch.device("cuda")
+
+
+def un(d, prefix):
+    return {k[len(prefix):].replace("__", "."): v for k, v in d.items() if k.startswith(prefix)}
+
+
+def make_model(ocfg, params, dev, dropout=None):
+    from vqacl_amd import VLT5VQA, VLT5Config
+    cfg = VLT5Config(d_model=ocfg.d_model, d_kv=ocfg.d_kv, num_heads=ocfg.num_heads, d_ff=ocfg.d_ff, num_layers=ocfg.num_layers,
+                     num_decoder_layers=ocfg.num_decoder_layers, vocab_size=ocfg.vocab_size, feat_dim=ocfg.feat_dim,
+                     dropout_rate=ocfg.dropout if dropout is None else dropout, n_ques=ocfg.n_ques, n_cate=ocfg.n_cate)
+    m = VLT5VQA(cfg, device=dev)
+    missing = m.load_state_dict({k: v.detach() for k, v in params.items()}, strict=False)
+    assert not missing.unexpected_keys
+    return m
+
+
+def rel_max_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+def cos(a, b):
+    a, b = a.float().cpu().flatten(), b.float().cpu().flatten()
+    return float(torch.dot(a, b) / (a.norm() * b.norm()).clamp(min=1e-30))
+
+
+def margin_ok(protos, pooled, thr=1e-2):
+    """per-sample top-2 cosine margin of the oracle's retrieval"""
+    import torch.nn.functional as F
+    a = F.normalize(torch.tanh(protos), dim=1)
+    b = F.normalize(torch.tanh(pooled), dim=1)
+    sim = (b @ a.t())
+    top = sim.topk(2, dim=1).values
+    return (top[:, 0] - top[:, 1]) > thr
+
+
+def check_grads(model, oracle_grads, min_cos=0.98, skip=()):
+    worst = (1.0, None)
+    for k, g in oracle_grads.items():
+        if k in skip or g is None:
+            continue
+        mine = dict(model.named_parameters()).get(k)
+        if mine is None:
+            continue
+        assert mine.grad is not None, f"no gradient for {k}"
+        if float(g.abs().max()) < 1e-10:
+            assert float(mine.grad.abs().max()) < 1e-6, k
+            continue
+        c = cos(mine.grad, g)
+        ratio = float(mine.grad.float().norm().cpu() / g.norm())
+        if c < worst[0]:
+            worst = (c, k)
+        assert c >= min_cos, f"gradient of {k}: cosine {c:.4f}"
+        assert 0.9 < ratio < 1.1, f"gradient of {k}: norm ratio {ratio:.3f}"
+    return worst
+
+
+def test_tiny_model_against_golden_fixture(dev):
+    """3 scripted train steps (tasks 0,0,1; ragged L) of the committed tiny-model fixture."""
+    from oracle import ref_cpu as R
+    G = load_golden("g6_tiny_model")
+    ocfg = R.tiny_cfg()
+    model = make_model(ocfg, un(G, "p__"), dev)
+    model.train()
+    for step, task in enumerate((0, 0, 1)):
+        batch = {k[len(f"s{step}_in_"):]: v for k, v in G.items() if k.startswith(f"s{step}_in_")}
+        for p in model.parameters():
+            p.grad = None
+        res = model.train_step(batch, task, 0.5, 0.3)
+        B, T = batch["target_ids"].shape
+        logits = model._ws_view(model.cfg.c_struct(), (B, batch["input_ids"].shape[1], 36, T), 2, torch.float32,
+                                (B, T, ocfg.vocab_size))
+        assert rel_max_err(logits, G[f"s{step}_logits"]) < 3e-2, f"logits step {step}"
+        assert abs(float(res["loss"]) - float(G[f"s{step}_loss"])) < 2e-2, f"loss step {step}"
+        assert rel_max_err(res["encoder_hidden_states"], G[f"s{step}_enc"]) < 3e-2, f"encoder output step {step}"
+        assert rel_max_err(model.Q_prototype, G[f"s{step}_Qproto"]) < 3e-2
+        assert rel_max_err(model.V_prototype, G[f"s{step}_Vproto"]) < 3e-2
+        if step == 0:
+            res["loss"].backward()
+            worst = check_grads(model, un(G, "s0_g__"))
+            print("worst gradient cosine:", worst)
+
+
+def test_tiny_model_prototype_indices_bit_exact_with_margin(dev):
+    from oracle import ref_cpu as R
+    G = load_golden("g6_tiny_model")
+    ocfg = R.tiny_cfg()
+    model = make_model(ocfg, un(G, "p__"), dev)
+    oracle = R.OracleModel(ocfg, un(G, "p__"))
+    model.train()
+    checked = 0
+    for step, task in enumerate((0, 0, 1)):
+        batch = {k[len(f"s{step}_in_"):]: v for k, v in G.items() if k.startswith(f"s{step}_in_")}
+        out = model(input_ids=batch["input_ids"], vis_inputs=(batch["vis_feats"], batch["boxes"]), labels=batch["target_ids"],
+                    cate_labels=batch["cate_labels"], ques_labels=batch["ques_labels"], proto_update=True, current_task_id=task,
+                    proto_alpha=0.5, proto_beta=0.3)
+        o = oracle.train_step(batch, task, 0.5, 0.3)
+        h = o["encoder_hidden_states"].detach()
+        okQ = margin_ok(oracle.state.Q_prototype, h[:, :20].mean(1))
+        okV = margin_ok(oracle.state.V_prototype, h[:, 20:].mean(1))
+        assert torch.equal(out["max_idx_Q"].cpu()[okQ], o["max_idx_Q"][okQ])
+        assert torch.equal(out["max_idx_V"].cpu()[okV], o["max_idx_V"][okV])
+        checked += int(okQ.sum()) + int(okV.sum())
+    assert checked > 0
+
+
+def _base_case(dev, B, seed, dropout=0.0, L=20, T=5):
+    from oracle import ref_cpu as R
+    ocfg = R.Cfg(dropout=dropout)
+    params = R.init_params(ocfg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in params:                                   # non-trivial norm weights / biases so their grads are exercised
+        if params[k].dim() == 1:
+            params[k] = params[k] + 0.1 * torch.randn(params[k].shape, generator=g)
+    batch = R.synthetic_batch(ocfg, B=B, L=L, V=36, T=T, seed=seed + 2, task_id=0)
+    return ocfg, params, batch
+
+
+def test_base_model_forward_backward_vs_oracle(dev):
+    """VL-T5-base, B=4 (BASELINE config 1 shape), dropout off: logits / loss / every gradient vs the fp32 CPU oracle."""
+    from oracle import ref_cpu as R
+    torch.set_num_threads(8)
+    ocfg, params, batch = _base_case(dev, B=4, seed=1234)
+    model = make_model(ocfg, params, dev)
+    model.train()
+    oracle = R.OracleModel(ocfg, params)
+    o = oracle.train_step(batch, 0, 0.5, 0.3, training=True)
+    o["loss"].backward()
+    res = model.train_step(batch, 0, 0.5, 0.3)
+    res["loss"].backward()
+    B, T = batch["target_ids"].shape
+    logits = model._ws_view(model.cfg.c_struct(), (B, 20, 36, T), 2, torch.float32, (B, T, ocfg.vocab_size))
+    e = rel_max_err(logits, o["logits"])
+    print("base logits rel max err", e, "loss", float(res["loss"]), float(o["loss"]))
+    assert e < 3e-2
+    assert abs(float(res["loss"]) - float(o["loss"])) < 2e-2
+    assert rel_max_err(res["encoder_hidden_states"], o["encoder_hidden_states"]) < 3e-2
+    worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()}, min_cos=0.97)
+    print("worst gradient cosine:", worst)
+    # never-used parameters get no gradient, exactly like the reference
+    assert dict(model.named_parameters())["prototype_fc1.weight"].grad is None
+
+
+def test_second_step_and_rehearsal_batch_shapes(dev):
+    """A ragged current batch (L=14, T=3) followed by a different shape reuses/grows the workspace correctly."""
+    from oracle import ref_cpu as R
+    ocfg = R.tiny_cfg()
+    params = R.init_params(ocfg, seed=5)
+    model = make_model(ocfg, params, dev)
+    oracle = R.OracleModel(ocfg, params)
+    model.train()
+    for i, (B, L, T, task) in enumerate(((6, 14, 3, 0), (3, 20, 6, 0), (8, 7, 2, 1), (5, 23, 6, 1))):
+        batch = R.synthetic_batch(ocfg, B=B, L=L, V=36 if i != 3 else 16, T=T, seed=50 + i, task_id=task)
+        res = model.train_step(batch, task, 0.5, 0.3)
+        o = oracle.train_step(batch, task, 0.5, 0.3)
+        assert abs(float(res["loss"]) - float(o["loss"])) < 3e-2, (i, float(res["loss"]), float(o["loss"]))
+        assert res["BL"] == (B, T)
+        assert tuple(res["encoder_attention_mask"].shape) == (B, L + (36 if i != 3 else 16) + 2)
+        assert torch.equal(res["encoder_attention_mask"].cpu(), o["encoder_attention_mask"])
+
+
+def test_dropout_is_seeded_and_consistent_between_forward_and_backward(dev):
+    from oracle import ref_cpu as R
+    ocfg = R.tiny_cfg()
+    params = R.init_params(ocfg, seed=9)
+    batch = R.synthetic_batch(ocfg, B=8, L=12, V=36, T=4, seed=3)
+    losses = []
+    for rep in range(2):
+        model = make_model(ocfg, params, dev, dropout=0.1)
+        model.train()
+        model.base_seed = 777
+        res = model.train_step(batch, 0, 0.5, 0.3)
+        res["loss"].backward()
+        losses.append((float(res["loss"]), model.flat_grads().clone()))
+    assert losses[0][0] == losses[1][0], "same seed, same loss"
+    assert torch.equal(losses[0][1], losses[1][1]) or cos(losses[0][1], losses[1][1]) > 0.9999
+    model.eval()
+    with torch.no_grad():
+        e1 = float(model.train_step(batch, 0, 0.5, 0.3)["loss"])
+    assert e1 != losses[0][0], "eval mode disables dropout"
+    # finite-difference check of the dropout path along the gradient direction: the backward must use the forward's masks
+    model.train()
+
+    def fused_loss():
+        model._step_count = 100                      # pin the dropout seed
+        out = model(input_ids=batch["input_ids"], vis_inputs=(batch["vis_feats"], batch["boxes"]), labels=batch["target_ids"],
+                    proto_update=False, scores=batch["scores"])
+        return out["loss_reduced"]
+
+    for p in model.parameters():
+        p.grad = None
+    fused_loss().backward()
+    gflat = model.flat_grads().clone()
+    eps = 0.05 / float(gflat.norm() ** 2)
+    vals = []
+    for sgn in (1.0, -1.0):
+        with torch.no_grad():
+            model.flat_params().add_(gflat, alpha=sgn * eps)
+            vals.append(float(fused_loss()))
+            model.flat_params().add_(gflat, alpha=-sgn * eps)
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    an = float(gflat.norm() ** 2)
+    print("finite difference", fd, "analytic", an)
+    assert abs(fd - an) / abs(an) < 0.15, (fd, an)
+
+
+def test_training_loop_drop_in_with_torch_optimizer_and_fused_optimizer(dev):
+    """The Trainer's step (vqacl.py:429-509): backward, clip_grad_norm_(5), optimizer step, grads = None -- first with a
+    stock torch optimizer over named_parameters(), then with the fused clip+AdamW; both against the oracle's optimizer."""
+    from oracle import ref_cpu as R
+    from vqacl_amd import FusedAdamW, reference_param_groups
+    ocfg = R.tiny_cfg()
+    params = R.init_params(ocfg, seed=21)
+    batch = R.synthetic_batch(ocfg, B=8, L=12, V=36, T=4, seed=4)
+    oracle = R.OracleModel(ocfg, params)
+    oopt = R.HFAdamW(oracle.used, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    ref_losses = []
+    for it in range(4):
+        oracle.zero_grad()
+        o = oracle.train_step(batch, 0, 0.5, 0.3)
+        o["loss"].backward()
+        R.clip_grad_norm(list(oracle.used.values()), 5.0)
+        oopt.step()
+        ref_losses.append(float(o["loss"]))
+    for kind in ("torch", "fused"):
+        model = make_model(ocfg, params, dev)
+        model.train()
+        if kind == "torch":
+            opt = torch.optim.AdamW(reference_param_groups(model, 0.01), lr=1e-3, eps=1e-6)
+        else:
+            opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-3, eps=1e-6, max_grad_norm=5.0)
+        got = []
+        for it in range(4):
+            res = model.train_step(batch, 0, 0.5, 0.3)
+            res["loss"].backward()
+            if kind == "torch":
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+            opt.step()
+            for p in model.parameters():
+                p.grad = None
+            got.append(float(res["loss"]))
+        print(kind, got, ref_losses)
+        for a, b in zip(got, ref_losses):
+            assert abs(a - b) < 5e-2, (kind, got, ref_losses)
+        assert got[-1] < got[0], "loss decreases on a repeated batch"
+        w = dict(model.named_parameters())["decoder.block.1.layer.2.DenseReluDense.wo.weight"]
+        assert rel_max_err(w, oracle.P["decoder.block.1.layer.2.DenseReluDense.wo.weight"]) < 5e-2
+
+
+def test_gradient_accumulation_path(dev):
+    """If the caller does not clear .grad, the second backward accumulates (autograd semantics)."""
+    from oracle import ref_cpu as R
+    ocfg = R.tiny_cfg()
+    params = R.init_params(ocfg, seed=33)
+    batch = R.synthetic_batch(ocfg, B=4, L=10, V=36, T=3, seed=8)
+    model = make_model(ocfg, params, dev)
+    model.train()
+    model.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
+    g1 = model.flat_grads().clone()
+    model.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
+    name = "encoder.block.0.layer.1.DenseReluDense.wi.weight"
+    p = dict(model.named_parameters())[name]
+    off, n = model._pinfo[name][:2]
+    assert cos(p.grad, 2 * g1[off:off + n]) > 0.9999
+    assert abs(float(p.grad.norm() / g1[off:off + n].norm()) - 2.0) < 1e-2
+
+
+def test_state_dict_roundtrip_and_greedy_decode(dev):
+    from oracle import ref_cpu as R
+    ocfg = R.tiny_cfg()
+    params = R.init_params(ocfg, seed=41)
+    model = make_model(ocfg, params, dev)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    for k, v in params.items():
+        assert torch.equal(sd[k].cpu(), v), k
+    assert sd["lm_head.weight"].data_ptr() != 0 and torch.equal(sd["lm_head.weight"], sd["shared.weight"])
+    batch = R.synthetic_batch(ocfg, B=4, L=11, V=36, T=4, seed=12)
+    model.train()
+    model.train_step(batch, 0, 0.5, 0.3)          # populate the prototypes
+    out = model.test_step(batch, max_length=6)
+    tok = out["token_ids"]
+    assert tok.shape[0] == 4 and tok.shape[1] <= 6 and int(tok[:, 0].abs().sum()) == 0
+    # oracle greedy decoding with the same prototypes
+    st = R.PrototypeState(Q_prototype=model.Q_prototype.cpu().clone(), V_prototype=model.V_prototype.cpu().clone())
+    P = {k: v for k, v in params.items()}
+    cur = torch.zeros(4, 1, dtype=torch.long)
+    for _ in range(tok.shape[1] - 1):
+        o = R.vlt5_forward(P, st, ocfg, input_ids=batch["input_ids"], vis_feats=batch["vis_feats"], boxes=batch["boxes"],
+                           decoder_input_ids=cur, training=False)
+        cur = torch.cat([cur, o["logits"][:, -1].argmax(-1, keepdim=True)], dim=1)
+    agree = float((cur[:, :tok.shape[1]] == tok.cpu()).float().mean())
+    print("greedy agreement with oracle:", agree)
+    assert agree >= 0.75

@@ -1,0 +1,143 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, the parameter layout
+mirrors the reference's state_dict, the bucket tables are bit-exact, the module tree is drop-in.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, ROOT
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    from vqacl_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_symbol_of_the_header(built):
+    hdr = open(os.path.join(ROOT, "include", "vlt5_hip.h")).read()
+    declared = set(re.findall(r"\b(vlt5_[a-z0-9_]+)\s*\(", hdr))
+    raw = C.CDLL(built.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"libvlt5_hip.so does not export {name}"
+    assert set(built.PROTOTYPES) == declared, (set(built.PROTOTYPES) ^ declared)
+    assert built.lib().vlt5_abi_version() == 1
+
+
+def test_struct_sizes_match_the_c_side(built, tmp_path):
+    """Compile a tiny C program against the header and compare sizeof() with the ctypes mirrors."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "vlt5_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(vlt5_gemm_desc), '
+                   'sizeof(vlt5_attn_desc), sizeof(vlt5_config), sizeof(vlt5_step));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [C.sizeof(built.GemmDesc), C.sizeof(built.AttnDesc), C.sizeof(built.Config), C.sizeof(built.Step)]
+
+
+def test_bucket_tables_bit_exact_vs_library_golden():
+    from vqacl_amd.buckets import bucket_table
+    G = load_golden("g4_integer_tables")
+    n = G["bucket_bidirectional"].shape[0]
+    assert np.array_equal(bucket_table(n, n, True), G["bucket_bidirectional"].numpy())
+    assert np.array_equal(bucket_table(n, n, False), G["bucket_causal"].numpy())
+    assert bucket_table(20, 20, True).dtype == np.int32
+
+
+def test_parameter_layout_mirrors_reference_state_dict(built):
+    from vqacl_amd import VLT5Config, param_layout
+    from oracle import ref_cpu as R
+    for ocfg in (R.tiny_cfg(), R.Cfg()):
+        cfg = VLT5Config(d_model=ocfg.d_model, d_kv=ocfg.d_kv, num_heads=ocfg.num_heads, d_ff=ocfg.d_ff,
+                         num_layers=ocfg.num_layers, vocab_size=ocfg.vocab_size, feat_dim=ocfg.feat_dim)
+        layout, total, nb = param_layout(cfg)
+        shapes = R.param_shapes(ocfg)
+        assert {n for n, *_ in layout} == set(shapes)
+        prev_end = 0
+        for name, off, shape, bucket, decay, used in layout:
+            assert tuple(shape) == tuple(shapes[name]), name
+            assert off % 64 == 0 and off >= prev_end
+            prev_end = off + int(np.prod(shape))
+            assert decay == (R.weight_decay_of(name, 0.01) > 0), name
+            assert used == (not name.startswith("prototype_fc"))
+        assert prev_end <= total
+        assert nb == ocfg.num_layers + ocfg.num_decoder_layers + 2
+        # fused operands are adjacent: q,k,v of a self-attention, and the cross k,v of all decoder layers
+        by = {n: (o, s) for n, o, s, *_ in layout}
+        inner = ocfg.inner
+        q, k, v = (by[f"encoder.block.0.layer.0.SelfAttention.{x}.weight"][0] for x in "qkv")
+        assert k - q == inner * ocfg.d_model and v - k == inner * ocfg.d_model
+        k0 = by["decoder.block.0.layer.1.EncDecAttention.k.weight"][0]
+        v1 = by[f"decoder.block.{ocfg.num_decoder_layers - 1}.layer.1.EncDecAttention.v.weight"][0]
+        assert v1 - k0 == (2 * ocfg.num_decoder_layers - 1) * inner * ocfg.d_model
+    # base model: the 225.7 M parameters of the survey
+    n_params = sum(int(np.prod(s)) for _, _, s, *_ in layout)
+    assert abs(n_params - 225.72e6) < 0.05e6
+
+
+def test_module_tree_is_drop_in_on_cpu(built):
+    """state_dict names/aliases, named_parameters order, weight-decay grouping, init_bert_weights-style apply()."""
+    from vqacl_amd import VLT5VQA, VLT5Config, reference_param_groups
+    from oracle import ref_cpu as R
+    ocfg = R.tiny_cfg()
+    m = VLT5VQA(VLT5Config(d_model=64, d_kv=16, num_heads=4, d_ff=128, num_layers=2, vocab_size=400, feat_dim=64),
+                device="cpu")
+    sd = m.state_dict()
+    for k, shp in R.param_shapes(ocfg).items():
+        assert tuple(sd[k].shape) == tuple(shp)
+    for alias in ("encoder.embed_tokens.weight", "decoder.embed_tokens.weight", "lm_head.weight",
+                  "encoder.visual_embedding.obj_order_embedding.weight"):
+        assert sd[alias].data_ptr() == sd["shared.weight"].data_ptr()
+    names = [n for n, _ in m.named_parameters()]
+    assert names[0] == "shared.weight" and len(names) == len(R.param_shapes(ocfg))
+    groups = reference_param_groups(m, 0.01)
+    nd = {id(p) for p in groups[1]["params"]}
+    named = dict(m.named_parameters())
+    assert id(named["encoder.visual_embedding.feat_embedding.0.bias"]) in nd
+    assert id(named["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"]) in nd
+    assert id(named["encoder.block.0.layer.0.layer_norm.weight"]) not in nd          # T5 norms DO decay
+
+    # the reference's re-initialisation walks nn.Linear / nn.Embedding modules (trainer_base.py:227-237)
+    def init_bert_weights(module):
+        if isinstance(module, (torch.nn.Linear, torch.nn.Embedding)):
+            module.weight.data.fill_(0.5)
+        if isinstance(module, torch.nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+    m.apply(init_bert_weights)
+    assert float(m.flat_params()[m._pinfo["shared.weight"][0]]) == 0.5, "parameters are views of the flat buffer"
+    assert float(named["decoder.block.1.layer.2.DenseReluDense.wi.weight"][0, 0]) == 0.5
+    # load_state_dict keeps the flat aliasing
+    new = {k: torch.full_like(v, 0.25) for k, v in sd.items()}
+    m.load_state_dict(new)
+    assert float(m.flat_params()[m._pinfo["encoder.final_layer_norm.weight"][0]]) == 0.25
+    # resize_token_embeddings keeps the old rows (vqacl.py:98-99)
+    m.resize_token_embeddings(408)
+    assert m.state_dict()["shared.weight"].shape == (408, 64)
+    assert float(m.state_dict()["shared.weight"][0, 0]) == 0.25
+    # the compute path refuses to run without a GPU -- no silent fallback
+    from vqacl_amd._lib import Vlt5Error
+    b = R.synthetic_batch(ocfg, B=2, L=8, V=36, T=3)
+    with pytest.raises(Vlt5Error):
+        m.train_step(b, 0, 0.5, 0.3)
+
+
+def test_workspace_plan_is_consistent(built):
+    from vqacl_amd import VLT5Config
+    cfg = VLT5Config()
+    c = cfg.c_struct()
+    L = built.lib()
+    need = L.vlt5_workspace_bytes(C.byref(c), 80, 20, 36, 5)
+    assert 1 << 30 < need < 16 << 30, need             # a few GB of activations at B=80: trivial next to 288 GB
+    offs = [L.vlt5_workspace_offset(C.byref(c), 80, 20, 36, 5, w) for w in range(7)]
+    assert all(0 <= o < need for o in offs) and len(set(offs)) == 7
+    # encoder-side offsets do not depend on T (greedy decoding re-plans with a growing T)
+    a = L.vlt5_workspace_offset(C.byref(c), 80, 20, 36, 5, built.WS_ENC_EXT)
+    b = L.vlt5_workspace_offset(C.byref(c), 80, 20, 36, 9, built.WS_ENC_EXT)
+    assert a == b
+    assert L.vlt5_workspace_bytes(C.byref(c), 0, 20, 36, 5) < 0

@@ -1,0 +1,140 @@
+"""ctypes binding of libvlt5_hip.so (include/vlt5_hip.h).
+
+The library is the product's only compute path: if it is missing or a call fails, this module raises --
+there is no eager/CPU fallback anywhere in `vqacl_amd`.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime the library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvlt5_hip.so")
+
+c_f = C.c_float
+c_i = C.c_int
+c_ll = C.c_longlong
+c_u32 = C.c_uint32
+vp = C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("M", c_i), ("N", c_i), ("K", c_i), ("lda", c_i), ("ldb", c_i), ("ldc", c_i),
+                ("a_kmajor", c_i), ("b_kmajor", c_i), ("alpha", c_f), ("bias", vp), ("resid", vp), ("ldr", c_i),
+                ("gate", vp), ("ldg", c_i), ("gate_scale", c_f), ("drop_p", c_f), ("drop_seed", c_u32),
+                ("relu", c_i), ("out_f32", c_i), ("accum", c_i), ("split_k", c_i), ("workspace", vp),
+                ("tile_m", c_i), ("tile_n", c_i)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("q_sb", c_ll), ("q_st", c_ll), ("k_sb", c_ll), ("k_st", c_ll),
+                ("v_sb", c_ll), ("v_st", c_ll), ("ctx", vp), ("o_sb", c_ll), ("o_st", c_ll), ("lse", vp),
+                ("bias", vp), ("bias_q", c_i), ("bias_k", c_i), ("key_mask", vp), ("mask_value", c_f), ("causal", c_i),
+                ("B", c_i), ("H", c_i), ("Tq", c_i), ("Tk", c_i), ("dk", c_i), ("drop_p", c_f), ("drop_seed", c_u32),
+                ("d_ctx", vp), ("do_sb", c_ll), ("do_st", c_ll), ("dq", vp), ("dk_", vp), ("dv", vp),
+                ("dq_sb", c_ll), ("dq_st", c_ll), ("dk_sb", c_ll), ("dk_st", c_ll), ("dv_sb", c_ll), ("dv_st", c_ll),
+                ("dbias", vp)]
+
+
+class Config(C.Structure):
+    _fields_ = [("d_model", c_i), ("d_kv", c_i), ("num_heads", c_i), ("d_ff", c_i), ("num_layers", c_i),
+                ("num_decoder_layers", c_i), ("vocab", c_i), ("rel_buckets", c_i), ("feat_dim", c_i), ("n_images", c_i),
+                ("pad_id", c_i), ("dec_start_id", c_i), ("n_ques", c_i), ("n_cate", c_i), ("eps", c_f), ("dropout", c_f)]
+
+
+class Step(C.Structure):
+    _fields_ = [("B", c_i), ("L", c_i), ("V", c_i), ("T", c_i), ("training", c_i), ("seed", c_u32),
+                ("params", vp), ("params_bf16", vp), ("grads", vp), ("workspace", vp), ("workspace_bytes", c_ll),
+                ("vis_feats", vp), ("boxes", vp), ("input_ids", vp), ("labels", vp), ("scores", vp),
+                ("enc_lut", vp), ("dec_lut", vp), ("gout", vp), ("d_loss_tok", vp), ("events", C.POINTER(vp)), ("n_events", c_i)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/vlt5_hip.h
+PROTOTYPES = {
+    "vlt5_abi_version": (c_i, []),
+    "vlt5_gemm_bf16": (c_i, [C.POINTER(GemmDesc), vp]),
+    "vlt5_gemm_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
+    "vlt5_layernorm_fwd": (c_i, [vp, vp, vp, vp, vp, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),
+    "vlt5_layernorm_bwd": (c_i, [vp, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp]),
+    "vlt5_layernorm_bwd_blocks": (c_i, [c_i]),
+    "vlt5_attn_fwd": (c_i, [C.POINTER(AttnDesc), vp]),
+    "vlt5_attn_bwd": (c_i, [C.POINTER(AttnDesc), vp]),
+    "vlt5_relbias_build": (c_i, [vp, vp, vp, c_i, c_i, c_i, c_i, vp]),
+    "vlt5_relbias_bwd": (c_i, [vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_i, c_i, vp]),
+    "vlt5_embed_fwd": (c_i, [vp, vp, vp, c_ll, c_ll, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp]),
+    "vlt5_embed_bwd": (c_i, [vp, vp, c_ll, c_ll, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp]),
+    "vlt5_shift_right": (c_i, [vp, vp, c_i, c_i, c_i, c_i, vp]),
+    "vlt5_build_mask": (c_i, [vp, vp, c_i, c_i, c_i, c_i, vp]),
+    "vlt5_vis_embed_fwd": (c_i, [vp] * 9 + [c_ll, c_ll, vp, vp, c_i, c_i, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),
+    "vlt5_vis_embed_bwd": (c_i, [vp, c_ll, c_ll] + [vp] * 11 + [c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp]),
+    "vlt5_vis_embed_bwd_blocks": (c_i, [c_i]),
+    "vlt5_colsum": (c_i, [vp, vp, c_i, c_i, c_i, c_i, vp]),
+    "vlt5_ce_fwd": (c_i, [vp, vp, vp, vp, c_i, c_i, vp]),
+    "vlt5_loss_reduce": (c_i, [vp, vp, vp, vp, vp, c_i, c_i, vp]),
+    "vlt5_ce_bwd": (c_i, [vp, vp, vp, vp, vp, vp, c_i, c_i, vp]),
+    "vlt5_proto_pool": (c_i, [vp, c_ll, c_i, c_i, c_i, c_i, vp, vp, vp]),
+    "vlt5_proto_class_mean": (c_i, [vp, vp, vp, vp, c_i, c_i, c_i, vp]),
+    "vlt5_proto_update": (c_i, [vp] * 9 + [c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, vp]),
+    "vlt5_proto_retrieve": (c_i, [vp, vp, vp, vp, c_ll, vp, c_ll, c_i, c_i, c_i, vp]),
+    "vlt5_proto_memory_loss": (c_i, [vp, vp, vp, vp, c_i, c_i, c_i, vp]),
+    "vlt5_sqnorm": (c_i, [vp, c_ll, vp, vp, c_i, vp]),
+    "vlt5_sqnorm_blocks": (c_i, [c_ll]),
+    "vlt5_adamw_step": (c_i, [vp, vp, vp, vp, vp, c_ll, c_f, c_f, c_f, c_f, c_f, c_i, vp, c_f, c_i, vp]),
+    "vlt5_cast_bf16": (c_i, [vp, vp, c_ll, vp]),
+    "vlt5_scale_add": (c_i, [vp, vp, c_f, c_f, c_ll, vp]),
+    "vlt5_drop_cast": (c_i, [vp, vp, c_ll, c_i, c_f, c_u32, vp]),
+    "vlt5_layout_count": (c_i, [C.POINTER(Config)]),
+    "vlt5_layout_get": (c_i, [C.POINTER(Config), c_i, C.c_char_p, c_i, C.POINTER(c_ll), C.POINTER(c_i), C.POINTER(c_i),
+                              C.POINTER(c_i), C.POINTER(c_i), C.POINTER(c_i)]),
+    "vlt5_layout_total": (c_ll, [C.POINTER(Config)]),
+    "vlt5_layout_buckets": (c_i, [C.POINTER(Config)]),
+    "vlt5_workspace_bytes": (c_ll, [C.POINTER(Config), c_i, c_i, c_i, c_i]),
+    "vlt5_workspace_offset": (c_ll, [C.POINTER(Config), c_i, c_i, c_i, c_i, c_i]),
+    "vlt5_encoder_fwd": (c_i, [C.POINTER(Config), C.POINTER(Step), vp]),
+    "vlt5_decoder_fwd": (c_i, [C.POINTER(Config), C.POINTER(Step), vp]),
+    "vlt5_decoder_bwd": (c_i, [C.POINTER(Config), C.POINTER(Step), vp]),
+    "vlt5_encoder_bwd": (c_i, [C.POINTER(Config), C.POINTER(Step), vp]),
+}
+
+WS_ENC_OUT, WS_ENC_EXT, WS_LOGITS, WS_LOSS_TOK, WS_LOSS, WS_ENC_MASK_EXT, WS_DEC_OUT = range(7)
+
+_lib = None
+
+
+class Vlt5Error(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Vlt5Error(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no fallback path)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if L.vlt5_abi_version() != 1:
+            raise Vlt5Error("libvlt5_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        kind = {1001: "bad argument", 1002: "alignment (contiguous dims must be multiples of 8)"}.get(rc, f"hipError {rc}")
+        raise Vlt5Error(f"{what} failed: {kind}")
+
+
+def stream_ptr():
+    return vp(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return vp(0)
+    return vp(t.data_ptr())

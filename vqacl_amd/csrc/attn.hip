@@ -1,0 +1,363 @@
+// T5 attention core for short sequences (Tq, Tk <= 64, d_kv <= 64): one workgroup per (batch, head).
+//
+//   P = softmax(Q K^T + bias + key-mask + causal-mask)   (no 1/sqrt(d): T5)      [fp32]
+//   ctx = dropout(P) V
+//
+// Everything of one (b,h) lives on chip: Q, K, V^T tiles in LDS (the whole K/V of a head is
+// 2 x 64 x 64 bf16 = 16 KB), scores and probabilities in registers.  Four waves, wave w owns query
+// rows 16w..16w+15.  MFMAs are issued with swapped operands (keys as the A operand, queries as B)
+// so a lane holds S[i = lane&15][j = 16*jb + 4*(lane>>4) + r]: a score row is spread over only
+// 4 lanes -> the softmax reductions are 15 in-lane ops + 2 wave shuffles, and the probabilities are
+// already in the B-operand layout of the P.V MFMA (the key "slots" of lane group g are
+// {32kk + 4g .. +3, 32kk + 16 + 4g .. +3}; V^T is read with the same slot pattern), so P never
+// leaves registers.  The backward recomputes P from the saved row log-sum-exp and regenerates the
+// dropout mask from the counter-based hash.
+#include "common.h"
+#include "vlt5_hip.h"
+
+namespace {
+
+constexpr int TS = 72;                 // LDS row stride in elements (64 + 8 pad) -> 144 B, 16-byte aligned rows
+constexpr int TILE_BYTES = 64 * TS * 2;
+
+struct AttnArgs {
+    const bf16_t *q, *k, *v;
+    long long q_sb, q_st, k_sb, k_st, v_sb, v_st;
+    bf16_t* ctx; long long o_sb, o_st;
+    float* lse;
+    const float* bias; int bias_q, bias_k;
+    const float* key_mask; float mask_value;
+    int causal;
+    int B, H, Tq, Tk, dk;
+    uint32_t drop_thr, drop_seed;
+    const bf16_t* d_ctx; long long do_sb, do_st;
+    bf16_t *dq, *dk_, *dv; long long dq_sb, dq_st, dk_sb, dk_st, dv_sb, dv_st;
+    float* dbias;
+};
+
+// stage a [T x dk] bf16 matrix (row stride st) into a natural [64][TS] tile and/or a transposed [64 d][TS] tile
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, long long st, int T, int dk, bf16_t* nat,
+                                           bf16_t* tr, int tid) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int c = tid + it * 256;
+        int row = c >> 3, dc = c & 7;
+        uint4 z = make_uint4(0, 0, 0, 0);
+        if (row < T && dc * 8 < dk) z = *reinterpret_cast<const uint4*>(src + (long long)row * st + dc * 8);
+        if (nat) *reinterpret_cast<uint4*>(nat + row * TS + dc * 8) = z;
+        if (tr) {
+            uint32_t w[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tr[(dc * 8 + e) * TS + row] = (bf16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+        }
+    }
+}
+
+__device__ __forceinline__ bf16x8_t lds_frag(const bf16_t* tile, int row, int chunk) {     // 8 consecutive elements
+    return *reinterpret_cast<const bf16x8_t*>(tile + row * TS + chunk * 8);
+}
+// transposed-operand fragment with the "P slot" pattern: 4 elements at col0 and 4 at col0+16
+__device__ __forceinline__ bf16x8_t lds_frag_slots(const bf16_t* tile, int row, int col0) {
+    uint2 a = *reinterpret_cast<const uint2*>(tile + row * TS + col0);
+    uint2 b = *reinterpret_cast<const uint2*>(tile + row * TS + col0 + 16);
+    union { uint32_t u[4]; bf16x8_t v; } r;
+    r.u[0] = a.x; r.u[1] = a.y; r.u[2] = b.x; r.u[3] = b.y;
+    return r.v;
+}
+__device__ __forceinline__ bf16x8_t pack_slots(const float (&lo)[4], const float (&hi)[4]) {
+    union { uint32_t u[4]; bf16x8_t v; } r;
+    r.u[0] = pack_bf16x2(lo[0], lo[1]); r.u[1] = pack_bf16x2(lo[2], lo[3]);
+    r.u[2] = pack_bf16x2(hi[0], hi[1]); r.u[3] = pack_bf16x2(hi[2], hi[3]);
+    return r.v;
+}
+
+// scores of this wave's 16 query rows against all 64 key slots, + bias/masks; s[jb][r] in the swapped layout
+__device__ __forceinline__ void scores_16x64(const AttnArgs& p, const bf16_t* Qs, const bf16_t* Ks, int b, int h, int i0,
+                                             int lane, float (&s)[4][4]) {
+    const int lr = lane & 15, g = lane >> 4;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int nks = p.dk > 32 ? 2 : 1;
+    for (int ks = 0; ks < nks; ++ks) {
+        bf16x8_t fq = lds_frag(Qs, i0 + lr, ks * 4 + g);
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            bf16x8_t fk = lds_frag(Ks, jb * 16 + lr, ks * 4 + g);
+            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq, acc[jb], 0, 0, 0);
+        }
+    }
+    const int i = i0 + lr;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = jb * 16 + g * 4 + r;
+            float v = acc[jb][r];
+            if (j < p.Tk) {
+                if (p.bias && i < p.bias_q && j < p.bias_k) v += p.bias[((size_t)h * p.bias_q + i) * p.bias_k + j];
+                if (p.key_mask) v += (1.0f - p.key_mask[(size_t)b * p.Tk + j]) * p.mask_value;
+                if (p.causal && j > i) v += -10000.0f;
+            } else {
+                v = -INFINITY;
+            }
+            s[jb][r] = v;
+        }
+}
+
+__device__ __forceinline__ float quad_lane_sum(float v) {     // the 4 lanes sharing a query row: l, l^16, l^32, l^48
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float quad_lane_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + TILE_BYTES);
+    bf16_t* Vt = reinterpret_cast<bf16_t*>(smem + 2 * TILE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    stage_tile(p.q + b * p.q_sb + (long long)h * p.dk, p.q_st, p.Tq, p.dk, Qs, nullptr, tid);
+    stage_tile(p.k + b * p.k_sb + (long long)h * p.dk, p.k_st, p.Tk, p.dk, Ks, nullptr, tid);
+    stage_tile(p.v + b * p.v_sb + (long long)h * p.dk, p.v_st, p.Tk, p.dk, nullptr, Vt, tid);
+    __syncthreads();
+    const int i0 = wave * 16;
+    if (i0 >= p.Tq) return;
+    const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
+
+    float s[4][4];
+    scores_16x64(p, Qs, Ks, b, h, i0, lane, s);
+    float m = -INFINITY;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, s[jb][r]);
+    m = quad_lane_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s[jb][r] = expf(s[jb][r] - m); sum += s[jb][r]; }
+    sum = quad_lane_sum(sum);
+    const float inv = 1.0f / sum;
+    if (g == 0 && i < p.Tq && p.lse) p.lse[((size_t)b * p.H + h) * p.Tq + i] = m + logf(sum);
+    const float dsc = drop_scale(p.drop_thr);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = s[jb][r] * inv;
+            if (p.drop_thr) {
+                const int j = jb * 16 + g * 4 + r;
+                uint32_t idx = (uint32_t)((((size_t)b * p.H + h) * p.Tq + i) * p.Tk + j);
+                v = drop_keep(p.drop_seed, idx, p.drop_thr) ? v * dsc : 0.f;
+            }
+            s[jb][r] = v;
+        }
+    bf16x8_t pf[2] = {pack_slots(s[0], s[1]), pack_slots(s[2], s[3])};
+    const int ndb = (p.dk + 15) / 16;
+    for (int db = 0; db < ndb; ++db) {
+        f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk * 32 < p.Tk) {
+                bf16x8_t fv = lds_frag_slots(Vt, db * 16 + lr, kk * 32 + g * 4);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[kk], o, 0, 0, 0);
+            }
+        }
+        const int d = db * 16 + g * 4;
+        if (i < p.Tq && d < p.dk) {
+            uint2 pk;
+            pk.x = pack_bf16x2(o[0], o[1]);
+            pk.y = pack_bf16x2(o[2], o[3]);
+            *reinterpret_cast<uint2*>(p.ctx + b * p.o_sb + (long long)i * p.o_st + (long long)h * p.dk + d) = pk;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + TILE_BYTES);
+    bf16_t* Vs = reinterpret_cast<bf16_t*>(smem + 2 * TILE_BYTES);
+    bf16_t* dOs = reinterpret_cast<bf16_t*>(smem + 3 * TILE_BYTES);
+    bf16_t* Qt = reinterpret_cast<bf16_t*>(smem + 4 * TILE_BYTES);
+    bf16_t* Kt = reinterpret_cast<bf16_t*>(smem + 5 * TILE_BYTES);
+    bf16_t* dOt = reinterpret_cast<bf16_t*>(smem + 6 * TILE_BYTES);
+    bf16_t* Pt = Vs;      // [j][i], reuses the V tile after phase A
+    bf16_t* dSt = dOs;    // [j][i], reuses the dO tile after phase A
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const long long hoff = (long long)h * p.dk;
+    stage_tile(p.q + b * p.q_sb + hoff, p.q_st, p.Tq, p.dk, Qs, Qt, tid);
+    stage_tile(p.k + b * p.k_sb + hoff, p.k_st, p.Tk, p.dk, Ks, Kt, tid);
+    stage_tile(p.v + b * p.v_sb + hoff, p.v_st, p.Tk, p.dk, Vs, nullptr, tid);
+    stage_tile(p.d_ctx + b * p.do_sb + hoff, p.do_st, p.Tq, p.dk, dOs, dOt, tid);
+    __syncthreads();
+
+    const int i0 = wave * 16;
+    const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
+    const bool active = i0 < p.Tq;              // wave-uniform
+    float pd[4][4], ds[4][4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pd[jb][r] = 0.f; ds[jb][r] = 0.f; }
+    const int ndb = (p.dk + 15) / 16;
+    const int nks = p.dk > 32 ? 2 : 1;
+
+    if (active) {
+        float s[4][4];
+        scores_16x64(p, Qs, Ks, b, h, i0, lane, s);
+        const float lse = (i < p.Tq) ? p.lse[((size_t)b * p.H + h) * p.Tq + i] : 0.f;
+        // dPd[i][j] = sum_d dO[i][d] V[j][d]  (same swapped layout as the scores)
+        f32x4_t dacc[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) dacc[jb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < nks; ++ks) {
+            bf16x8_t fo = lds_frag(dOs, i0 + lr, ks * 4 + g);
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                bf16x8_t fv = lds_frag(Vs, jb * 16 + lr, ks * 4 + g);
+                dacc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fo, dacc[jb], 0, 0, 0);
+            }
+        }
+        const float dsc = drop_scale(p.drop_thr);
+        float dsum = 0.f;
+        float pr[4][4], dp[4][4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jb * 16 + g * 4 + r;
+                float pv = (i < p.Tq && j < p.Tk) ? expf(s[jb][r] - lse) : 0.f;
+                float keep = 1.f;
+                if (p.drop_thr) {
+                    uint32_t idx = (uint32_t)((((size_t)b * p.H + h) * p.Tq + i) * p.Tk + j);
+                    keep = drop_keep(p.drop_seed, idx, p.drop_thr) ? dsc : 0.f;
+                }
+                pr[jb][r] = pv;
+                pd[jb][r] = pv * keep;
+                dp[jb][r] = dacc[jb][r] * keep;
+                dsum += dp[jb][r] * pv;
+            }
+        dsum = quad_lane_sum(dsum);
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ds[jb][r] = pr[jb][r] * (dp[jb][r] - dsum);
+                const int j = jb * 16 + g * 4 + r;
+                if (p.dbias && i < p.bias_q && j < p.bias_k && i < p.Tq && j < p.Tk)
+                    p.dbias[(((size_t)b * p.H + h) * p.bias_q + i) * p.bias_k + j] = ds[jb][r];
+            }
+        // dQ[i][d] = sum_j dS[i][j] K[j][d]
+        bf16x8_t dsf[2] = {pack_slots(ds[0], ds[1]), pack_slots(ds[2], ds[3])};
+        for (int db = 0; db < ndb; ++db) {
+            f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if (kk * 32 < p.Tk) {
+                    bf16x8_t fk = lds_frag_slots(Kt, db * 16 + lr, kk * 32 + g * 4);
+                    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, dsf[kk], o, 0, 0, 0);
+                }
+            }
+            const int d = db * 16 + g * 4;
+            if (i < p.Tq && d < p.dk) {
+                uint2 pk;
+                pk.x = pack_bf16x2(o[0], o[1]);
+                pk.y = pack_bf16x2(o[2], o[3]);
+                *reinterpret_cast<uint2*>(p.dq + b * p.dq_sb + (long long)i * p.dq_st + hoff + d) = pk;
+            }
+        }
+    }
+    __syncthreads();                     // every wave is done with Vs / dOs -> reuse them as Pt / dSt
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = jb * 16 + g * 4 + r;
+            Pt[j * TS + i] = f32_to_bf16(pd[jb][r]);
+            dSt[j * TS + i] = f32_to_bf16(ds[jb][r]);
+        }
+    __syncthreads();
+    // phase B: wave w owns key rows 16w..16w+15;  dV = Pd^T dO,  dK = dS^T Q  (reduction over the queries)
+    const int j0 = wave * 16;
+    if (j0 >= p.Tk) return;
+    const int j = j0 + lr;
+    const int nis = p.Tq > 32 ? 2 : 1;
+    for (int db = 0; db < ndb; ++db) {
+        f32x4_t av = (f32x4_t){0.f, 0.f, 0.f, 0.f}, ak = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < nis; ++ks) {
+            bf16x8_t fp = lds_frag(Pt, j0 + lr, ks * 4 + g);
+            bf16x8_t fs = lds_frag(dSt, j0 + lr, ks * 4 + g);
+            bf16x8_t fo = lds_frag(dOt, db * 16 + lr, ks * 4 + g);
+            bf16x8_t fq = lds_frag(Qt, db * 16 + lr, ks * 4 + g);
+            av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo, fp, av, 0, 0, 0);
+            ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, fs, ak, 0, 0, 0);
+        }
+        const int d = db * 16 + g * 4;
+        if (j < p.Tk && d < p.dk) {
+            uint2 pk;
+            pk.x = pack_bf16x2(av[0], av[1]);
+            pk.y = pack_bf16x2(av[2], av[3]);
+            *reinterpret_cast<uint2*>(p.dv + b * p.dv_sb + (long long)j * p.dv_st + hoff + d) = pk;
+            pk.x = pack_bf16x2(ak[0], ak[1]);
+            pk.y = pack_bf16x2(ak[2], ak[3]);
+            *reinterpret_cast<uint2*>(p.dk_ + b * p.dk_sb + (long long)j * p.dk_st + hoff + d) = pk;
+        }
+    }
+}
+
+int fill_args(const vlt5_attn_desc* d, AttnArgs& a, bool bwd) {
+    if (!d || !d->q || !d->k || !d->v) return VLT5_ERR_ARG;
+    if (d->Tq < 1 || d->Tq > 64 || d->Tk < 1 || d->Tk > 64 || d->dk < 8 || d->dk > 64 || d->B < 1 || d->H < 1) return VLT5_ERR_ARG;
+    if (d->dk & 7) return VLT5_ERR_ALIGN;
+    long long strides[] = {d->q_sb, d->q_st, d->k_sb, d->k_st, d->v_sb, d->v_st};
+    for (long long s : strides) if (s & 7) return VLT5_ERR_ALIGN;
+    a.q = (const bf16_t*)d->q; a.k = (const bf16_t*)d->k; a.v = (const bf16_t*)d->v;
+    a.q_sb = d->q_sb; a.q_st = d->q_st; a.k_sb = d->k_sb; a.k_st = d->k_st; a.v_sb = d->v_sb; a.v_st = d->v_st;
+    a.ctx = (bf16_t*)d->ctx; a.o_sb = d->o_sb; a.o_st = d->o_st; a.lse = d->lse;
+    a.bias = d->bias; a.bias_q = d->bias_q; a.bias_k = d->bias_k;
+    a.key_mask = d->key_mask; a.mask_value = d->mask_value; a.causal = d->causal;
+    a.B = d->B; a.H = d->H; a.Tq = d->Tq; a.Tk = d->Tk; a.dk = d->dk;
+    a.drop_thr = d->drop_p > 0.f ? drop_thr16(d->drop_p) : 0u; a.drop_seed = d->drop_seed;
+    a.d_ctx = (const bf16_t*)d->d_ctx; a.do_sb = d->do_sb; a.do_st = d->do_st;
+    a.dq = (bf16_t*)d->dq; a.dk_ = (bf16_t*)d->dk_; a.dv = (bf16_t*)d->dv;
+    a.dq_sb = d->dq_sb; a.dq_st = d->dq_st; a.dk_sb = d->dk_sb; a.dk_st = d->dk_st; a.dv_sb = d->dv_sb; a.dv_st = d->dv_st;
+    a.dbias = d->dbias;
+    if (!bwd) {
+        if (!d->ctx || (d->o_sb & 3) || (d->o_st & 3)) return VLT5_ERR_ARG;
+    } else {
+        if (!d->d_ctx || !d->dq || !d->dk_ || !d->dv || !d->lse) return VLT5_ERR_ARG;
+        long long s2[] = {d->do_sb, d->do_st, d->dq_sb, d->dq_st, d->dk_sb, d->dk_st, d->dv_sb, d->dv_st};
+        for (long long s : s2) if (s & 7) return VLT5_ERR_ALIGN;
+    }
+    return VLT5_OK;
+}
+
+}  // namespace
+
+extern "C" int vlt5_attn_fwd(const vlt5_attn_desc* d, void* stream) {
+    AttnArgs a;
+    int rc = fill_args(d, a, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(a.B * a.H), dim3(256), 3 * TILE_BYTES, (hipStream_t)stream, a);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+
+extern "C" int vlt5_attn_bwd(const vlt5_attn_desc* d, void* stream) {
+    AttnArgs a;
+    int rc = fill_args(d, a, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.B * a.H), dim3(256), 7 * TILE_BYTES, (hipStream_t)stream, a);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}

@@ -1,0 +1,62 @@
+// Shared device helpers for the VL-T5 gfx950 kernels (wave64, MFMA 16x16x32 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;                                             // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;         // one MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;          // one MFMA C/D fragment
+
+#define VLT5_OK 0
+#define VLT5_ERR_ARG 1001          // bad argument (null pointer, unsupported size)
+#define VLT5_ERR_ALIGN 1002        // a contiguous dimension is not a multiple of 8 elements
+
+#define WAVE 64
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even, NaN kept quiet
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ---- counter-based dropout mask ---------------------------------------------------------------
+// keep(idx) is a pure function of (seed, idx): forward and backward regenerate the same mask, no
+// mask tensor is stored.  One 32-bit hash serves two neighbouring elements (16 bits each).
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x;
+}
+__host__ __device__ __forceinline__ uint32_t drop_thr16(float p) {    // P(drop) = thr/65536
+    float t = p * 65536.0f + 0.5f;
+    return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)t);
+}
+__host__ __device__ __forceinline__ float drop_scale(uint32_t thr16) { return 65536.0f / (float)(65536u - thr16); }
+__host__ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t thr16) {
+    uint32_t h = mix32(((idx >> 1) * 0x9E3779B1u) ^ seed);
+    uint32_t v = (idx & 1u) ? (h >> 16) : (h & 0xffffu);
+    return v >= thr16;
+}
+__host__ __device__ __forceinline__ uint32_t site_seed(uint32_t base, uint32_t site) {
+    return mix32(base ^ (site * 0x632BE5ABu + 0x9E3779B9u));
+}
+
+// ---- wave reductions ----------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+#define HIP_RET(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return (int)e__; } while (0)
+#define LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

@@ -1,0 +1,348 @@
+// Embedding-side kernels of the VL-T5 path: token gather (+ input dropout), shift-right, masks,
+// the visual embedding tail (two RMS norms + 5->d box projection + order embeddings), and the
+// relative-position-bias gather / its gradient.  All bandwidth- or latency-bound, no MFMA work.
+#include "common.h"
+#include "vlt5_hip.h"
+
+namespace {
+
+// ---------------- token embedding ---------------------------------------------------------------
+__global__ void embed_fwd_kernel(const long long* __restrict__ ids, const float* __restrict__ table, float* __restrict__ out,
+                                 long long sb, long long st, int B, int T, int d, int vocab, uint32_t thr, uint32_t seed,
+                                 int drop_rows, int drop_row0) {
+    const int row = blockIdx.x;                       // b*T + t
+    const int b = row / T, t = row % T;
+    long long id = ids[row];
+    if (id < 0 || id >= vocab) id = 0;
+    const float* src = table + (size_t)id * d;
+    float* dst = out + b * sb + t * st;
+    const float dsc = drop_scale(thr);
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+        float4 v = *reinterpret_cast<const float4*>(src + c);
+        float o[4] = {v.x, v.y, v.z, v.w};
+        if (thr) {
+            uint32_t idx = (uint32_t)(((size_t)b * drop_rows + drop_row0 + t) * d + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = drop_keep(seed, idx + k, thr) ? o[k] * dsc : 0.f;
+        }
+        *reinterpret_cast<float4*>(dst + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ void embed_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dout, long long sb, long long st,
+                                 float* __restrict__ dtable, int B, int T, int d, int vocab, uint32_t thr, uint32_t seed,
+                                 int drop_rows, int drop_row0) {
+    const int row = blockIdx.x;
+    const int b = row / T, t = row % T;
+    long long id = ids[row];
+    if (id < 0 || id >= vocab) id = 0;
+    const float* src = dout + b * sb + t * st;
+    float* dst = dtable + (size_t)id * d;
+    const float dsc = drop_scale(thr);
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        float g = src[c];
+        if (thr) {
+            uint32_t idx = (uint32_t)(((size_t)b * drop_rows + drop_row0 + t) * d + c);
+            g = drop_keep(seed, idx, thr) ? g * dsc : 0.f;
+        }
+        atomicAdd(dst + c, g);
+    }
+}
+
+__global__ void shift_right_kernel(const long long* __restrict__ labels, long long* __restrict__ out, int B, int T,
+                                   int start_id, int pad_id) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T) return;
+    int t = i % T;
+    long long v = (t == 0) ? (long long)start_id : labels[i - 1];
+    if (v == -100) v = pad_id;
+    out[i] = v;
+}
+
+__global__ void build_mask_kernel(const long long* __restrict__ ids, float* __restrict__ mask, int B, int L, int S, int pad_id) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * S) return;
+    int b = i / S, s = i % S;
+    mask[i] = (s < L) ? (ids[b * L + s] != pad_id ? 1.f : 0.f) : 1.f;
+}
+
+// ---------------- visual embedding tail -----------------------------------------------------------
+__device__ __forceinline__ void load_pos5(const float* __restrict__ boxes, int row, float (&p5)[5]) {
+    float4 bx = *reinterpret_cast<const float4*>(boxes + (size_t)row * 4);
+    p5[0] = bx.x; p5[1] = bx.y; p5[2] = bx.z; p5[3] = bx.w;
+    p5[4] = (bx.w - bx.z) * (bx.y - bx.x);       // get_area reads the columns as (x1,x2,y1,y2)
+}
+__device__ __forceinline__ float pos_lin(const float* __restrict__ Wp, const float* __restrict__ bp, int c, const float (&p5)[5]) {
+    const float* w = Wp + (size_t)c * 5;
+    return bp[c] + (p5[0] * w[0] + p5[1] * w[1] + p5[2] * w[2] + p5[3] * w[3] + p5[4] * w[4]);
+}
+
+__global__ __launch_bounds__(256) void vis_fwd_kernel(const float* __restrict__ G, const float* __restrict__ boxes,
+                                                      const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                      const float* __restrict__ lnf_w, const float* __restrict__ lnp_w,
+                                                      const float* __restrict__ img0, const float* __restrict__ shared,
+                                                      float* __restrict__ out, long long sb, long long st,
+                                                      float* __restrict__ rstd_f, float* __restrict__ rstd_p, int B, int V,
+                                                      int d, int vocab, float eps, uint32_t thr, uint32_t seed,
+                                                      int drop_rows, int drop_row0) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * V) return;
+    const int b = row / V, i = row % V;
+    const float* gr = G + (size_t)row * d;
+    float p5[5];
+    load_pos5(boxes, row, p5);
+    float ssf = 0.f, ssp = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        float g = gr[c];
+        float a = pos_lin(Wp, bp, c, p5);
+        ssf += g * g;
+        ssp += a * a;
+    }
+    ssf = wave_sum(ssf);
+    ssp = wave_sum(ssp);
+    const float rf = rsqrtf(ssf / (float)d + eps), rp = rsqrtf(ssp / (float)d + eps);
+    if (lane == 0) { rstd_f[row] = rf; rstd_p[row] = rp; }
+    const float* obj = shared + (size_t)(vocab - 1 - i) * d;
+    float* dst = out + b * sb + i * st;
+    const float dsc = drop_scale(thr);
+    for (int c = lane; c < d; c += 64) {
+        float a = pos_lin(Wp, bp, c, p5);
+        float v = lnf_w[c] * (gr[c] * rf) + lnp_w[c] * (a * rp);
+        v = v + img0[c];
+        v = v + obj[c];
+        if (thr) {
+            uint32_t idx = (uint32_t)(((size_t)b * drop_rows + drop_row0 + i) * d + c);
+            v = drop_keep(seed, idx, thr) ? v * dsc : 0.f;
+        }
+        dst[c] = v;
+    }
+}
+
+// row-wise part of the backward: dG (bf16) and the per-row coefficient of the position branch
+__global__ __launch_bounds__(256) void vis_bwd_rows_kernel(const float* __restrict__ dout, long long sb, long long st,
+                                                           const float* __restrict__ G, const float* __restrict__ boxes,
+                                                           const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                           const float* __restrict__ lnf_w, const float* __restrict__ lnp_w,
+                                                           const float* __restrict__ rstd_f, const float* __restrict__ rstd_p,
+                                                           bf16_t* __restrict__ dG, float* __restrict__ coef_p, float* __restrict__ coef_f,
+                                                           int B, int V, int d, uint32_t thr, uint32_t seed, int drop_rows,
+                                                           int drop_row0) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * V) return;
+    const int b = row / V, i = row % V;
+    const float* gr = G + (size_t)row * d;
+    const float* go = dout + b * sb + i * st;
+    float p5[5];
+    load_pos5(boxes, row, p5);
+    const float rf = rstd_f[row], rp = rstd_p[row];
+    const float dsc = drop_scale(thr);
+    float sf = 0.f, sp = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        float g = go[c];
+        if (thr) {
+            uint32_t idx = (uint32_t)(((size_t)b * drop_rows + drop_row0 + i) * d + c);
+            g = drop_keep(seed, idx, thr) ? g * dsc : 0.f;
+        }
+        sf += g * lnf_w[c] * gr[c];
+        sp += g * lnp_w[c] * pos_lin(Wp, bp, c, p5);
+    }
+    sf = wave_sum(sf);
+    sp = wave_sum(sp);
+    const float cf = rf * rf * rf * sf / (float)d;
+    if (lane == 0) { coef_p[row] = rp * rp * rp * sp / (float)d; coef_f[row] = cf; }
+    for (int c = lane; c < d; c += 64) {
+        float g = go[c];
+        if (thr) {
+            uint32_t idx = (uint32_t)(((size_t)b * drop_rows + drop_row0 + i) * d + c);
+            g = drop_keep(seed, idx, thr) ? g * dsc : 0.f;
+        }
+        dG[(size_t)row * d + c] = f32_to_bf16(rf * g * lnf_w[c] - gr[c] * cf);
+    }
+}
+
+// column-wise part: parameter gradients, rows split over blockIdx.y, partial [split][9*d]
+__global__ void vis_bwd_cols_kernel(const float* __restrict__ dout, long long sb, long long st, const float* __restrict__ G,
+                                    const float* __restrict__ boxes, const float* __restrict__ Wp, const float* __restrict__ bp,
+                                    const float* __restrict__ lnf_w, const float* __restrict__ lnp_w,
+                                    const float* __restrict__ rstd_f, const float* __restrict__ rstd_p,
+                                    const float* __restrict__ coef_p, const float* __restrict__ coef_f,
+                                    float* __restrict__ partial, int B, int V, int d, int rows_per_split, uint32_t thr,
+                                    uint32_t seed, int drop_rows, int drop_row0) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    const int r0 = blockIdx.y * rows_per_split, r1 = min(B * V, r0 + rows_per_split);
+    const float dsc = drop_scale(thr);
+    float a_lnf = 0.f, a_lnp = 0.f, a_bp = 0.f, a_img = 0.f, a_bf = 0.f, a_w[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const float wl = lnp_w[c], wf = lnf_w[c];
+    for (int row = r0; row < r1; ++row) {
+        const int b = row / V, i = row % V;
+        float g = dout[b * sb + i * st + c];
+        if (thr) {
+            uint32_t idx = (uint32_t)(((size_t)b * drop_rows + drop_row0 + i) * d + c);
+            g = drop_keep(seed, idx, thr) ? g * dsc : 0.f;
+        }
+        float p5[5];
+        load_pos5(boxes, row, p5);
+        const float a = pos_lin(Wp, bp, c, p5);
+        const float rf = rstd_f[row], rp = rstd_p[row];
+        const float gv = G[(size_t)row * d + c];
+        a_lnf += g * gv * rf;
+        a_bf += rf * g * wf - gv * coef_f[row];
+        a_lnp += g * a * rp;
+        a_img += g;
+        const float da = rp * g * wl - a * coef_p[row];
+        a_bp += da;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) a_w[k] += da * p5[k];
+    }
+    float* pp = partial + (size_t)blockIdx.y * 10 * d;
+    pp[c] = a_lnf;
+    pp[d + c] = a_lnp;
+    pp[2 * d + c] = a_bp;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) pp[3 * d + c * 5 + k] = a_w[k];
+    pp[8 * d + c] = a_img;
+    pp[9 * d + c] = a_bf;
+}
+
+// dshared[vocab-1-i, c] += sum_b dout[b, i, c]   (fixed order over b)
+__global__ void vis_bwd_obj_kernel(const float* __restrict__ dout, long long sb, long long st, float* __restrict__ dshared,
+                                   int B, int V, int d, int vocab, uint32_t thr, uint32_t seed, int drop_rows, int drop_row0) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (c >= d) return;
+    const float dsc = drop_scale(thr);
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float g = dout[b * sb + i * st + c];
+        if (thr) {
+            uint32_t idx = (uint32_t)(((size_t)b * drop_rows + drop_row0 + i) * d + c);
+            g = drop_keep(seed, idx, thr) ? g * dsc : 0.f;
+        }
+        s += g;
+    }
+    dshared[(size_t)(vocab - 1 - i) * d + c] += s;
+}
+
+// ---------------- relative position bias ----------------------------------------------------------
+__global__ void relbias_build_kernel(const float* __restrict__ table, const int* __restrict__ lut, float* __restrict__ bias,
+                                     int H, int Lq, int Lk) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * Lq * Lk) return;
+    int h = i / (Lq * Lk), pos = i % (Lq * Lk);
+    bias[i] = table[lut[pos] * H + h];
+}
+__global__ void relbias_sum_mats_kernel(const float* __restrict__ dS, float* __restrict__ R, int nmat, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int m = 0; m < nmat; ++m) s += dS[(size_t)m * n + i];
+    R[i] = s;
+}
+__global__ void relbias_scatter_kernel(const float* __restrict__ R, const int* __restrict__ lut, float* __restrict__ dtable,
+                                       int H, int npos, int nbuckets, int accum) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * nbuckets) return;
+    int bucket = i / H, h = i % H;
+    float s = accum ? dtable[i] : 0.f;
+    for (int pos = 0; pos < npos; ++pos)
+        if (lut[pos] == bucket) s += R[(size_t)h * npos + pos];
+    dtable[i] = s;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+static inline uint32_t thr_of(float p) { return p > 0.f ? drop_thr16(p) : 0u; }
+
+extern "C" int vlt5_embed_fwd(const long long* ids, const float* table, float* out, long long out_sb, long long out_st, int B,
+                              int T, int d, int vocab, float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0,
+                              void* stream) {
+    if (!ids || !table || !out || B <= 0 || T <= 0) return VLT5_ERR_ARG;
+    if ((d & 3) || (out_sb & 3) || (out_st & 3)) return VLT5_ERR_ALIGN;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(B * T), dim3(d >= 1024 ? 256 : (d >= 512 ? 128 : 64)), 0, ST, ids, table, out,
+                       out_sb, out_st, B, T, d, vocab, thr_of(drop_p), drop_seed, drop_rows, drop_row0);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_embed_bwd(const long long* ids, const float* dout, long long sb, long long st, float* dtable, int B, int T,
+                              int d, int vocab, float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* stream) {
+    if (!ids || !dout || !dtable || B <= 0 || T <= 0) return VLT5_ERR_ARG;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * T), dim3(256), 0, ST, ids, dout, sb, st, dtable, B, T, d, vocab,
+                       thr_of(drop_p), drop_seed, drop_rows, drop_row0);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_shift_right(const long long* labels, long long* out, int B, int T, int start_id, int pad_id, void* stream) {
+    if (!labels || !out || B <= 0 || T <= 0) return VLT5_ERR_ARG;
+    hipLaunchKernelGGL(shift_right_kernel, dim3((B * T + 255) / 256), dim3(256), 0, ST, labels, out, B, T, start_id, pad_id);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_build_mask(const long long* ids, float* mask, int B, int L, int S, int pad_id, void* stream) {
+    if (!ids || !mask || B <= 0 || L < 0 || S < L) return VLT5_ERR_ARG;
+    hipLaunchKernelGGL(build_mask_kernel, dim3((B * S + 255) / 256), dim3(256), 0, ST, ids, mask, B, L, S, pad_id);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+
+extern "C" int vlt5_vis_embed_fwd(const float* G, const float* boxes, const float* Wp, const float* bp, const float* lnf_w,
+                                  const float* lnp_w, const float* img0, const float* shared, float* out, long long out_sb,
+                                  long long out_st, float* rstd_f, float* rstd_p, int B, int V, int d, int vocab, float eps,
+                                  float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* stream) {
+    if (!G || !boxes || !Wp || !bp || !lnf_w || !lnp_w || !img0 || !shared || !out || !rstd_f || !rstd_p) return VLT5_ERR_ARG;
+    if (B <= 0 || V <= 0 || V > vocab) return VLT5_ERR_ARG;
+    hipLaunchKernelGGL(vis_fwd_kernel, dim3((B * V + 3) / 4), dim3(256), 0, ST, G, boxes, Wp, bp, lnf_w, lnp_w, img0, shared, out,
+                       out_sb, out_st, rstd_f, rstd_p, B, V, d, vocab, eps, thr_of(drop_p), drop_seed, drop_rows, drop_row0);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_vis_embed_bwd_blocks(int rows) {
+    int s = (rows + 63) / 64;
+    return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+extern "C" int vlt5_vis_embed_bwd(const float* dout, long long sb, long long st, const float* G, const float* boxes,
+                                  const float* Wp, const float* bp, const float* lnf_w, const float* lnp_w, const float* rstd_f,
+                                  const float* rstd_p, void* dG_bf16, float* partial, float* dshared, int B, int V, int d,
+                                  int vocab, float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* stream) {
+    if (!dout || !G || !boxes || !Wp || !bp || !lnf_w || !lnp_w || !rstd_f || !rstd_p || !dG_bf16 || !partial || !dshared)
+        return VLT5_ERR_ARG;
+    const int rows = B * V;
+    const int nsplit = vlt5_vis_embed_bwd_blocks(rows);
+    const int rps = (rows + nsplit - 1) / nsplit;
+    float* coef_p = partial + (size_t)nsplit * 10 * d;            // 2 x [rows] scratch behind the partials
+    float* coef_f = coef_p + rows;
+    uint32_t thr = thr_of(drop_p);
+    hipLaunchKernelGGL(vis_bwd_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, dout, sb, st, G, boxes, Wp, bp, lnf_w, lnp_w,
+                       rstd_f, rstd_p, (bf16_t*)dG_bf16, coef_p, coef_f, B, V, d, thr, drop_seed, drop_rows, drop_row0);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(vis_bwd_cols_kernel, dim3((d + 127) / 128, nsplit), dim3(128), 0, ST, dout, sb, st, G, boxes, Wp, bp, lnf_w, lnp_w,
+                       rstd_f, rstd_p, coef_p, coef_f, partial, B, V, d, rps, thr, drop_seed, drop_rows, drop_row0);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(vis_bwd_obj_kernel, dim3((d + 127) / 128, V), dim3(128), 0, ST, dout, sb, st, dshared, B, V, d, vocab, thr,
+                       drop_seed, drop_rows, drop_row0);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+
+extern "C" int vlt5_relbias_build(const float* table, const int* lut, float* bias, int H, int Lq, int Lk, int nbuckets,
+                                  void* stream) {
+    if (!table || !lut || !bias || H <= 0 || Lq <= 0 || Lk <= 0 || nbuckets <= 0) return VLT5_ERR_ARG;
+    int n = H * Lq * Lk;
+    hipLaunchKernelGGL(relbias_build_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, table, lut, bias, H, Lq, Lk);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_relbias_bwd(const float* dS, const int* lut, float* dtable, float* scratch, int nmat, int H, int Lq, int Lk,
+                                int nbuckets, int accum, void* stream) {
+    if (!dS || !lut || !dtable || !scratch || nmat <= 0) return VLT5_ERR_ARG;
+    int n = H * Lq * Lk;
+    hipLaunchKernelGGL(relbias_sum_mats_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, dS, scratch, nmat, n);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(relbias_scatter_kernel, dim3((H * nbuckets + 63) / 64), dim3(64), 0, ST, scratch, lut, dtable, H, Lq * Lk,
+                       nbuckets, accum);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}

@@ -1,0 +1,567 @@
+// Whole-path engine: composes the kernels into VLT5 encoder/decoder forward and backward.
+// Pure host code (no kernels here): each entry point only enqueues work on the caller's stream, never allocates
+// and never synchronises, so one C call per phase keeps the host off the critical path.
+//
+// Reference being replaced: JointEncoder.forward (VL-T5/src/modeling_t5_our.py:175-339), VLT5.forward (:514-713),
+// the HF T5Stack/T5Block they call, and autograd's backward of both (src/vqacl.py:461).
+#include "common.h"
+#include "vlt5_hip.h"
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int MAXL = 48;
+
+// dropout sites (each gets its own seed so masks are independent)
+enum { SITE_ENC_EMBED = 1, SITE_DEC_EMBED = 2, SITE_ENC_FINAL = 5, SITE_DEC_FINAL = 6, SITE_ENC_BASE = 16, SITE_DEC_BASE = 1024 };
+enum { E_PROBS = 0, E_ATTN_OUT = 1, E_FFN_H = 2, E_FFN_OUT = 3 };
+enum { D_SPROBS = 0, D_SOUT = 1, D_CPROBS = 2, D_COUT = 3, D_FFN_H = 4, D_FFN_OUT = 5 };
+
+struct Entry { std::string name; long long off; int rows, cols, bucket, decay, used; };
+
+struct Layout {
+    std::vector<Entry> e;
+    long long total = 0;
+    int nbuckets = 0;
+    long long dec_final_ln = 0, dec_rel = 0, cross_kv = 0, enc_final_ln = 0, enc_rel = 0;
+    struct DecL { long long wo, wi, ln_f, co, cq, ln_c, so, sqkv, ln_s; } dec[MAXL];
+    struct EncL { long long wo, wi, ln_f, so, sqkv, ln_s; } enc[MAXL];
+    long long vis_wf = 0, vis_bf = 0, vis_lnf = 0, vis_wp = 0, vis_bp = 0, vis_lnp = 0, vis_img = 0, shared = 0;
+};
+
+// Flat parameter order = order in which gradients complete during backward (decoder top -> encoder bottom -> embeddings),
+// every tensor aligned to 64 elements.  q,k,v of a self-attention are adjacent (one fused [3*inner, d] GEMM operand);
+// the cross-attention k,v of ALL decoder layers are adjacent (one [Ld*2*inner, d] operand over the encoder output).
+void build_layout(const vlt5_config& c, Layout& L, bool names) {
+    const int d = c.d_model, inner = c.num_heads * c.d_kv, ff = c.d_ff;
+    long long off = 0;
+    auto add = [&](const std::string& name, int rows, int cols, int bucket, int used = 1) -> long long {
+        long long o = off;
+        if (names) {
+            int decay = (name.find("bias") != std::string::npos || name.find("LayerNorm.weight") != std::string::npos) ? 0 : 1;
+            L.e.push_back({name, o, rows, cols, bucket, decay, used});
+        }
+        long long n = (long long)rows * (cols > 0 ? cols : 1);
+        off += (n + 63) / 64 * 64;
+        return o;
+    };
+    auto nm = [&](const char* fmt, int i) { char b[160]; snprintf(b, sizeof b, fmt, i); return std::string(b); };
+    int bucket = 0;
+    const int Ld = c.num_decoder_layers, Le = c.num_layers;
+    L.dec_final_ln = add("decoder.final_layer_norm.weight", d, 0, bucket);
+    for (int i = Ld - 1; i >= 0; --i) {
+        auto& D = L.dec[i];
+        D.wo = add(nm("decoder.block.%d.layer.2.DenseReluDense.wo.weight", i), d, ff, bucket);
+        D.wi = add(nm("decoder.block.%d.layer.2.DenseReluDense.wi.weight", i), ff, d, bucket);
+        D.ln_f = add(nm("decoder.block.%d.layer.2.layer_norm.weight", i), d, 0, bucket);
+        D.co = add(nm("decoder.block.%d.layer.1.EncDecAttention.o.weight", i), d, inner, bucket);
+        D.cq = add(nm("decoder.block.%d.layer.1.EncDecAttention.q.weight", i), inner, d, bucket);
+        D.ln_c = add(nm("decoder.block.%d.layer.1.layer_norm.weight", i), d, 0, bucket);
+        D.so = add(nm("decoder.block.%d.layer.0.SelfAttention.o.weight", i), d, inner, bucket);
+        D.sqkv = add(nm("decoder.block.%d.layer.0.SelfAttention.q.weight", i), inner, d, bucket);
+        add(nm("decoder.block.%d.layer.0.SelfAttention.k.weight", i), inner, d, bucket);
+        add(nm("decoder.block.%d.layer.0.SelfAttention.v.weight", i), inner, d, bucket);
+        D.ln_s = add(nm("decoder.block.%d.layer.0.layer_norm.weight", i), d, 0, bucket);
+        if (i == 0) L.dec_rel = add("decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", c.rel_buckets, c.num_heads, bucket);
+        ++bucket;
+    }
+    for (int i = 0; i < Ld; ++i) {
+        long long o = add(nm("decoder.block.%d.layer.1.EncDecAttention.k.weight", i), inner, d, bucket);
+        if (i == 0) L.cross_kv = o;
+        add(nm("decoder.block.%d.layer.1.EncDecAttention.v.weight", i), inner, d, bucket);
+    }
+    ++bucket;
+    L.enc_final_ln = add("encoder.final_layer_norm.weight", d, 0, bucket);
+    for (int i = Le - 1; i >= 0; --i) {
+        auto& E = L.enc[i];
+        E.wo = add(nm("encoder.block.%d.layer.1.DenseReluDense.wo.weight", i), d, ff, bucket);
+        E.wi = add(nm("encoder.block.%d.layer.1.DenseReluDense.wi.weight", i), ff, d, bucket);
+        E.ln_f = add(nm("encoder.block.%d.layer.1.layer_norm.weight", i), d, 0, bucket);
+        E.so = add(nm("encoder.block.%d.layer.0.SelfAttention.o.weight", i), d, inner, bucket);
+        E.sqkv = add(nm("encoder.block.%d.layer.0.SelfAttention.q.weight", i), inner, d, bucket);
+        add(nm("encoder.block.%d.layer.0.SelfAttention.k.weight", i), inner, d, bucket);
+        add(nm("encoder.block.%d.layer.0.SelfAttention.v.weight", i), inner, d, bucket);
+        E.ln_s = add(nm("encoder.block.%d.layer.0.layer_norm.weight", i), d, 0, bucket);
+        if (i == 0) L.enc_rel = add("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", c.rel_buckets, c.num_heads, bucket);
+        ++bucket;
+    }
+    const char* ve = "encoder.visual_embedding.";
+    L.vis_wf = add(std::string(ve) + "feat_embedding.0.weight", d, c.feat_dim, bucket);
+    L.vis_bf = add(std::string(ve) + "feat_embedding.0.bias", d, 0, bucket);
+    L.vis_lnf = add(std::string(ve) + "feat_embedding.1.weight", d, 0, bucket);
+    L.vis_wp = add(std::string(ve) + "absolute_vis_pos_embedding.0.weight", d, 5, bucket);
+    L.vis_bp = add(std::string(ve) + "absolute_vis_pos_embedding.0.bias", d, 0, bucket);
+    L.vis_lnp = add(std::string(ve) + "absolute_vis_pos_embedding.1.weight", d, 0, bucket);
+    L.vis_img = add(std::string(ve) + "img_order_embedding.weight", c.n_images, d, bucket);
+    L.shared = add("shared.weight", c.vocab, d, bucket);
+    ++bucket;
+    L.nbuckets = bucket;
+    // never used in forward (src/modeling_t5_our.py:379-380): kept for state_dict compatibility, excluded from buckets
+    add("prototype_fc1.weight", d, d, -1, 0);
+    add("prototype_fc1.bias", d, 0, -1, 0);
+    add("prototype_fc2.weight", d, d, -1, 0);
+    add("prototype_fc2.bias", d, 0, -1, 0);
+    L.total = off;
+}
+
+struct Plan {
+    int B, L, V, T, S, Sx, M, Mx, Md;
+    size_t total;
+    size_t feats_bf16, visG, vis_rf, vis_rp, mask, enc_bias;
+    size_t x[2 * MAXL + 1], xr[2 * MAXL + 1];
+    size_t xn_a[MAXL], qkv[MAXL], lse[MAXL], ctx[MAXL], xn_f[MAXL], h[MAXL];
+    size_t enc_out, enc_ext, mask_ext;
+    size_t dec_ids, dec_bias, kv_all;
+    size_t y[3 * MAXL + 1], yr[3 * MAXL + 1];
+    size_t yn_a[MAXL], dqkv_s[MAXL], lse_s[MAXL], ctx_s[MAXL], yn_c[MAXL], qc[MAXL], lse_c[MAXL], ctx_c[MAXL], yn_f[MAXL], hd[MAXL];
+    size_t dec_out, logits, lse_ce, loss_tok, row_w, loss;
+    // backward scratch
+    size_t dx, tmp, dyd, dh, dctx, dqkv, dq_c, dkv_all, d_enc_ext, dS_enc, dS_dec, dlogits, slab, ln_partial, vis_partial,
+        rel_scratch, vis_dG, small;
+    size_t slab_bytes;
+};
+
+void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
+    const size_t d = c.d_model, inner = (size_t)c.num_heads * c.d_kv, ff = c.d_ff, H = c.num_heads;
+    const int Le = c.num_layers, Ld = c.num_decoder_layers;
+    p.B = B; p.L = L; p.V = V; p.T = T; p.S = L + V; p.Sx = p.S + 2;
+    p.M = B * p.S; p.Mx = B * p.Sx; p.Md = B * T;
+    const size_t M = p.M, Mx = p.Mx, Md = p.Md;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    p.feats_bf16 = take((size_t)B * V * c.feat_dim * 2);
+    p.visG = take((size_t)B * V * d * 4);
+    p.vis_rf = take((size_t)B * V * 4);
+    p.vis_rp = take((size_t)B * V * 4);
+    p.mask = take((size_t)B * p.S * 4);
+    p.enc_bias = take(H * L * L * 4);
+    for (int i = 0; i <= 2 * Le; ++i) { p.x[i] = take(M * d * 4); p.xr[i] = take(M * 4); }
+    for (int l = 0; l < Le; ++l) {
+        p.xn_a[l] = take(M * d * 2); p.qkv[l] = take(M * 3 * inner * 2); p.lse[l] = take((size_t)B * H * p.S * 4);
+        p.ctx[l] = take(M * inner * 2); p.xn_f[l] = take(M * d * 2); p.h[l] = take(M * ff * 2);
+    }
+    p.enc_out = take(Mx * d * 4);
+    p.enc_ext = take(Mx * d * 2);
+    p.mask_ext = take((size_t)B * p.Sx * 4);
+    p.dec_ids = take(Md * 8);
+    p.dec_bias = take(H * T * T * 4);
+    p.kv_all = take(Mx * (size_t)Ld * 2 * inner * 2);
+    for (int i = 0; i <= 3 * Ld; ++i) { p.y[i] = take(Md * d * 4); p.yr[i] = take(Md * 4); }
+    for (int l = 0; l < Ld; ++l) {
+        p.yn_a[l] = take(Md * d * 2); p.dqkv_s[l] = take(Md * 3 * inner * 2); p.lse_s[l] = take((size_t)B * H * T * 4);
+        p.ctx_s[l] = take(Md * inner * 2); p.yn_c[l] = take(Md * d * 2); p.qc[l] = take(Md * inner * 2);
+        p.lse_c[l] = take((size_t)B * H * T * 4); p.ctx_c[l] = take(Md * inner * 2); p.yn_f[l] = take(Md * d * 2);
+        p.hd[l] = take(Md * ff * 2);
+    }
+    p.dec_out = take(Md * d * 2);
+    p.logits = take(Md * (size_t)c.vocab * 4);
+    p.lse_ce = take(Md * 4); p.loss_tok = take(Md * 4); p.row_w = take(Md * 4); p.loss = take(256);
+    const size_t Mmax = Mx > Md ? Mx : Md;
+    p.dx = take(Mmax * d * 4);
+    p.tmp = take(Mmax * d * 4);
+    p.dyd = take(Mmax * d * 2);
+    p.dh = take(Mmax * ff * 2);
+    p.dctx = take(Mmax * inner * 2);
+    p.dqkv = take(Mmax * 3 * inner * 2);
+    p.dq_c = take(Md * inner * 2);
+    p.dkv_all = take(Mx * (size_t)Ld * 2 * inner * 2);
+    p.d_enc_ext = take(Mx * d * 4);
+    p.dS_enc = take((size_t)Le * B * H * L * L * 4);
+    p.dS_dec = take((size_t)Ld * B * H * T * T * 4);
+    p.dlogits = take(Md * (size_t)c.vocab * 2);
+    size_t wmax = ff * d;
+    if (3 * inner * d > wmax) wmax = 3 * inner * d;
+    p.slab_bytes = 8 * wmax * 4;
+    p.slab = take(p.slab_bytes);
+    p.ln_partial = take((size_t)256 * d * 4);
+    p.vis_partial = take(((size_t)64 * 10 * d + 2 * (size_t)B * V) * 4);
+    size_t rs = H * (size_t)(L > T ? L : T) * (L > T ? L : T) * 4;
+    p.rel_scratch = take(rs);
+    p.vis_dG = take((size_t)B * V * d * 2);
+    p.small = take(10 * d * 4);
+    p.total = off;
+}
+
+struct Ctx {
+    const vlt5_config& c;
+    const vlt5_step& s;
+    hipStream_t st;
+    Layout lay;
+    Plan p;
+    char* ws;
+    const float* P;
+    const bf16_t* Pb;
+    float* Gr;
+    float pdrop;
+    int d, inner, ff, H;
+    Ctx(const vlt5_config& c_, const vlt5_step& s_, void* stream) : c(c_), s(s_), st((hipStream_t)stream) {
+        build_layout(c, lay, false);
+        make_plan(c, s.B, s.L, s.V, s.T, p);
+        ws = (char*)s.workspace;
+        P = s.params; Pb = (const bf16_t*)s.params_bf16; Gr = s.grads;
+        pdrop = s.training ? c.dropout : 0.f;
+        d = c.d_model; inner = c.num_heads * c.d_kv; ff = c.d_ff; H = c.num_heads;
+    }
+    template <class T> T* w(size_t off) const { return reinterpret_cast<T*>(ws + off); }
+    uint32_t seed(uint32_t site) const { return site_seed(s.seed, site); }
+    int check(bool bwd) const {
+        if (!s.params || !s.params_bf16 || !s.workspace) return VLT5_ERR_ARG;
+        if (bwd && !s.grads) return VLT5_ERR_ARG;
+        if (s.workspace_bytes < (long long)p.total) return VLT5_ERR_ARG;
+        if (c.num_layers > MAXL || c.num_decoder_layers > MAXL) return VLT5_ERR_ARG;
+        if (p.Sx > 64 || s.T > 64 || c.d_kv > 64 || s.B < 1 || s.L < 1 || s.V < 1 || s.T < 1) return VLT5_ERR_ARG;
+        if ((d & 7) || (inner & 7) || (ff & 7) || (c.vocab & 7) || (c.feat_dim & 7) || (c.d_kv & 7)) return VLT5_ERR_ALIGN;
+        return VLT5_OK;
+    }
+
+    // y[M,N] = epi(alpha * x[M,K] W[N,K]^T)
+    int lin_fwd(const bf16_t* X, const bf16_t* W, void* C, int M, int N, int K, int out_f32, float alpha = 1.f,
+                const float* bias = nullptr, int relu = 0, float dp = 0.f, uint32_t dseed = 0, const float* resid = nullptr) const {
+        vlt5_gemm_desc g;
+        memset(&g, 0, sizeof g);
+        g.A = X; g.B = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
+        g.alpha = alpha; g.bias = bias; g.relu = relu; g.drop_p = dp; g.drop_seed = dseed; g.resid = resid; g.ldr = N;
+        g.out_f32 = out_f32;
+        return vlt5_gemm_bf16(&g, st);
+    }
+    // dX[M,K] = epi(alpha * dY[M,N] W[N,K])     (W read k-major)
+    int lin_dgrad(const bf16_t* dY, const bf16_t* W, void* dX, int M, int N, int K, int out_f32, float alpha = 1.f,
+                  const bf16_t* gate = nullptr, float gate_scale = 1.f) const {
+        vlt5_gemm_desc g;
+        memset(&g, 0, sizeof g);
+        g.A = dY; g.B = W; g.C = dX; g.M = M; g.N = K; g.K = N; g.lda = N; g.ldb = K; g.ldc = K; g.b_kmajor = 1;
+        g.alpha = alpha; g.gate = gate; g.ldg = K; g.gate_scale = gate_scale; g.out_f32 = out_f32;
+        return vlt5_gemm_bf16(&g, st);
+    }
+    // dW[N,K] (+)= alpha * dY[M,N]^T X[M,K]     (both read k-major, reduction over the M rows)
+    int lin_wgrad(const bf16_t* dY, int ldy, const bf16_t* X, int ldx, float* dW, int M, int N, int K, float alpha = 1.f,
+                  int accum = 0) const {
+        vlt5_gemm_desc g;
+        memset(&g, 0, sizeof g);
+        g.A = dY; g.B = X; g.C = dW; g.M = N; g.N = K; g.K = M; g.lda = ldy; g.ldb = ldx; g.ldc = K;
+        g.a_kmajor = 1; g.b_kmajor = 1; g.alpha = alpha; g.out_f32 = 1; g.accum = accum;
+        long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
+        if (M >= 2048 && tiles < 384 && alpha == 1.f) {
+            int sk = (int)((512 + tiles - 1) / tiles);
+            if (sk > 8) sk = 8;
+            if ((size_t)sk * N * K * 4 <= p.slab_bytes && sk > 1) { g.split_k = sk; g.workspace = w<void>(p.slab); }
+        }
+        return vlt5_gemm_bf16(&g, st);
+    }
+    int record(int k) const {
+        if (s.events && k >= 0 && k < s.n_events && s.events[k]) HIP_RET(hipEventRecord((hipEvent_t)s.events[k], st));
+        return VLT5_OK;
+    }
+};
+
+#define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+int attn_call(const Ctx& k, bool bwd, const bf16_t* q, long long q_sb, long long q_st, const bf16_t* kk, const bf16_t* v,
+              long long kv_sb, long long kv_st, bf16_t* ctx, float* lse, const float* bias, int bq, int bk, const float* kmask,
+              float mval, int causal, int Tq, int Tk, uint32_t dseed, const bf16_t* dctx = nullptr, bf16_t* dq = nullptr,
+              long long dq_sb = 0, long long dq_st = 0, bf16_t* dk = nullptr, bf16_t* dv = nullptr, long long dkv_sb = 0,
+              long long dkv_st = 0, float* dbias = nullptr) {
+    vlt5_attn_desc a;
+    memset(&a, 0, sizeof a);
+    a.q = q; a.k = kk; a.v = v; a.q_sb = q_sb; a.q_st = q_st; a.k_sb = kv_sb; a.k_st = kv_st; a.v_sb = kv_sb; a.v_st = kv_st;
+    a.ctx = ctx; a.o_sb = (long long)Tq * k.inner; a.o_st = k.inner; a.lse = lse;
+    a.bias = bias; a.bias_q = bq; a.bias_k = bk; a.key_mask = kmask; a.mask_value = mval; a.causal = causal;
+    a.B = k.s.B; a.H = k.H; a.Tq = Tq; a.Tk = Tk; a.dk = k.c.d_kv; a.drop_p = k.pdrop; a.drop_seed = dseed;
+    if (!bwd) return vlt5_attn_fwd(&a, k.st);
+    a.d_ctx = dctx; a.do_sb = (long long)Tq * k.inner; a.do_st = k.inner;
+    a.dq = dq; a.dq_sb = dq_sb; a.dq_st = dq_st; a.dk_ = dk; a.dv = dv; a.dk_sb = dkv_sb; a.dk_st = dkv_st; a.dv_sb = dkv_sb;
+    a.dv_st = dkv_st; a.dbias = dbias;
+    return vlt5_attn_bwd(&a, k.st);
+}
+
+int encoder_fwd(const Ctx& k) {
+    const Plan& p = k.p; const Layout& L = k.lay; const vlt5_config& c = k.c; const vlt5_step& s = k.s;
+    const int d = k.d, inner = k.inner, ff = k.ff, M = p.M, S = p.S, Sx = p.Sx, B = s.B;
+    float* x0 = k.w<float>(p.x[0]);
+    RC(vlt5_build_mask(s.input_ids, k.w<float>(p.mask), B, s.L, S, c.pad_id, k.st));
+    RC(vlt5_relbias_build(k.P + L.enc_rel, s.enc_lut, k.w<float>(p.enc_bias), k.H, s.L, s.L, c.rel_buckets, k.st));
+    RC(vlt5_embed_fwd(s.input_ids, k.P + L.shared, x0, (long long)S * d, d, B, s.L, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, 0, k.st));
+    RC(vlt5_cast_bf16(s.vis_feats, k.w<void>(p.feats_bf16), (long long)B * s.V * c.feat_dim, k.st));
+    RC(k.lin_fwd(k.w<bf16_t>(p.feats_bf16), k.Pb + L.vis_wf, k.w<void>(p.visG), B * s.V, d, c.feat_dim, 1, 1.f, k.P + L.vis_bf));
+    RC(vlt5_vis_embed_fwd(k.w<float>(p.visG), s.boxes, k.P + L.vis_wp, k.P + L.vis_bp, k.P + L.vis_lnf, k.P + L.vis_lnp,
+                          k.P + L.vis_img, k.P + L.shared, x0 + (size_t)s.L * d, (long long)S * d, d, k.w<float>(p.vis_rf),
+                          k.w<float>(p.vis_rp), B, s.V, d, c.vocab, c.eps, k.pdrop, k.seed(SITE_ENC_EMBED), S, s.L, k.st));
+    for (int l = 0; l < c.num_layers; ++l) {
+        const auto& E = L.enc[l];
+        const uint32_t sb = SITE_ENC_BASE + l * 8;
+        float* xa = k.w<float>(p.x[2 * l]);
+        float* xf = k.w<float>(p.x[2 * l + 1]);
+        float* xo = k.w<float>(p.x[2 * l + 2]);
+        bf16_t* qkv = k.w<bf16_t>(p.qkv[l]);
+        RC(vlt5_layernorm_fwd(xa, k.P + E.ln_s, k.w<void>(p.xn_a[l]), nullptr, k.w<float>(p.xr[2 * l]), M, d, c.eps, 0.f, 0, 0, 0, k.st));
+        RC(k.lin_fwd(k.w<bf16_t>(p.xn_a[l]), k.Pb + E.sqkv, qkv, M, 3 * inner, d, 0));
+        RC(attn_call(k, false, qkv, (long long)S * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)S * 3 * inner,
+                     3 * inner, k.w<bf16_t>(p.ctx[l]), k.w<float>(p.lse[l]), k.w<float>(p.enc_bias), s.L, s.L, k.w<float>(p.mask),
+                     -10000.f, 0, S, S, k.seed(sb + E_PROBS)));
+        RC(k.lin_fwd(k.w<bf16_t>(p.ctx[l]), k.Pb + E.so, xf, M, d, inner, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + E_ATTN_OUT), xa));
+        RC(vlt5_layernorm_fwd(xf, k.P + E.ln_f, k.w<void>(p.xn_f[l]), nullptr, k.w<float>(p.xr[2 * l + 1]), M, d, c.eps, 0.f, 0, 0, 0, k.st));
+        RC(k.lin_fwd(k.w<bf16_t>(p.xn_f[l]), k.Pb + E.wi, k.w<void>(p.h[l]), M, ff, d, 0, 1.f, nullptr, 1, k.pdrop, k.seed(sb + E_FFN_H)));
+        RC(k.lin_fwd(k.w<bf16_t>(p.h[l]), k.Pb + E.wo, xo, M, d, ff, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + E_FFN_OUT), xf));
+    }
+    const int Le = c.num_layers;
+    RC(vlt5_layernorm_fwd(k.w<float>(p.x[2 * Le]), k.P + L.enc_final_ln, k.w<void>(p.enc_ext), k.w<float>(p.enc_out),
+                          k.w<float>(p.xr[2 * Le]), M, d, c.eps, k.pdrop, k.seed(SITE_ENC_FINAL), S, Sx, k.st));
+    return VLT5_OK;
+}
+
+int decoder_fwd(const Ctx& k) {
+    const Plan& p = k.p; const Layout& L = k.lay; const vlt5_config& c = k.c; const vlt5_step& s = k.s;
+    const int d = k.d, inner = k.inner, ff = k.ff, Md = p.Md, Mx = p.Mx, Sx = p.Sx, B = s.B, T = s.T, Ld = c.num_decoder_layers;
+    const int kvw = Ld * 2 * inner;
+    long long* ids = k.w<long long>(p.dec_ids);
+    RC(vlt5_shift_right(s.labels, ids, B, T, c.dec_start_id, c.pad_id, k.st));
+    RC(vlt5_build_mask(s.input_ids, k.w<float>(p.mask_ext), B, s.L, Sx, c.pad_id, k.st));
+    RC(vlt5_relbias_build(k.P + L.dec_rel, s.dec_lut, k.w<float>(p.dec_bias), k.H, T, T, c.rel_buckets, k.st));
+    RC(k.lin_fwd(k.w<bf16_t>(p.enc_ext), k.Pb + L.cross_kv, k.w<void>(p.kv_all), Mx, kvw, d, 0));
+    RC(vlt5_embed_fwd(ids, k.P + L.shared, k.w<float>(p.y[0]), (long long)T * d, d, B, T, d, c.vocab, k.pdrop, k.seed(SITE_DEC_EMBED), T, 0, k.st));
+    for (int l = 0; l < Ld; ++l) {
+        const auto& D = L.dec[l];
+        const uint32_t sb = SITE_DEC_BASE + l * 8;
+        float* y0 = k.w<float>(p.y[3 * l]);
+        float* y1 = k.w<float>(p.y[3 * l + 1]);
+        float* y2 = k.w<float>(p.y[3 * l + 2]);
+        float* y3 = k.w<float>(p.y[3 * l + 3]);
+        bf16_t* qkv = k.w<bf16_t>(p.dqkv_s[l]);
+        bf16_t* kv = k.w<bf16_t>(p.kv_all) + (size_t)l * 2 * inner;
+        RC(vlt5_layernorm_fwd(y0, k.P + D.ln_s, k.w<void>(p.yn_a[l]), nullptr, k.w<float>(p.yr[3 * l]), Md, d, c.eps, 0.f, 0, 0, 0, k.st));
+        RC(k.lin_fwd(k.w<bf16_t>(p.yn_a[l]), k.Pb + D.sqkv, qkv, Md, 3 * inner, d, 0));
+        RC(attn_call(k, false, qkv, (long long)T * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)T * 3 * inner,
+                     3 * inner, k.w<bf16_t>(p.ctx_s[l]), k.w<float>(p.lse_s[l]), k.w<float>(p.dec_bias), T, T, nullptr, 0.f, 1, T, T,
+                     k.seed(sb + D_SPROBS)));
+        RC(k.lin_fwd(k.w<bf16_t>(p.ctx_s[l]), k.Pb + D.so, y1, Md, d, inner, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + D_SOUT), y0));
+        RC(vlt5_layernorm_fwd(y1, k.P + D.ln_c, k.w<void>(p.yn_c[l]), nullptr, k.w<float>(p.yr[3 * l + 1]), Md, d, c.eps, 0.f, 0, 0, 0, k.st));
+        RC(k.lin_fwd(k.w<bf16_t>(p.yn_c[l]), k.Pb + D.cq, k.w<void>(p.qc[l]), Md, inner, d, 0));
+        RC(attn_call(k, false, k.w<bf16_t>(p.qc[l]), (long long)T * inner, inner, kv, kv + inner, (long long)Sx * kvw, kvw,
+                     k.w<bf16_t>(p.ctx_c[l]), k.w<float>(p.lse_c[l]), nullptr, 0, 0, k.w<float>(p.mask_ext), -1e9f, 0, T, Sx,
+                     k.seed(sb + D_CPROBS)));
+        RC(k.lin_fwd(k.w<bf16_t>(p.ctx_c[l]), k.Pb + D.co, y2, Md, d, inner, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + D_COUT), y1));
+        RC(vlt5_layernorm_fwd(y2, k.P + D.ln_f, k.w<void>(p.yn_f[l]), nullptr, k.w<float>(p.yr[3 * l + 2]), Md, d, c.eps, 0.f, 0, 0, 0, k.st));
+        RC(k.lin_fwd(k.w<bf16_t>(p.yn_f[l]), k.Pb + D.wi, k.w<void>(p.hd[l]), Md, ff, d, 0, 1.f, nullptr, 1, k.pdrop, k.seed(sb + D_FFN_H)));
+        RC(k.lin_fwd(k.w<bf16_t>(p.hd[l]), k.Pb + D.wo, y3, Md, d, ff, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + D_FFN_OUT), y2));
+    }
+    RC(vlt5_layernorm_fwd(k.w<float>(p.y[3 * Ld]), k.P + L.dec_final_ln, k.w<void>(p.dec_out), nullptr, k.w<float>(p.yr[3 * Ld]), Md,
+                          d, c.eps, k.pdrop, k.seed(SITE_DEC_FINAL), 0, 0, k.st));
+    const float alpha = 1.0f / sqrtf((float)d);           // tied embeddings: rescale before the vocabulary projection
+    RC(k.lin_fwd(k.w<bf16_t>(p.dec_out), k.Pb + L.shared, k.w<void>(p.logits), Md, c.vocab, d, 1, alpha));
+    RC(vlt5_ce_fwd(k.w<float>(p.logits), s.labels, k.w<float>(p.loss_tok), k.w<float>(p.lse_ce), Md, c.vocab, k.st));
+    if (s.scores)
+        RC(vlt5_loss_reduce(k.w<float>(p.loss_tok), s.labels, s.scores, k.w<float>(p.loss), k.w<float>(p.row_w), B, T, k.st));
+    return VLT5_OK;
+}
+
+// backward of one  x_out = x_in + drop(W_o . drop(relu(W_i . LN(x_in))))  sublayer; dx is updated in place
+int ffn_bwd(const Ctx& k, int M, float* dx, const float* x_in, const float* rstd, const bf16_t* xn, const bf16_t* h, long long wi,
+            long long wo, long long ln, uint32_t seed_h, uint32_t seed_out) {
+    const Plan& p = k.p;
+    const int d = k.d, ff = k.ff;
+    bf16_t* dyd = k.w<bf16_t>(p.dyd);
+    bf16_t* dh = k.w<bf16_t>(p.dh);
+    float* tmp = k.w<float>(p.tmp);
+    (void)seed_h;
+    RC(vlt5_drop_cast(dx, dyd, M, d, k.pdrop, seed_out, k.st));
+    RC(k.lin_wgrad(dyd, d, h, ff, k.Gr + wo, M, d, ff));
+    const float gs = k.pdrop > 0.f ? drop_scale(drop_thr16(k.pdrop)) : 1.f;
+    RC(k.lin_dgrad(dyd, k.Pb + wo, dh, M, d, ff, 0, 1.f, h, gs));
+    RC(k.lin_wgrad(dh, ff, xn, d, k.Gr + wi, M, ff, d));
+    RC(k.lin_dgrad(dh, k.Pb + wi, tmp, M, ff, d, 1));
+    RC(vlt5_layernorm_bwd(tmp, x_in, k.P + ln, rstd, dx, k.Gr + ln, k.w<float>(p.ln_partial), M, d, 1, 0, 0.f, 0, 0, 0, k.st));
+    return VLT5_OK;
+}
+
+int decoder_bwd(const Ctx& k) {
+    const Plan& p = k.p; const Layout& L = k.lay; const vlt5_config& c = k.c; const vlt5_step& s = k.s;
+    const int d = k.d, inner = k.inner, Md = p.Md, Mx = p.Mx, Sx = p.Sx, B = s.B, T = s.T, Ld = c.num_decoder_layers;
+    const int kvw = Ld * 2 * inner;
+    const float alpha = 1.0f / sqrtf((float)d);
+    float* dx = k.w<float>(p.dx);
+    float* tmp = k.w<float>(p.tmp);
+    bf16_t* dyd = k.w<bf16_t>(p.dyd);
+    bf16_t* dctx = k.w<bf16_t>(p.dctx);
+    bf16_t* dqkv = k.w<bf16_t>(p.dqkv);
+    bf16_t* dq_c = k.w<bf16_t>(p.dq_c);
+    bf16_t* dlog = k.w<bf16_t>(p.dlogits);
+    float* lnp = k.w<float>(p.ln_partial);
+    const long long* ids = k.w<long long>(p.dec_ids);
+    RC(vlt5_ce_bwd(k.w<float>(p.logits), s.labels, k.w<float>(p.lse_ce), s.d_loss_tok ? s.d_loss_tok : k.w<float>(p.row_w),
+                   s.d_loss_tok ? nullptr : s.gout, dlog, Md, c.vocab, k.st));
+    // lm_head (tied to shared): dShared = alpha * dlogits^T dec_out ; d dec_out = alpha * dlogits shared
+    RC(k.lin_wgrad(dlog, c.vocab, k.w<bf16_t>(p.dec_out), d, k.Gr + L.shared, Md, c.vocab, d, alpha, 0));
+    RC(k.lin_dgrad(dlog, k.Pb + L.shared, tmp, Md, c.vocab, d, 1, alpha));
+    RC(vlt5_layernorm_bwd(tmp, k.w<float>(p.y[3 * Ld]), k.P + L.dec_final_ln, k.w<float>(p.yr[3 * Ld]), dx, k.Gr + L.dec_final_ln, lnp,
+                          Md, d, 0, 0, k.pdrop, k.seed(SITE_DEC_FINAL), 0, 0, k.st));
+    for (int l = Ld - 1; l >= 0; --l) {
+        const auto& D = L.dec[l];
+        const uint32_t sb = SITE_DEC_BASE + l * 8;
+        bf16_t* qkv = k.w<bf16_t>(p.dqkv_s[l]);
+        bf16_t* kv = k.w<bf16_t>(p.kv_all) + (size_t)l * 2 * inner;
+        bf16_t* dkv = k.w<bf16_t>(p.dkv_all) + (size_t)l * 2 * inner;
+        RC(ffn_bwd(k, Md, dx, k.w<float>(p.y[3 * l + 2]), k.w<float>(p.yr[3 * l + 2]), k.w<bf16_t>(p.yn_f[l]), k.w<bf16_t>(p.hd[l]),
+                   D.wi, D.wo, D.ln_f, k.seed(sb + D_FFN_H), k.seed(sb + D_FFN_OUT)));
+        // cross-attention sublayer
+        RC(vlt5_drop_cast(dx, dyd, Md, d, k.pdrop, k.seed(sb + D_COUT), k.st));
+        RC(k.lin_wgrad(dyd, d, k.w<bf16_t>(p.ctx_c[l]), inner, k.Gr + D.co, Md, d, inner));
+        RC(k.lin_dgrad(dyd, k.Pb + D.co, dctx, Md, d, inner, 0));
+        RC(attn_call(k, true, k.w<bf16_t>(p.qc[l]), (long long)T * inner, inner, kv, kv + inner, (long long)Sx * kvw, kvw, nullptr,
+                     k.w<float>(p.lse_c[l]), nullptr, 0, 0, k.w<float>(p.mask_ext), -1e9f, 0, T, Sx, k.seed(sb + D_CPROBS), dctx, dq_c,
+                     (long long)T * inner, inner, dkv, dkv + inner, (long long)Sx * kvw, kvw, nullptr));
+        RC(k.lin_wgrad(dq_c, inner, k.w<bf16_t>(p.yn_c[l]), d, k.Gr + D.cq, Md, inner, d));
+        RC(k.lin_dgrad(dq_c, k.Pb + D.cq, tmp, Md, inner, d, 1));
+        RC(vlt5_layernorm_bwd(tmp, k.w<float>(p.y[3 * l + 1]), k.P + D.ln_c, k.w<float>(p.yr[3 * l + 1]), dx, k.Gr + D.ln_c, lnp, Md, d,
+                              1, 0, 0.f, 0, 0, 0, k.st));
+        // causal self-attention sublayer
+        RC(vlt5_drop_cast(dx, dyd, Md, d, k.pdrop, k.seed(sb + D_SOUT), k.st));
+        RC(k.lin_wgrad(dyd, d, k.w<bf16_t>(p.ctx_s[l]), inner, k.Gr + D.so, Md, d, inner));
+        RC(k.lin_dgrad(dyd, k.Pb + D.so, dctx, Md, d, inner, 0));
+        RC(attn_call(k, true, qkv, (long long)T * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)T * 3 * inner,
+                     3 * inner, nullptr, k.w<float>(p.lse_s[l]), k.w<float>(p.dec_bias), T, T, nullptr, 0.f, 1, T, T,
+                     k.seed(sb + D_SPROBS), dctx, dqkv, (long long)T * 3 * inner, 3 * inner, dqkv + inner, dqkv + 2 * inner,
+                     (long long)T * 3 * inner, 3 * inner, k.w<float>(p.dS_dec) + (size_t)l * B * k.H * T * T));
+        RC(k.lin_wgrad(dqkv, 3 * inner, k.w<bf16_t>(p.yn_a[l]), d, k.Gr + D.sqkv, Md, 3 * inner, d));
+        RC(k.lin_dgrad(dqkv, k.Pb + D.sqkv, tmp, Md, 3 * inner, d, 1));
+        RC(vlt5_layernorm_bwd(tmp, k.w<float>(p.y[3 * l]), k.P + D.ln_s, k.w<float>(p.yr[3 * l]), dx, k.Gr + D.ln_s, lnp, Md, d, 1, 0,
+                              0.f, 0, 0, 0, k.st));
+        if (l == 0)
+            RC(vlt5_relbias_bwd(k.w<float>(p.dS_dec), s.dec_lut, k.Gr + L.dec_rel, k.w<float>(p.rel_scratch), Ld * B, k.H, T, T,
+                                c.rel_buckets, 0, k.st));
+        RC(k.record(Ld - 1 - l));
+    }
+    RC(vlt5_embed_bwd(ids, dx, (long long)T * d, d, k.Gr + L.shared, B, T, d, c.vocab, k.pdrop, k.seed(SITE_DEC_EMBED), T, 0, k.st));
+    // cross-attention K/V projections of all layers at once
+    RC(k.lin_wgrad(k.w<bf16_t>(p.dkv_all), kvw, k.w<bf16_t>(p.enc_ext), d, k.Gr + L.cross_kv, Mx, kvw, d));
+    RC(k.lin_dgrad(k.w<bf16_t>(p.dkv_all), k.Pb + L.cross_kv, k.w<void>(p.d_enc_ext), Mx, kvw, d, 1));
+    RC(k.record(Ld));
+    return VLT5_OK;
+}
+
+int encoder_bwd(const Ctx& k) {
+    const Plan& p = k.p; const Layout& L = k.lay; const vlt5_config& c = k.c; const vlt5_step& s = k.s;
+    const int d = k.d, inner = k.inner, M = p.M, S = p.S, Sx = p.Sx, B = s.B, Le = c.num_layers, Ld = c.num_decoder_layers;
+    float* dx = k.w<float>(p.dx);
+    float* tmp = k.w<float>(p.tmp);
+    bf16_t* dyd = k.w<bf16_t>(p.dyd);
+    bf16_t* dctx = k.w<bf16_t>(p.dctx);
+    bf16_t* dqkv = k.w<bf16_t>(p.dqkv);
+    float* lnp = k.w<float>(p.ln_partial);
+    // the 2 prototype rows of every sample are detached (src/modeling_t5_our.py:615): only rows 0..S-1 flow back
+    RC(vlt5_layernorm_bwd(k.w<float>(p.d_enc_ext), k.w<float>(p.x[2 * Le]), k.P + L.enc_final_ln, k.w<float>(p.xr[2 * Le]), dx,
+                          k.Gr + L.enc_final_ln, lnp, M, d, 0, 0, k.pdrop, k.seed(SITE_ENC_FINAL), S, Sx, k.st));
+    for (int l = Le - 1; l >= 0; --l) {
+        const auto& E = L.enc[l];
+        const uint32_t sb = SITE_ENC_BASE + l * 8;
+        bf16_t* qkv = k.w<bf16_t>(p.qkv[l]);
+        RC(ffn_bwd(k, M, dx, k.w<float>(p.x[2 * l + 1]), k.w<float>(p.xr[2 * l + 1]), k.w<bf16_t>(p.xn_f[l]), k.w<bf16_t>(p.h[l]), E.wi,
+                   E.wo, E.ln_f, k.seed(sb + E_FFN_H), k.seed(sb + E_FFN_OUT)));
+        RC(vlt5_drop_cast(dx, dyd, M, d, k.pdrop, k.seed(sb + E_ATTN_OUT), k.st));
+        RC(k.lin_wgrad(dyd, d, k.w<bf16_t>(p.ctx[l]), inner, k.Gr + E.so, M, d, inner));
+        RC(k.lin_dgrad(dyd, k.Pb + E.so, dctx, M, d, inner, 0));
+        RC(attn_call(k, true, qkv, (long long)S * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)S * 3 * inner,
+                     3 * inner, nullptr, k.w<float>(p.lse[l]), k.w<float>(p.enc_bias), s.L, s.L, k.w<float>(p.mask), -10000.f, 0, S, S,
+                     k.seed(sb + E_PROBS), dctx, dqkv, (long long)S * 3 * inner, 3 * inner, dqkv + inner, dqkv + 2 * inner,
+                     (long long)S * 3 * inner, 3 * inner, k.w<float>(p.dS_enc) + (size_t)l * B * k.H * s.L * s.L));
+        RC(k.lin_wgrad(dqkv, 3 * inner, k.w<bf16_t>(p.xn_a[l]), d, k.Gr + E.sqkv, M, 3 * inner, d));
+        RC(k.lin_dgrad(dqkv, k.Pb + E.sqkv, tmp, M, 3 * inner, d, 1));
+        RC(vlt5_layernorm_bwd(tmp, k.w<float>(p.x[2 * l]), k.P + E.ln_s, k.w<float>(p.xr[2 * l]), dx, k.Gr + E.ln_s, lnp, M, d, 1, 0, 0.f,
+                              0, 0, 0, k.st));
+        if (l == 0)
+            RC(vlt5_relbias_bwd(k.w<float>(p.dS_enc), s.enc_lut, k.Gr + L.enc_rel, k.w<float>(p.rel_scratch), Le * B, k.H, s.L, s.L,
+                                c.rel_buckets, 0, k.st));
+        RC(k.record(Ld + 1 + (Le - 1 - l)));
+    }
+    // inputs: text rows -> shared (scatter-add), visual rows -> visual embedding parameters
+    RC(vlt5_embed_bwd(s.input_ids, dx, (long long)S * d, d, k.Gr + L.shared, B, s.L, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, 0, k.st));
+    float* vpart = k.w<float>(p.vis_partial);
+    RC(vlt5_vis_embed_bwd(dx + (size_t)s.L * d, (long long)S * d, d, k.w<float>(p.visG), s.boxes, k.P + L.vis_wp, k.P + L.vis_bp,
+                          k.P + L.vis_lnf, k.P + L.vis_lnp, k.w<float>(p.vis_rf), k.w<float>(p.vis_rp), k.w<void>(p.vis_dG), vpart,
+                          k.Gr + L.shared, B, s.V, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, s.L, k.st));
+    const int nsp = vlt5_vis_embed_bwd_blocks(B * s.V);
+    RC(vlt5_colsum(vpart, k.Gr + L.vis_lnf, nsp, d, 10 * d, 0, k.st));
+    RC(vlt5_colsum(vpart + d, k.Gr + L.vis_lnp, nsp, d, 10 * d, 0, k.st));
+    RC(vlt5_colsum(vpart + 2 * d, k.Gr + L.vis_bp, nsp, d, 10 * d, 0, k.st));
+    RC(vlt5_colsum(vpart + 3 * d, k.Gr + L.vis_wp, nsp, 5 * d, 10 * d, 0, k.st));
+    // img_order_embedding has n_images rows; only row 0 is ever looked up (src/modeling_t5_our.py:121-124)
+    HIP_RET(hipMemsetAsync(k.Gr + L.vis_img, 0, (size_t)c.n_images * d * 4, k.st));
+    RC(vlt5_colsum(vpart + 8 * d, k.Gr + L.vis_img, nsp, d, 10 * d, 0, k.st));
+    RC(vlt5_colsum(vpart + 9 * d, k.Gr + L.vis_bf, nsp, d, 10 * d, 0, k.st));
+    RC(k.lin_wgrad(k.w<bf16_t>(p.vis_dG), d, k.w<bf16_t>(p.feats_bf16), c.feat_dim, k.Gr + L.vis_wf, B * s.V, d, c.feat_dim));
+    RC(k.record(Ld + 1 + Le));
+    return VLT5_OK;
+}
+
+}  // namespace
+
+extern "C" int vlt5_layout_count(const vlt5_config* c) {
+    if (!c) return -1;
+    Layout L;
+    build_layout(*c, L, true);
+    return (int)L.e.size();
+}
+extern "C" int vlt5_layout_get(const vlt5_config* c, int i, char* name, int name_cap, long long* offset, int* rows, int* cols,
+                               int* bucket, int* decay, int* used) {
+    if (!c || !name || name_cap < 128) return VLT5_ERR_ARG;
+    Layout L;
+    build_layout(*c, L, true);
+    if (i < 0 || i >= (int)L.e.size()) return VLT5_ERR_ARG;
+    const Entry& e = L.e[i];
+    snprintf(name, name_cap, "%s", e.name.c_str());
+    if (offset) *offset = e.off;
+    if (rows) *rows = e.rows;
+    if (cols) *cols = e.cols;
+    if (bucket) *bucket = e.bucket;
+    if (decay) *decay = e.decay;
+    if (used) *used = e.used;
+    return VLT5_OK;
+}
+extern "C" long long vlt5_layout_total(const vlt5_config* c) {
+    if (!c) return -1;
+    Layout L;
+    build_layout(*c, L, false);
+    return L.total;
+}
+extern "C" int vlt5_layout_buckets(const vlt5_config* c) {
+    if (!c) return -1;
+    Layout L;
+    build_layout(*c, L, false);
+    return L.nbuckets;
+}
+extern "C" long long vlt5_workspace_bytes(const vlt5_config* c, int B, int L, int V, int T) {
+    if (!c || B < 1 || L < 1 || V < 1 || T < 1) return -1;
+    Plan p;
+    make_plan(*c, B, L, V, T, p);
+    return (long long)p.total;
+}
+extern "C" long long vlt5_workspace_offset(const vlt5_config* c, int B, int L, int V, int T, int which) {
+    if (!c) return -1;
+    Plan p;
+    make_plan(*c, B, L, V, T, p);
+    switch (which) {
+        case VLT5_WS_ENC_OUT: return (long long)p.enc_out;
+        case VLT5_WS_ENC_EXT: return (long long)p.enc_ext;
+        case VLT5_WS_LOGITS: return (long long)p.logits;
+        case VLT5_WS_LOSS_TOK: return (long long)p.loss_tok;
+        case VLT5_WS_LOSS: return (long long)p.loss;
+        case VLT5_WS_ENC_MASK_EXT: return (long long)p.mask_ext;
+        case VLT5_WS_DEC_OUT: return (long long)p.dec_out;
+        default: return -1;
+    }
+}
+
+#define ENGINE_ENTRY(fn, bwd)                                                   \
+    extern "C" int vlt5_##fn(const vlt5_config* c, const vlt5_step* s, void* stream) { \
+        if (!c || !s) return VLT5_ERR_ARG;                                      \
+        Ctx k(*c, *s, stream);                                                  \
+        int rc = k.check(bwd);                                                  \
+        if (rc) return rc;                                                      \
+        return fn(k);                                                           \
+    }
+ENGINE_ENTRY(encoder_fwd, false)
+ENGINE_ENTRY(decoder_fwd, false)
+ENGINE_ENTRY(decoder_bwd, true)
+ENGINE_ENTRY(encoder_bwd, true)

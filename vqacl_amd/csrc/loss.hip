@@ -1,0 +1,122 @@
+// lm_head cross-entropy over the 32200-entry vocabulary and the train_step loss reduction.
+// Bandwidth-bound: fwd reads R*V f32 logits once (+1 for the exp pass, L2-resident), bwd reads them once and
+// writes R*V bf16 dlogits.
+#include "common.h"
+#include "vlt5_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh) {
+    v = is_max ? wave_max(v) : wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int i = 1; i < nw; ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                     float* __restrict__ loss_tok, float* __restrict__ lse, int R, int V) {
+    __shared__ float sh[4];
+    const int r = blockIdx.x;
+    const float* row = logits + (size_t)r * V;
+    float m = -INFINITY;
+    for (int c = threadIdx.x * 4; c < V; c += 1024) {
+        float4 v = *reinterpret_cast<const float4*>(row + c);
+        m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    m = block_reduce(m, true, sh);
+    float s = 0.f;
+    for (int c = threadIdx.x * 4; c < V; c += 1024) {
+        float4 v = *reinterpret_cast<const float4*>(row + c);
+        s += expf(v.x - m) + expf(v.y - m) + expf(v.z - m) + expf(v.w - m);
+    }
+    s = block_reduce(s, false, sh);
+    if (threadIdx.x == 0) {
+        const float l = m + logf(s);
+        lse[r] = l;
+        const long long y = labels[r];
+        loss_tok[r] = (y >= 0 && y < V) ? (l - row[y]) : 0.f;          // ignore_index = -100 -> 0
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                     const float* __restrict__ lse, const float* __restrict__ row_w,
+                                                     const float* __restrict__ gout, bf16_t* __restrict__ dlogits, int R, int V) {
+    const int r = blockIdx.x;
+    const float* row = logits + (size_t)r * V;
+    bf16_t* drow = dlogits + (size_t)r * V;
+    const long long y = labels[r];
+    const bool valid = (y >= 0 && y < V);
+    const float w = valid ? row_w[r] * (gout ? gout[0] : 1.f) : 0.f;
+    const float l = lse[r];
+    for (int c = threadIdx.x * 4; c < V; c += 1024) {
+        float4 v = *reinterpret_cast<const float4*>(row + c);
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float p = valid ? expf(o[k] - l) : 0.f;
+            if (c + k == y) p -= 1.f;
+            o[k] = p * w;
+        }
+        uint2 pk;
+        pk.x = pack_bf16x2(o[0], o[1]);
+        pk.y = pack_bf16x2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(drow + c) = pk;
+    }
+}
+
+// one block; thread b handles sample b (grid-stride), fixed-order final sum by thread 0
+__global__ void loss_reduce_kernel(const float* __restrict__ loss_tok, const long long* __restrict__ labels,
+                                   const float* __restrict__ scores, float* __restrict__ loss, float* __restrict__ row_w, int B,
+                                   int T) {
+    extern __shared__ float per[];
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        float cnt = 0.f, s = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const bool m = labels[b * T + t] != -100;
+            cnt += m ? 1.f : 0.f;
+            s += m ? loss_tok[b * T + t] : 0.f;
+        }
+        const float den = fmaxf(cnt, 1.f);
+        per[b] = (s / den) * scores[b];
+        if (row_w)
+            for (int t = 0; t < T; ++t)
+                row_w[b * T + t] = (labels[b * T + t] != -100) ? scores[b] / (den * (float)B) : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int b = 0; b < B; ++b) tot += per[b];
+        loss[0] = tot / (float)B;
+    }
+}
+
+}  // namespace
+
+extern "C" int vlt5_ce_fwd(const float* logits, const long long* labels, float* loss_tok, float* lse, int R, int V, void* stream) {
+    if (!logits || !labels || !loss_tok || !lse || R <= 0 || V <= 0) return VLT5_ERR_ARG;
+    if (V & 3) return VLT5_ERR_ALIGN;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, labels, loss_tok, lse, R, V);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_ce_bwd(const float* logits, const long long* labels, const float* lse, const float* row_w, const float* gout,
+                           void* dlogits_bf16, int R, int V, void* stream) {
+    if (!logits || !labels || !lse || !row_w || !dlogits_bf16 || R <= 0 || V <= 0) return VLT5_ERR_ARG;
+    if (V & 3) return VLT5_ERR_ALIGN;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, labels, lse, row_w, gout,
+                       (bf16_t*)dlogits_bf16, R, V);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_loss_reduce(const float* loss_tok, const long long* labels, const float* scores, float* loss, float* row_w,
+                                int B, int T, void* stream) {
+    if (!loss_tok || !labels || !scores || !loss || B <= 0 || T <= 0) return VLT5_ERR_ARG;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), B * sizeof(float), (hipStream_t)stream, loss_tok, labels, scores,
+                       loss, row_w, B, T);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}

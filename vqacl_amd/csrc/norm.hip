@@ -1,0 +1,173 @@
+// T5LayerNorm (RMS norm) forward / backward, one wave64 per row, fp32 statistics.
+// Bandwidth-bound: algorithmic bytes fwd = rows*d*(4 in + 2 out bf16 [+4 f32 out]) ; bwd = rows*d*(4 dy + 4 x + 4..8 dx).
+#include "common.h"
+#include "vlt5_hip.h"
+
+namespace {
+
+__device__ __forceinline__ int remap_row(int r, int group, int gstride) {
+    return group > 0 ? (r / group) * gstride + (r % group) : r;
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     bf16_t* __restrict__ yb, float* __restrict__ yf,
+                                                     float* __restrict__ rstd_out, int rows, int d, float eps,
+                                                     uint32_t thr, uint32_t seed, int group, int gstride) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * d;
+    float ss = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(xr + c);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)d + eps);
+    if (lane == 0 && rstd_out) rstd_out[row] = rs;
+    const int orow = remap_row(row, group, gstride);
+    const float dsc = drop_scale(thr);
+    for (int c = lane * 4; c < d; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(xr + c);
+        float4 g = *reinterpret_cast<const float4*>(w + c);
+        float o[4] = {g.x * (v.x * rs), g.y * (v.y * rs), g.z * (v.z * rs), g.w * (v.w * rs)};
+        if (thr) {
+            uint32_t idx = (uint32_t)row * (uint32_t)d + (uint32_t)c;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = drop_keep(seed, idx + k, thr) ? o[k] * dsc : 0.f;
+        }
+        if (yf) *reinterpret_cast<float4*>(yf + (size_t)orow * d + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (yb) {
+            uint2 pk;
+            pk.x = pack_bf16x2(o[0], o[1]);
+            pk.y = pack_bf16x2(o[2], o[3]);
+            *reinterpret_cast<uint2*>(yb + (size_t)orow * d + c) = pk;
+        }
+    }
+}
+
+constexpr int LN_MAXCH = 8;   // d <= 2048
+
+// grid-stride over rows; each wave keeps dw partials for its columns, block-reduced through LDS
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ w, const float* __restrict__ rstd,
+                                                     float* __restrict__ dx, float* __restrict__ dwp, int rows, int d,
+                                                     int accum_dx, uint32_t thr, uint32_t seed, int group, int gstride) {
+    extern __shared__ float red[];                       // [4][d]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 dwacc[LN_MAXCH];
+#pragma unroll
+    for (int k = 0; k < LN_MAXCH; ++k) dwacc[k] = make_float4(0, 0, 0, 0);
+    const float dsc = drop_scale(thr);
+    const float inv_d = 1.0f / (float)d;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float* xr = x + (size_t)row * d;
+        const float* gr = dy + (size_t)remap_row(row, group, gstride) * d;
+        const float rs = rstd[row];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXCH; ++k) {
+            int c = lane * 4 + k * 256;
+            if (c < d) {
+                float4 xv = *reinterpret_cast<const float4*>(xr + c);
+                float4 gv = *reinterpret_cast<const float4*>(gr + c);
+                float4 wv = *reinterpret_cast<const float4*>(w + c);
+                float g[4] = {gv.x, gv.y, gv.z, gv.w};
+                if (thr) {
+                    uint32_t idx = (uint32_t)row * (uint32_t)d + (uint32_t)c;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] = drop_keep(seed, idx + q, thr) ? g[q] * dsc : 0.f;
+                }
+                s += g[0] * wv.x * xv.x + g[1] * wv.y * xv.y + g[2] * wv.z * xv.z + g[3] * wv.w * xv.w;
+                dwacc[k].x += g[0] * xv.x * rs; dwacc[k].y += g[1] * xv.y * rs;
+                dwacc[k].z += g[2] * xv.z * rs; dwacc[k].w += g[3] * xv.w * rs;
+            }
+        }
+        s = wave_sum(s);
+        const float coef = rs * rs * rs * s * inv_d;
+#pragma unroll
+        for (int k = 0; k < LN_MAXCH; ++k) {
+            int c = lane * 4 + k * 256;
+            if (c < d) {
+                float4 xv = *reinterpret_cast<const float4*>(xr + c);
+                float4 gv = *reinterpret_cast<const float4*>(gr + c);
+                float4 wv = *reinterpret_cast<const float4*>(w + c);
+                float g[4] = {gv.x, gv.y, gv.z, gv.w};
+                if (thr) {
+                    uint32_t idx = (uint32_t)row * (uint32_t)d + (uint32_t)c;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] = drop_keep(seed, idx + q, thr) ? g[q] * dsc : 0.f;
+                }
+                float4 o;
+                o.x = rs * g[0] * wv.x - xv.x * coef; o.y = rs * g[1] * wv.y - xv.y * coef;
+                o.z = rs * g[2] * wv.z - xv.z * coef; o.w = rs * g[3] * wv.w - xv.w * coef;
+                float* dp = dx + (size_t)row * d + c;
+                if (accum_dx) {
+                    float4 q = *reinterpret_cast<const float4*>(dp);
+                    o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+                }
+                *reinterpret_cast<float4*>(dp) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LN_MAXCH; ++k) {
+        int c = lane * 4 + k * 256;
+        if (c < d) *reinterpret_cast<float4*>(red + wave * d + c) = dwacc[k];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256)
+        dwp[(size_t)blockIdx.x * d + c] = red[c] + red[d + c] + red[2 * d + c] + red[3 * d + c];
+}
+
+__global__ void colsum_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int width, int row_stride,
+                              int accum) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    float s = accum ? out[c] : 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * row_stride + c];
+    out[c] = s;
+}
+
+}  // namespace
+
+extern "C" int vlt5_layernorm_bwd_blocks(int rows) {
+    int b = (rows + 3) / 4;
+    return b < 256 ? (b < 1 ? 1 : b) : 256;
+}
+
+extern "C" int vlt5_layernorm_fwd(const float* x, const float* w, void* y_bf16, float* y_f32, float* rstd, int rows, int d,
+                                  float eps, float drop_p, uint32_t drop_seed, int out_group, int out_group_stride,
+                                  void* stream) {
+    if (!x || !w || (!y_bf16 && !y_f32) || rows <= 0 || d <= 0) return VLT5_ERR_ARG;
+    if (d & 3) return VLT5_ERR_ALIGN;
+    uint32_t thr = drop_p > 0.f ? drop_thr16(drop_p) : 0u;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16_t*)y_bf16, y_f32,
+                       rstd, rows, d, eps, thr, drop_seed, out_group, out_group_stride);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+
+extern "C" int vlt5_layernorm_bwd(const float* dy, const float* x, const float* w, const float* rstd, float* dx, float* dw,
+                                  float* dw_partial, int rows, int d, int accum_dx, int accum_dw, float drop_p,
+                                  uint32_t drop_seed, int in_group, int in_group_stride, void* stream) {
+    if (!dy || !x || !w || !rstd || !dx || !dw || !dw_partial || rows <= 0) return VLT5_ERR_ARG;
+    if ((d & 3) || d > 256 * LN_MAXCH) return VLT5_ERR_ALIGN;
+    uint32_t thr = drop_p > 0.f ? drop_thr16(drop_p) : 0u;
+    int nblk = vlt5_layernorm_bwd_blocks(rows);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 4 * d * sizeof(float), (hipStream_t)stream, dy, x, w, rstd, dx,
+                       dw_partial, rows, d, accum_dx, thr, drop_seed, in_group, in_group_stride);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, dw_partial, dw, nblk, d,
+                       d, accum_dw);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+
+extern "C" int vlt5_colsum(const float* partial, float* out, int nblk, int width, int row_stride, int accum, void* stream) {
+    if (!partial || !out || nblk <= 0 || width <= 0 || row_stride < width) return VLT5_ERR_ARG;
+    hipLaunchKernelGGL(colsum_kernel, dim3((width + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, out, nblk, width,
+                       row_stride, accum);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}

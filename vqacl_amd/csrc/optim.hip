@@ -1,0 +1,180 @@
+// Optimizer-side kernels: global gradient norm, fused clip + AdamW over the flat parameter buffer (also refreshes the bf16
+// shadow the GEMMs read), fp32 -> bf16 cast.  HBM-bound: AdamW moves 28 B/param (+2 B for the shadow).
+#include "common.h"
+#include "vlt5_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long long n, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            float4 v = *reinterpret_cast<const float4*>(g + i);
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        } else {
+            for (long long k = i; k < n; ++k) s += g[k] * g[k];
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void sqnorm_final_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ total, int accum) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = accum ? total[0] : 0.f;
+        for (int i = 0; i < nblk; ++i) s += partial[i];
+        total[0] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ pb, long long n, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2,
+                                                    const float* __restrict__ total_sq, float max_norm, int hf_mode) {
+    float clip = 1.f;
+    if (total_sq) clip = fminf(1.f, max_norm / (sqrtf(total_sq[0]) + 1e-6f));
+    const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        const int cnt = (i + 3 < n) ? 4 : (int)(n - i);
+        float pv[4], gv[4], mv[4], vv[4];
+        if (cnt == 4) {
+            float4 a = *reinterpret_cast<const float4*>(p + i), b = *reinterpret_cast<const float4*>(g + i);
+            float4 c = *reinterpret_cast<const float4*>(m + i), e = *reinterpret_cast<const float4*>(v + i);
+            pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w; gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+            mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w; vv[0] = e.x; vv[1] = e.y; vv[2] = e.z; vv[3] = e.w;
+        } else {
+            for (int k = 0; k < cnt; ++k) { pv[k] = p[i + k]; gv[k] = g[i + k]; mv[k] = m[i + k]; vv[k] = v[i + k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < cnt) {
+                const float gr = gv[k] * clip;
+                mv[k] = b1 * mv[k] + (1.f - b1) * gr;
+                vv[k] = b2 * vv[k] + (1.f - b2) * gr * gr;
+                if (hf_mode) {           // transformers.AdamW: denom = sqrt(v)+eps ; step = lr*sqrt(bc2)/bc1 ; then decay
+                    const float step = lr * sqrtf(bc2) / bc1;
+                    pv[k] = pv[k] - step * (mv[k] / (sqrtf(vv[k]) + eps));
+                    if (wd > 0.f) pv[k] = pv[k] - lr * wd * pv[k];
+                } else {                 // torch.optim.AdamW: decay first ; denom = sqrt(v)/sqrt(bc2)+eps ; step = lr/bc1
+                    if (wd > 0.f) pv[k] = pv[k] * (1.f - lr * wd);
+                    pv[k] = pv[k] - (lr / bc1) * (mv[k] / (sqrtf(vv[k]) / sqrtf(bc2) + eps));
+                }
+            }
+        }
+        if (cnt == 4) {
+            *reinterpret_cast<float4*>(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            *reinterpret_cast<float4*>(m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+            *reinterpret_cast<float4*>(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            if (pb) {
+                uint2 pk;
+                pk.x = pack_bf16x2(pv[0], pv[1]);
+                pk.y = pack_bf16x2(pv[2], pv[3]);
+                *reinterpret_cast<uint2*>(pb + i) = pk;
+            }
+        } else {
+            for (int k = 0; k < cnt; ++k) {
+                p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k];
+                if (pb) pb[i + k] = f32_to_bf16(pv[k]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x * 8;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 7 < n) {
+            float4 a = *reinterpret_cast<const float4*>(src + i), b = *reinterpret_cast<const float4*>(src + i + 4);
+            uint4 o;
+            o.x = pack_bf16x2(a.x, a.y); o.y = pack_bf16x2(a.z, a.w); o.z = pack_bf16x2(b.x, b.y); o.w = pack_bf16x2(b.z, b.w);
+            *reinterpret_cast<uint4*>(dst + i) = o;
+        } else {
+            for (long long k = i; k < n; ++k) dst[k] = f32_to_bf16(src[k]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_add_kernel(float* __restrict__ dst, const float* __restrict__ src, float a, float b,
+                                                        long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = a * dst[i] + b * src[i];
+}
+
+__global__ __launch_bounds__(256) void drop_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n,
+                                                        uint32_t thr, uint32_t seed) {
+    const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    const float dsc = drop_scale(thr);
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        float4 a = *reinterpret_cast<const float4*>(src + i);
+        float o[4] = {a.x, a.y, a.z, a.w};
+        if (thr) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = drop_keep(seed, (uint32_t)(i + k), thr) ? o[k] * dsc : 0.f;
+        }
+        uint2 pk;
+        pk.x = pack_bf16x2(o[0], o[1]);
+        pk.y = pack_bf16x2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(dst + i) = pk;
+    }
+}
+
+inline int grid_for(long long n, int per_thread) {
+    long long b = (n / per_thread + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;         // 256 CUs x 8 blocks, grid-stride beyond that
+    return (int)b;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+extern "C" int vlt5_sqnorm_blocks(long long n) { return grid_for(n, 4); }
+extern "C" int vlt5_sqnorm(const float* g, long long n, float* partial, float* total_sq, int accum_total, void* stream) {
+    if (!g || !partial || !total_sq || n <= 0) return VLT5_ERR_ARG;
+    if (((uintptr_t)g) & 15) return VLT5_ERR_ALIGN;
+    int nblk = grid_for(n, 4);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk), dim3(256), 0, ST, g, n, partial);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(64), 0, ST, partial, nblk, total_sq, accum_total);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, const float* total_sq, float max_norm,
+                               int hf_mode, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return VLT5_ERR_ARG;
+    if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return VLT5_ERR_ALIGN;
+    if (p_bf16 && (((uintptr_t)p_bf16) & 7)) return VLT5_ERR_ALIGN;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 4)), dim3(256), 0, ST, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2, total_sq, max_norm, hf_mode);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream) {
+    if (!src || !dst_bf16 || n <= 0) return VLT5_ERR_ARG;
+    if ((((uintptr_t)src) | ((uintptr_t)dst_bf16)) & 15) return VLT5_ERR_ALIGN;
+    hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n, 8)), dim3(256), 0, ST, src, (bf16_t*)dst_bf16, n);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_scale_add(float* dst, const float* src, float a, float b, long long n, void* stream) {
+    if (!dst || !src || n <= 0) return VLT5_ERR_ARG;
+    hipLaunchKernelGGL(scale_add_kernel, dim3(grid_for(n, 1)), dim3(256), 0, ST, dst, src, a, b, n);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_drop_cast(const float* src, void* dst_bf16, long long rows, int cols, float drop_p, uint32_t drop_seed,
+                              void* stream) {
+    if (!src || !dst_bf16 || rows <= 0 || cols <= 0) return VLT5_ERR_ARG;
+    if (cols & 3) return VLT5_ERR_ALIGN;
+    const long long n = rows * cols;
+    hipLaunchKernelGGL(drop_cast_kernel, dim3(grid_for(n, 4)), dim3(256), 0, ST, src, (bf16_t*)dst_bf16, n,
+                       drop_p > 0.f ? drop_thr16(drop_p) : 0u, drop_seed);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_abi_version(void) { return VLT5_ABI_VERSION; }

@@ -1,0 +1,204 @@
+"""Thin torch-tensor wrappers over the per-kernel C ABI (used by the parity tests and the host-side model code).
+
+Every function enqueues on torch's current HIP stream.  Tensors must live on the GPU; nothing here computes
+on the host and nothing falls back to torch ops.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import AttnDesc, GemmDesc, check, lib, ptr, stream_ptr
+
+BF16 = torch.bfloat16
+
+
+def _need(t, dtype=None):
+    if not t.is_cuda:
+        raise L.Vlt5Error("tensor must be on the GPU")
+    if dtype is not None and t.dtype != dtype:
+        raise L.Vlt5Error(f"expected {dtype}, got {t.dtype}")
+    return t
+
+
+def gemm(A, B, M, N, K, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, alpha=1.0, bias=None, relu=False,
+         resid=None, gate=None, gate_scale=1.0, drop_p=0.0, drop_seed=0, accum=False, split_k=1, tile=(0, 0),
+         lda=None, ldb=None, ldc=None):
+    """C[M,N] = epi(alpha * sum_k A[m,k] B[n,k]); A,B bf16 2-D tensors, k-major flags as in vlt5_gemm_desc."""
+    _need(A, BF16), _need(B, BF16)
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32 if out_f32 else BF16)
+    out_f32 = out.dtype == torch.float32
+    g = GemmDesc()
+    g.A, g.B, g.C = ptr(A), ptr(B), ptr(out)
+    g.M, g.N, g.K = M, N, K
+    g.lda = lda if lda is not None else A.stride(0)
+    g.ldb = ldb if ldb is not None else B.stride(0)
+    g.ldc = ldc if ldc is not None else out.stride(0)
+    g.a_kmajor, g.b_kmajor = int(a_kmajor), int(b_kmajor)
+    g.alpha = alpha
+    g.bias = ptr(bias)
+    g.resid, g.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
+    g.gate, g.ldg, g.gate_scale = ptr(gate), (gate.stride(0) if gate is not None else 0), gate_scale
+    g.drop_p, g.drop_seed = drop_p, drop_seed
+    g.relu, g.out_f32, g.accum = int(relu), int(out_f32), int(accum)
+    ws = None
+    if split_k > 1:
+        ws = torch.empty(lib().vlt5_gemm_workspace_bytes(M, g.ldc, split_k), device=A.device, dtype=torch.uint8)
+        g.split_k, g.workspace = split_k, ptr(ws)
+    g.tile_m, g.tile_n = tile
+    check(lib().vlt5_gemm_bf16(C.byref(g), stream_ptr()), "vlt5_gemm_bf16")
+    return out
+
+
+def layernorm_fwd(x, w, eps=1e-6, want_f32=False, drop_p=0.0, drop_seed=0):
+    rows, d = x.shape
+    yb = torch.empty(rows, d, device=x.device, dtype=BF16)
+    yf = torch.empty(rows, d, device=x.device, dtype=torch.float32) if want_f32 else None
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    check(lib().vlt5_layernorm_fwd(ptr(_need(x, torch.float32)), ptr(w), ptr(yb), ptr(yf), ptr(rstd), rows, d, eps, drop_p,
+                                   drop_seed, 0, 0, stream_ptr()), "vlt5_layernorm_fwd")
+    return yb, yf, rstd
+
+
+def layernorm_bwd(dy, x, w, rstd, dx=None, drop_p=0.0, drop_seed=0):
+    rows, d = x.shape
+    accum = dx is not None
+    if dx is None:
+        dx = torch.empty_like(x)
+    dw = torch.empty(d, device=x.device, dtype=torch.float32)
+    part = torch.empty(lib().vlt5_layernorm_bwd_blocks(rows), d, device=x.device, dtype=torch.float32)
+    check(lib().vlt5_layernorm_bwd(ptr(dy), ptr(x), ptr(w), ptr(rstd), ptr(dx), ptr(dw), ptr(part), rows, d, int(accum), 0,
+                                   drop_p, drop_seed, 0, 0, stream_ptr()), "vlt5_layernorm_bwd")
+    return dx, dw
+
+
+def _attn_desc(q, k, v, H, dk, bias, key_mask, mask_value, causal, drop_p, drop_seed):
+    B, Tq = q.shape[:2]
+    Tk = k.shape[1]
+    a = AttnDesc()
+    a.q, a.k, a.v = ptr(_need(q, BF16)), ptr(_need(k, BF16)), ptr(_need(v, BF16))
+    a.q_sb, a.q_st = q.stride(0), q.stride(1)
+    a.k_sb, a.k_st = k.stride(0), k.stride(1)
+    a.v_sb, a.v_st = v.stride(0), v.stride(1)
+    if bias is not None:
+        a.bias, a.bias_q, a.bias_k = ptr(bias), bias.shape[1], bias.shape[2]
+    a.key_mask, a.mask_value, a.causal = ptr(key_mask), mask_value, int(causal)
+    a.B, a.H, a.Tq, a.Tk, a.dk = B, H, Tq, Tk, dk
+    a.drop_p, a.drop_seed = drop_p, drop_seed
+    return a
+
+
+def attn_fwd(q, k, v, H, dk, bias=None, key_mask=None, mask_value=-10000.0, causal=False, drop_p=0.0, drop_seed=0):
+    """q [B,Tq,H*dk], k/v [B,Tk,H*dk] bf16 (any strides along batch/token) -> ctx [B,Tq,H*dk] bf16, lse [B,H,Tq]."""
+    B, Tq = q.shape[:2]
+    a = _attn_desc(q, k, v, H, dk, bias, key_mask, mask_value, causal, drop_p, drop_seed)
+    ctx = torch.empty(B, Tq, H * dk, device=q.device, dtype=BF16)
+    lse = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
+    a.ctx, a.o_sb, a.o_st, a.lse = ptr(ctx), ctx.stride(0), ctx.stride(1), ptr(lse)
+    check(lib().vlt5_attn_fwd(C.byref(a), stream_ptr()), "vlt5_attn_fwd")
+    return ctx, lse
+
+
+def attn_bwd(q, k, v, d_ctx, lse, H, dk, bias=None, key_mask=None, mask_value=-10000.0, causal=False, drop_p=0.0,
+             drop_seed=0, want_dbias=False):
+    B, Tq = q.shape[:2]
+    Tk = k.shape[1]
+    a = _attn_desc(q, k, v, H, dk, bias, key_mask, mask_value, causal, drop_p, drop_seed)
+    dq = torch.empty(B, Tq, H * dk, device=q.device, dtype=BF16)
+    dk_ = torch.empty(B, Tk, H * dk, device=q.device, dtype=BF16)
+    dv = torch.empty(B, Tk, H * dk, device=q.device, dtype=BF16)
+    a.lse = ptr(lse)
+    a.d_ctx, a.do_sb, a.do_st = ptr(_need(d_ctx, BF16)), d_ctx.stride(0), d_ctx.stride(1)
+    a.dq, a.dq_sb, a.dq_st = ptr(dq), dq.stride(0), dq.stride(1)
+    a.dk_, a.dk_sb, a.dk_st = ptr(dk_), dk_.stride(0), dk_.stride(1)
+    a.dv, a.dv_sb, a.dv_st = ptr(dv), dv.stride(0), dv.stride(1)
+    dbias = None
+    if want_dbias and bias is not None:
+        dbias = torch.zeros(B, H, bias.shape[1], bias.shape[2], device=q.device, dtype=torch.float32)
+        a.dbias = ptr(dbias)
+    check(lib().vlt5_attn_bwd(C.byref(a), stream_ptr()), "vlt5_attn_bwd")
+    return dq, dk_, dv, dbias
+
+
+def relbias_build(table, lut, H, Lq, Lk):
+    bias = torch.empty(H, Lq, Lk, device=table.device, dtype=torch.float32)
+    check(lib().vlt5_relbias_build(ptr(table), ptr(_need(lut, torch.int32)), ptr(bias), H, Lq, Lk, table.shape[0], stream_ptr()),
+          "vlt5_relbias_build")
+    return bias
+
+
+def relbias_bwd(dS, lut, nbuckets):
+    nmat, H, Lq, Lk = dS.shape
+    dtable = torch.empty(nbuckets, H, device=dS.device, dtype=torch.float32)
+    scratch = torch.empty(H * Lq * Lk, device=dS.device, dtype=torch.float32)
+    check(lib().vlt5_relbias_bwd(ptr(dS), ptr(lut), ptr(dtable), ptr(scratch), nmat, H, Lq, Lk, nbuckets, 0, stream_ptr()),
+          "vlt5_relbias_bwd")
+    return dtable
+
+
+def cast_bf16(src, dst=None):
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=BF16)
+    check(lib().vlt5_cast_bf16(ptr(_need(src, torch.float32)), ptr(dst), src.numel(), stream_ptr()), "vlt5_cast_bf16")
+    return dst
+
+
+def ce_fwd(logits, labels):
+    R, V = logits.shape
+    loss = torch.empty(R, device=logits.device, dtype=torch.float32)
+    lse = torch.empty(R, device=logits.device, dtype=torch.float32)
+    check(lib().vlt5_ce_fwd(ptr(_need(logits, torch.float32)), ptr(_need(labels, torch.int64)), ptr(loss), ptr(lse), R, V,
+                            stream_ptr()), "vlt5_ce_fwd")
+    return loss, lse
+
+
+def loss_reduce(loss_tok, labels, scores):
+    B, T = labels.shape
+    loss = torch.empty(1, device=labels.device, dtype=torch.float32)
+    row_w = torch.empty(B * T, device=labels.device, dtype=torch.float32)
+    check(lib().vlt5_loss_reduce(ptr(loss_tok), ptr(labels), ptr(scores), ptr(loss), ptr(row_w), B, T, stream_ptr()),
+          "vlt5_loss_reduce")
+    return loss, row_w
+
+
+def ce_bwd(logits, labels, lse, row_w, gout=None):
+    R, V = logits.shape
+    d = torch.empty(R, V, device=logits.device, dtype=BF16)
+    check(lib().vlt5_ce_bwd(ptr(logits), ptr(labels), ptr(lse), ptr(row_w), ptr(gout), ptr(d), R, V, stream_ptr()), "vlt5_ce_bwd")
+    return d
+
+
+def proto_pool(hidden, S, split):
+    """hidden f32 [B, >=S, d] (batch stride may exceed S*d) -> poolQ, poolV [B,d]."""
+    B, d = hidden.shape[0], hidden.shape[2]
+    pq = torch.empty(B, d, device=hidden.device, dtype=torch.float32)
+    pv = torch.empty(B, d, device=hidden.device, dtype=torch.float32)
+    check(lib().vlt5_proto_pool(ptr(_need(hidden, torch.float32)), hidden.stride(0), B, S, d, split, ptr(pq), ptr(pv), stream_ptr()),
+          "vlt5_proto_pool")
+    return pq, pv
+
+
+def proto_class_mean(pool, onehot):
+    B, d = pool.shape
+    Cn = onehot.shape[1]
+    proto = torch.empty(Cn, d, device=pool.device, dtype=torch.float32)
+    cnt = torch.empty(Cn, device=pool.device, dtype=torch.float32)
+    check(lib().vlt5_proto_class_mean(ptr(pool), ptr(_need(onehot.contiguous(), torch.float32)), ptr(proto), ptr(cnt), B, Cn, d,
+                                      stream_ptr()), "vlt5_proto_class_mean")
+    return proto, cnt
+
+
+def proto_retrieve(protos, pool, out_f32=None, sb=0, out_bf16=None, sb_bf16=0):
+    B, d = pool.shape
+    idx = torch.empty(B, device=pool.device, dtype=torch.int64)
+    check(lib().vlt5_proto_retrieve(ptr(_need(protos, torch.float32)), ptr(pool), ptr(idx), ptr(out_f32), sb, ptr(out_bf16), sb_bf16,
+                                    B, protos.shape[0], d, stream_ptr()), "vlt5_proto_retrieve")
+    return idx
+
+
+def proto_memory_loss(pool, onehot, protos):
+    out = torch.empty(1, device=pool.device, dtype=torch.float32)
+    check(lib().vlt5_proto_memory_loss(ptr(pool), ptr(onehot.contiguous()), ptr(protos), ptr(out), pool.shape[0], protos.shape[0],
+                                       pool.shape[1], stream_ptr()), "vlt5_proto_memory_loss")
+    return out

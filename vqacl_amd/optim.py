@@ -1,0 +1,98 @@
+"""Fused clip-grad-norm + AdamW over the model's flat parameter buffer.
+
+Drop-in for the optimizer the reference builds (trainer_base.py:130-198: transformers AdamW, lr 1e-4, eps 1e-6,
+weight decay 0.01 except names containing "bias"/"LayerNorm.weight") followed by `clip_grad_norm_(params, 5)`
+(vqacl.py:466-487), as two HIP kernels: one squared-norm reduction over the flat gradient buffer and one update
+pass that also rewrites the bf16 shadow the GEMMs read (28 B/param + 2 B).  The clip coefficient stays on the
+device, so the step never synchronises with the host.
+"""
+import torch
+
+from . import _lib as L
+from ._lib import check, lib, ptr, stream_ptr
+
+
+def reference_param_groups(model, weight_decay=0.01):
+    """The reference's grouping rule, by substring on the parameter NAME (trainer_base.py:148-161)."""
+    no_decay = ["bias", "LayerNorm.weight"]
+    named = list(model.named_parameters())
+    return [
+        {"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": weight_decay},
+        {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0},
+    ]
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, max_grad_norm=None,
+                 hf_mode=True):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.model = model
+        self.max_grad_norm = max_grad_norm
+        self.hf_mode = int(hf_mode)
+        flat = model.flat_params()
+        self._m = torch.zeros_like(flat)
+        self._v = torch.zeros_like(flat)
+        self._t = 0
+        dev = flat.device
+        self._total_sq = torch.zeros(1, device=dev, dtype=torch.float32)
+        base = flat.data_ptr()
+        # the gradient-bearing region: everything up to the first never-used parameter (prototype_fc*)
+        used_end = 0
+        for name, (off, n, bucket, decay, used) in model._pinfo.items():
+            if used:
+                used_end = max(used_end, off + n)
+        self._used_end = used_end
+        self._partial = torch.empty(lib().vlt5_sqnorm_blocks(used_end), device=dev, dtype=torch.float32)
+        # contiguous runs of equal hyper-parameters (alignment gaps hold zeros and stay zero under the update)
+        spans = []
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                off = (p.data_ptr() - base) // 4
+                if off < 0 or off + p.numel() > flat.numel():
+                    raise L.Vlt5Error("FusedAdamW only handles parameters of the engine-backed model")
+                if off >= used_end:
+                    continue                         # never receives a gradient: skipped like a grad=None param
+                spans.append((off, off + p.numel(), gi))
+        spans.sort()
+        runs = []
+        for a, b, gi in spans:
+            if runs and runs[-1][2] == gi and a - runs[-1][1] < 64:
+                runs[-1][1] = b
+            else:
+                runs.append([a, b, gi])
+        self._runs = runs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise L.Vlt5Error("closures are not supported")
+        model = self.model
+        flat, grad, bf16 = model.flat_params(), model.flat_grads(), model.flat_bf16()
+        anchor = model._params_by_name["shared.weight"]
+        if anchor.grad is None:
+            return None
+        if anchor.grad.data_ptr() != model._gviews["shared.weight"].data_ptr():
+            for name, p in model._params_by_name.items():           # grads were accumulated outside the flat buffer
+                if p.grad is not None:
+                    model._gviews[name].copy_(p.grad)
+        self._t += 1
+        st = stream_ptr()
+        total = None
+        if self.max_grad_norm is not None and self.max_grad_norm > 0:
+            check(lib().vlt5_sqnorm(ptr(grad), self._used_end, ptr(self._partial), ptr(self._total_sq), 0, st), "vlt5_sqnorm")
+            total = self._total_sq
+        for a, b, gi in self._runs:
+            g = self.param_groups[gi]
+            n = b - a
+            check(lib().vlt5_adamw_step(L.vp(flat.data_ptr() + 4 * a), L.vp(grad.data_ptr() + 4 * a),
+                                        L.vp(self._m.data_ptr() + 4 * a), L.vp(self._v.data_ptr() + 4 * a),
+                                        L.vp(bf16.data_ptr() + 2 * a), n, float(g["lr"]), float(g["betas"][0]),
+                                        float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._t, ptr(total),
+                                        float(self.max_grad_norm or 0.0), self.hf_mode, st), "vlt5_adamw_step")
+        model.external_bf16_sync = True
+        model._bf16_version = flat._version
+        return None
+
+    def grad_norm(self):
+        """L2 norm of the last step's (pre-clip) gradients; reading it synchronises."""
+        return float(self._total_sq.sqrt())

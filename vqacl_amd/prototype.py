@@ -1,0 +1,75 @@
+"""Host side of the SS/SI prototype head (reference: VL-T5/src/modeling_t5_our.py:434-511, 583-615).
+
+The arithmetic runs in the HIP kernels of csrc/proto.hip; this class only keeps the per-task state machine
+of `VLT5.update_prototype` (which task has been seen, which task owns a memory tensor) -- plain Python control
+flow on the integer `current_task_id`, exactly like the reference, so no device->host synchronisation is needed.
+"""
+import torch
+
+from . import _lib as L
+from ._lib import check, lib, ptr, stream_ptr
+from . import ops
+
+
+class PrototypeHead:
+    def __init__(self, n_ques: int, n_cate: int, d_model: int, device):
+        self.CQ, self.CV, self.d = n_ques, n_cate, d_model
+        self.device = device
+        z = dict(device=device, dtype=torch.float32)
+        self.Q_prototype = torch.zeros(n_ques, d_model, **z)
+        self.V_prototype = torch.zeros(n_cate, d_model, **z)
+        self.Q_prototype_num = torch.zeros(n_ques, **z)
+        self.V_prototype_num = torch.zeros(n_cate, **z)
+        self.seen_tasks = set()            # keys of the reference's Q_task_cur_proto
+        self.Q_task_mem_proto = {}         # task -> [CQ,d] memory tensor (reference name)
+        self.dist_group = None             # set by DataParallelVLT5: statistics are summed over ranks
+
+    def reset(self):
+        self.seen_tasks.clear()
+        self.Q_task_mem_proto.clear()
+
+    # ---- training: calculate_current_prototype x2 + update_prototype ---------------------------------
+    def update(self, poolQ, poolV, ques_labels, cate_labels, task: int, alpha: float, beta: float):
+        curQ, numQ = ops.proto_class_mean(poolQ, ques_labels)
+        curV, numV = ops.proto_class_mean(poolV, cate_labels)
+        if self.dist_group is not None:
+            curQ, numQ = self._allreduce_stats(curQ, numQ)
+            curV, numV = self._allreduce_stats(curV, numV)
+        first = task not in self.seen_tasks
+        qmem, qinit = None, 0
+        if not first and task != 0:
+            if task in self.Q_task_mem_proto:
+                qmem, qinit = self.Q_task_mem_proto[task], 1
+            else:
+                qmem = torch.empty_like(self.Q_prototype)
+                self.Q_task_mem_proto[task] = qmem
+        check(lib().vlt5_proto_update(ptr(curQ), ptr(curV), ptr(numQ), ptr(numV), ptr(self.Q_prototype), ptr(self.V_prototype),
+                                      ptr(self.Q_prototype_num), ptr(self.V_prototype_num), ptr(qmem), qinit, int(first),
+                                      int(task), float(alpha), float(beta), self.CQ, self.CV, self.d, stream_ptr()),
+              "vlt5_proto_update")
+        self.seen_tasks.add(task)
+        return curQ, curV
+
+    def _allreduce_stats(self, proto, cnt):
+        """Data parallel: class means over the GLOBAL batch = all-reduced sums / all-reduced counts, so every rank
+        holds the prototypes a single process would compute on the concatenated batch."""
+        import torch.distributed as dist
+        sums = proto * cnt.clamp(min=1).unsqueeze(1)
+        packed = torch.cat([sums.reshape(-1), cnt])
+        dist.all_reduce(packed, group=self.dist_group)
+        n = proto.numel()
+        cnt = packed[n:].clone()
+        sums = packed[:n].view_as(proto)
+        return (sums / cnt.clamp(min=1).unsqueeze(1)).contiguous(), cnt
+
+    # ---- retrieval: cosine_similarity_multi + gather, written straight into the decoder's memory rows --
+    def retrieve(self, poolQ, poolV, enc_f32, enc_bf16, S: int):
+        """enc_f32 / enc_bf16: [B, S+2, d] buffers whose rows S and S+1 receive the retrieved Q / V prototypes."""
+        Sx, d = S + 2, self.d
+        idxQ = ops.proto_retrieve(self.Q_prototype, poolQ, enc_f32[:, S], Sx * d, enc_bf16[:, S], Sx * d)
+        idxV = ops.proto_retrieve(self.V_prototype, poolV, enc_f32[:, S + 1], Sx * d, enc_bf16[:, S + 1], Sx * d)
+        return idxQ, idxV
+
+    def memory_loss(self, poolQ, poolV, ques_labels, cate_labels):
+        return (ops.proto_memory_loss(poolQ, ques_labels, self.Q_prototype),
+                ops.proto_memory_loss(poolV, cate_labels, self.V_prototype))
