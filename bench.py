@@ -57,13 +57,16 @@ def gemm_schedule(cfg, B, L, V, T):
 def time_gemms(cfg, B, L, V, T, dev, reps=10):
     """HIP-event timing of each distinct GEMM launch shape on the current stream; returns per-instantiation totals."""
     from vqacl_amd import ops
+    from vqacl_amd._lib import lib
     BF = torch.bfloat16
     rows = []
     for count, M, N, K, akm, bkm, of32 in gemm_schedule(cfg, B, L, V, T):
         A = torch.randn((K, M) if akm else (M, K), device=dev).to(BF)
         Bm = torch.randn((K, N) if bkm else (N, K), device=dev).to(BF)
         out = torch.empty(M, N, device=dev, dtype=torch.float32 if of32 else BF)
-        kw = dict(a_kmajor=bool(akm), b_kmajor=bool(bkm), out=out)
+        # same split-K policy as csrc/engine.hip (plain f32 outputs of dgrad / wgrad GEMMs)
+        sk = lib().vlt5_gemm_auto_split(M, N, K, 8 * max(cfg.d_ff, 3 * cfg.num_heads * cfg.d_kv) * cfg.d_model * 4) if (of32 and bkm) else 1
+        kw = dict(a_kmajor=bool(akm), b_kmajor=bool(bkm), out=out, split_k=sk)
         for _ in range(2):
             ops.gemm(A, Bm, M, N, K, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -81,7 +84,11 @@ def time_gemms(cfg, B, L, V, T, dev, reps=10):
 def cpu_baseline(seconds_budget=25.0):
     """The oracle (CPU restatement of the reference path) timed on the host: fwd + bwd + clip + AdamW, dropout on."""
     from oracle import ref_cpu as R
-    cores = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    cores = max(1, min(usable, 16))           # torch intra-op threads actually used: 16 was the fastest on the 256-core box
     torch.set_num_threads(cores)
     cfg = R.Cfg(dropout=0.1)
     Bc = 8

@@ -48,6 +48,8 @@ typedef struct {
 } vlt5_gemm_desc;
 int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream);
 long long vlt5_gemm_workspace_bytes(int M, int ldc, int split_k);
+/* the split-K factor the engine uses for a plain f32 output [M,N] reduced over Kred (1 = no split) */
+int vlt5_gemm_auto_split(int M, int N, int Kred, long long slab_bytes);
 
 /* ---- T5LayerNorm (RMS, no mean, no bias): HF T5LayerNorm.forward ------------------------------
  * y = x * rsqrt(mean(x^2)+eps) * w, statistics in f32.  Optional inverted dropout on y
@@ -91,7 +93,7 @@ int vlt5_attn_bwd(const vlt5_attn_desc* d, void* stream);
  * The integer bucket table lut[Lq*Lk] is computed on the host (vqacl_amd/buckets.py, bit-exact
  * with the library); the kernel gathers table[lut[i,j], h] into bias[h,i,j]. */
 int vlt5_relbias_build(const float* table, const int* lut, float* bias, int H, int Lq, int Lk, int nbuckets, void* stream);
-/* dtable[bucket,h] (+)= sum over nmat matrices and positions of dS[mat,h,i,j];  scratch f32 [H*Lq*Lk] */
+/* dtable[bucket,h] (+)= sum over nmat matrices and positions of dS[mat,h,i,j];  scratch f32 [16*H*Lq*Lk] */
 int vlt5_relbias_bwd(const float* dS, const int* lut, float* dtable, float* scratch, int nmat, int H, int Lq, int Lk,
                      int nbuckets, int accum, void* stream);
 

@@ -54,6 +54,7 @@ PROTOTYPES = {
     "vlt5_abi_version": (c_i, []),
     "vlt5_gemm_bf16": (c_i, [C.POINTER(GemmDesc), vp]),
     "vlt5_gemm_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
+    "vlt5_gemm_auto_split": (c_i, [c_i, c_i, c_i, c_ll]),
     "vlt5_layernorm_fwd": (c_i, [vp, vp, vp, vp, vp, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),
     "vlt5_layernorm_bwd": (c_i, [vp, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp]),
     "vlt5_layernorm_bwd_blocks": (c_i, [c_i]),

@@ -234,21 +234,24 @@ __global__ void relbias_build_kernel(const float* __restrict__ table, const int*
     int h = i / (Lq * Lk), pos = i % (Lq * Lk);
     bias[i] = table[lut[pos] * H + h];
 }
-__global__ void relbias_sum_mats_kernel(const float* __restrict__ dS, float* __restrict__ R, int nmat, int n) {
+// R[g][i] = sum over the matrices of group g (blockIdx.y) of dS[m][i]; second stage sums the groups in a fixed order
+__global__ void relbias_sum_mats_kernel(const float* __restrict__ dS, float* __restrict__ R, int nmat, int n, int per_group) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const int m0 = blockIdx.y * per_group, m1 = min(nmat, m0 + per_group);
     float s = 0.f;
-    for (int m = 0; m < nmat; ++m) s += dS[(size_t)m * n + i];
-    R[i] = s;
+    for (int m = m0; m < m1; ++m) s += dS[(size_t)m * n + i];
+    R[(size_t)blockIdx.y * n + i] = s;
 }
 __global__ void relbias_scatter_kernel(const float* __restrict__ R, const int* __restrict__ lut, float* __restrict__ dtable,
-                                       int H, int npos, int nbuckets, int accum) {
+                                       int H, int npos, int nbuckets, int ngroups, int accum) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= H * nbuckets) return;
     int bucket = i / H, h = i % H;
     float s = accum ? dtable[i] : 0.f;
     for (int pos = 0; pos < npos; ++pos)
-        if (lut[pos] == bucket) s += R[(size_t)h * npos + pos];
+        if (lut[pos] == bucket)
+            for (int g = 0; g < ngroups; ++g) s += R[((size_t)g * H + h) * npos + pos];
     dtable[i] = s;
 }
 
@@ -339,10 +342,12 @@ extern "C" int vlt5_relbias_bwd(const float* dS, const int* lut, float* dtable, 
                                 int nbuckets, int accum, void* stream) {
     if (!dS || !lut || !dtable || !scratch || nmat <= 0) return VLT5_ERR_ARG;
     int n = H * Lq * Lk;
-    hipLaunchKernelGGL(relbias_sum_mats_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, dS, scratch, nmat, n);
+    const int ngroups = nmat < 16 ? nmat : 16;                 // scratch holds ngroups partial matrices
+    const int per_group = (nmat + ngroups - 1) / ngroups;
+    hipLaunchKernelGGL(relbias_sum_mats_kernel, dim3((n + 255) / 256, ngroups), dim3(256), 0, ST, dS, scratch, nmat, n, per_group);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(relbias_scatter_kernel, dim3((H * nbuckets + 63) / 64), dim3(64), 0, ST, scratch, lut, dtable, H, Lq * Lk,
-                       nbuckets, accum);
+                       nbuckets, (nmat + per_group - 1) / per_group, accum);
     LAUNCH_CHECK();
     return VLT5_OK;
 }

@@ -178,7 +178,7 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     p.slab = take(p.slab_bytes);
     p.ln_partial = take((size_t)256 * d * 4);
     p.vis_partial = take(((size_t)64 * 10 * d + 2 * (size_t)B * V) * 4);
-    size_t rs = H * (size_t)(L > T ? L : T) * (L > T ? L : T) * 4;
+    size_t rs = 16 * H * (size_t)(L > T ? L : T) * (L > T ? L : T) * 4;
     p.rel_scratch = take(rs);
     p.vis_dG = take((size_t)B * V * d * 2);
     p.small = take(10 * d * 4);
@@ -227,6 +227,7 @@ struct Ctx {
         g.out_f32 = out_f32;
         return vlt5_gemm_bf16(&g, st);
     }
+    int pick_split(int M, int N, int Kred) const { return vlt5_gemm_auto_split(M, N, Kred, (long long)p.slab_bytes); }
     // dX[M,K] = epi(alpha * dY[M,N] W[N,K])     (W read k-major)
     int lin_dgrad(const bf16_t* dY, const bf16_t* W, void* dX, int M, int N, int K, int out_f32, float alpha = 1.f,
                   const bf16_t* gate = nullptr, float gate_scale = 1.f) const {
@@ -234,6 +235,10 @@ struct Ctx {
         memset(&g, 0, sizeof g);
         g.A = dY; g.B = W; g.C = dX; g.M = M; g.N = K; g.K = N; g.lda = N; g.ldb = K; g.ldc = K; g.b_kmajor = 1;
         g.alpha = alpha; g.gate = gate; g.ldg = K; g.gate_scale = gate_scale; g.out_f32 = out_f32;
+        if (out_f32 && !gate) {
+            int sk = pick_split(M, K, N);
+            if (sk > 1) { g.split_k = sk; g.workspace = w<void>(p.slab); }
+        }
         return vlt5_gemm_bf16(&g, st);
     }
     // dW[N,K] (+)= alpha * dY[M,N]^T X[M,K]     (both read k-major, reduction over the M rows)
@@ -243,12 +248,8 @@ struct Ctx {
         memset(&g, 0, sizeof g);
         g.A = dY; g.B = X; g.C = dW; g.M = N; g.N = K; g.K = M; g.lda = ldy; g.ldb = ldx; g.ldc = K;
         g.a_kmajor = 1; g.b_kmajor = 1; g.alpha = alpha; g.out_f32 = 1; g.accum = accum;
-        long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
-        if (M >= 2048 && tiles < 384 && alpha == 1.f) {
-            int sk = (int)((512 + tiles - 1) / tiles);
-            if (sk > 8) sk = 8;
-            if ((size_t)sk * N * K * 4 <= p.slab_bytes && sk > 1) { g.split_k = sk; g.workspace = w<void>(p.slab); }
-        }
+        int sk = pick_split(N, K, M);
+        if (sk > 1) { g.split_k = sk; g.workspace = w<void>(p.slab); }
         return vlt5_gemm_bf16(&g, st);
     }
     int record(int k) const {

@@ -11,9 +11,9 @@
 //
 // Structure: 256 threads = 4 waves in a 2x2 grid over a BM x BN tile, BK = 64 per step, two LDS
 // stages, global -> registers -> LDS staging (the load of step t+1 is issued before the MFMAs of
-// step t).  LDS tiles are always [row][64 k] with k contiguous, 16-byte slots XOR-swizzled by
-// (row & 7) so the ds_read_b128 fragment reads are bank-conflict free; k-major operands are
-// transposed in registers (8x4 blocks) on their way into LDS.
+// step t).  Row-major operands sit in LDS as [row][64 k] with k contiguous, 16-byte slots XOR-swizzled by
+// (row & 7) so the ds_read_b128 fragment reads are bank-conflict free; k-major operands stay [64 k][row] in LDS and are
+// gathered into fragments with the hardware transpose read ds_read_b64_tr_b16 (no register transposes).
 // MFMA: v_mfma_f32_16x16x32_bf16 with the operands swapped (weight fragment as A, activation
 // fragment as B) so each lane ends up with 4 consecutive n of one row m -> 8/16-byte stores.
 //
@@ -67,43 +67,57 @@ __device__ __forceinline__ void lstore_rm(char* tile, const uint4 (&v)[4], int t
     }
 }
 
-// ---- k-major operand: storage [K][R'] (r contiguous).  A thread owns an 8(r) x 4(k) block ---------
+// ---- k-major operand: storage [K][R'] (r contiguous).  The tile is kept in LDS exactly as it lies in memory, [64 k][R] with
+// r contiguous (same 16-byte global loads / ds_write_b128 as a row-major operand, no VALU work), and the MFMA fragments are
+// gathered with the gfx950 transpose read ds_read_b64_tr_b16: within each 16-lane group, lane l receives element (l&3) of
+// the 8 bytes addressed by lanes 4j + (l>>2), j = 0..3  (semantics pinned by tests/test_gpu_probe.py).  Lane i of a group
+// therefore points at T[k0 + (i>>2)][r0 + 4*(i&3)] and ends up with T[k0 .. k0+3][r0 + i]: four consecutive k of "its" row.
+// 16-byte slots are XOR-swizzled per k-row so that the 8 k-rows x 32 bytes touched by one 32-lane half land on 64
+// distinct banks.
+template <int R>
+__device__ __forceinline__ int km_swz(int k) {
+    return R == 128 ? (((k & 3) << 1) | (((k >> 3) & 1) << 3)) : ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2));
+}
 template <int R>
 __device__ __forceinline__ void gload_km(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, int K,
                                          uint4 (&v)[4], int tid) {
-    if (tid < 2 * R) {
-        int kq = (tid & 7) | (((tid >> 6) & 1) << 3);
-        int rb = ((tid >> 3) & 7) | ((tid >> 7) << 3);
-        int gr = row0 + rb * 8;
+    constexpr int CPR = R / 8;                                  // 16-byte chunks per k-row
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            int gk = k0 + kq * 4 + c;
-            uint4 z = make_uint4(0, 0, 0, 0);
-            if (gr < rmax && gk < K) z = *reinterpret_cast<const uint4*>(base + (size_t)gk * ld + gr);
-            v[c] = z;
-        }
+    for (int i = 0; i < R / 32; ++i) {
+        int c = tid + i * 256;
+        int k = c / CPR, rc = c % CPR;
+        int gk = k0 + k, gr = row0 + rc * 8;
+        uint4 z = make_uint4(0, 0, 0, 0);
+        if (gr < rmax && gk < K) z = *reinterpret_cast<const uint4*>(base + (size_t)gk * ld + gr);
+        v[i] = z;
     }
-}
-__device__ __forceinline__ uint32_t word_of(const uint4& q, int i) {
-    return i == 0 ? q.x : (i == 1 ? q.y : (i == 2 ? q.z : q.w));
 }
 template <int R>
 __device__ __forceinline__ void lstore_km(char* tile, const uint4 (&v)[4], int tid) {
-    if (tid < 2 * R) {
-        int kq = (tid & 7) | (((tid >> 6) & 1) << 3);
-        int rb = ((tid >> 3) & 7) | ((tid >> 7) << 3);
-        int kc = kq >> 1, within = (kq & 1) * 8;
+    constexpr int CPR = R / 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            uint32_t w0 = word_of(v[0], e >> 1), w1 = word_of(v[1], e >> 1);
-            uint32_t w2 = word_of(v[2], e >> 1), w3 = word_of(v[3], e >> 1);
-            uint2 o;
-            if (e & 1) { o.x = (w0 >> 16) | (w1 & 0xffff0000u); o.y = (w2 >> 16) | (w3 & 0xffff0000u); }
-            else       { o.x = (w0 & 0xffffu) | (w1 << 16);     o.y = (w2 & 0xffffu) | (w3 << 16); }
-            int row = rb * 8 + e;
-            *reinterpret_cast<uint2*>(tile + lds_off(row, kc) + within) = o;
-        }
+    for (int i = 0; i < R / 32; ++i) {
+        int c = tid + i * 256;
+        int k = c / CPR, rc = c % CPR;
+        *reinterpret_cast<uint4*>(tile + k * (R * 2) + ((rc ^ km_swz<R>(k)) << 4)) = v[i];
     }
+}
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ s16x4_t lds_tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+}
+// fragment of rows r0..r0+15, k = ks*32 + 8*(lane>>4) .. +7, from a k-major tile
+template <int R>
+__device__ __forceinline__ bf16x8_t frag_km(const char* tile, int r0, int ks, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int k = ks * 32 + g * 8 + (i >> 2);
+    const int cb = r0 * 2 + (i & 3) * 8;
+    const char* a = tile + k * (R * 2) + (((cb >> 4) ^ km_swz<R>(k)) << 4) + (cb & 15);
+    s16x4_t lo = lds_tr_read(a);
+    s16x4_t hi = lds_tr_read(a + 4 * (R * 2));                  // k + 4: same swizzle
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
 }
 
 template <int BM, int BN, bool AKM, bool BKM>
@@ -115,14 +129,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile mapping: the dispatcher places workgroup b on XCD b % 8 (each XCD has a private 4 MB L2), so give
+    // every XCD one contiguous run of tiles, n fastest: the tiles that share an A row-panel run on the same L2 back to
+    // back, and the weight panel stays L2-resident per XCD.  Bijective for any tile count (speed only, never correctness).
+    const int gx = (p.N + BN - 1) / BN, gy = (p.M + BM - 1) / BM;
+    const int ntiles = gx * gy;
+    int tile_id;
+    {
+        const int b = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = b & 7, loc = b >> 3;
+        tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int m0 = (tile_id / gx) * BM, n0 = (tile_id % gx) * BN;
     const int nk_total = (p.K + BK - 1) / BK;
     int kt0 = 0, kt1 = nk_total;
     char* Cbase = reinterpret_cast<char*>(p.C);
     if (p.ktiles_per_split > 0) {
-        kt0 = blockIdx.z * p.ktiles_per_split;
+        kt0 = blockIdx.y * p.ktiles_per_split;
         kt1 = min(nk_total, kt0 + p.ktiles_per_split);
-        Cbase += (size_t)blockIdx.z * (size_t)p.c_split_stride * 4;
+        Cbase += (size_t)blockIdx.y * (size_t)p.c_split_stride * 4;
     }
 
     f32x4_t acc[FM][FN];
@@ -163,13 +187,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
             bf16x8_t fa[FM], fb[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                int row = wm * (BM / 2) + i * 16 + lrow;
-                fa[i] = *reinterpret_cast<const bf16x8_t*>(at + lds_off(row, ks * 4 + lg));
+                const int r0 = wm * (BM / 2) + i * 16;
+                if (AKM) fa[i] = frag_km<BM>(at, r0, ks, lane);
+                else     fa[i] = *reinterpret_cast<const bf16x8_t*>(at + lds_off(r0 + lrow, ks * 4 + lg));
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                int row = wn * (BN / 2) + j * 16 + lrow;
-                fb[j] = *reinterpret_cast<const bf16x8_t*>(bt + lds_off(row, ks * 4 + lg));
+                const int r0 = wn * (BN / 2) + j * 16;
+                if (BKM) fb[j] = frag_km<BN>(bt, r0, ks, lane);
+                else     fb[j] = *reinterpret_cast<const bf16x8_t*>(bt + lds_off(r0 + lrow, ks * 4 + lg));
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i)
@@ -253,7 +279,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
 
 template <int BM, int BN>
 int launch_tile(const GemmArgs& a, int akm, int bkm, int splits, hipStream_t st) {
-    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits > 1 ? splits : 1);
+    dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM), splits > 1 ? splits : 1, 1);
     size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
     if (!akm && !bkm)      hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), grid, dim3(256), lds, st, a);
     else if (!akm && bkm)  hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true>), grid, dim3(256), lds, st, a);
@@ -323,6 +349,39 @@ extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
     return VLT5_OK;
 }
 
+// split-K factor for a GEMM whose output has few tiles but a long reduction: aim at ~2 workgroups per CU, keep >= 4
+// k-steps (of 64) per slice, and stay inside the caller's slab scratch.  Only valid for plain f32 outputs.
+extern "C" int vlt5_gemm_auto_split(int M, int N, int Kred, long long slab_bytes) {
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const int ksteps = (Kred + 63) / 64;
+    if (Kred < 1024 || tiles >= 256) return 1;
+    int sk = (int)((512 + tiles / 2) / tiles);
+    if (sk > 8) sk = 8;
+    if (sk > ksteps / 4) sk = ksteps / 4;
+    while (sk > 1 && (long long)sk * M * N * 4 > slab_bytes) --sk;
+    return sk < 1 ? 1 : sk;
+}
+
 extern "C" long long vlt5_gemm_workspace_bytes(int M, int ldc, int split_k) {
     return split_k > 1 ? (long long)M * ldc * 4 * split_k : 0;
+}
+
+// ---- debug probe (not part of the public ABI): raw semantics of ds_read_b64_tr_b16 -------------------------------
+// Every lane supplies its own LDS element offset; the 4 returned bf16 per lane are written to out[lane*4 + j].
+namespace {
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__global__ void tr_probe_kernel(const uint16_t* in, uint16_t* out, const int* addr_elems, int n_in) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[8192];
+    for (int i = threadIdx.x; i < n_in && i < 8192; i += 64) lds[i] = in[i];
+    __syncthreads();
+    const int a = addr_elems[threadIdx.x];
+    s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lds + a));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (uint16_t)v[j];
+}
+}  // namespace
+extern "C" int vlt5dbg_tr_read(const void* in, void* out, const int* addr_elems, int n_in, void* stream) {
+    hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)in, (uint16_t*)out, addr_elems, n_in);
+    LAUNCH_CHECK();
+    return VLT5_OK;
 }

@@ -120,20 +120,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         dwp[(size_t)blockIdx.x * d + c] = red[c] + red[d + c] + red[2 * d + c] + red[3 * d + c];
 }
 
-__global__ void colsum_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int width, int row_stride,
-                              int accum) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= width) return;
-    float s = accum ? out[c] : 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * row_stride + c];
-    out[c] = s;
+// out[c] (+)= sum_blk partial[blk*row_stride + c]: 64 columns per block, 4 row groups reduced through LDS (fixed order)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int width,
+                                                     int row_stride, int accum) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < width)
+        for (int b = grp; b < nblk; b += 4) s += partial[(size_t)b * row_stride + c];
+    sh[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && c < width) {
+        float t = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+        out[c] = accum ? out[c] + t : t;
+    }
 }
 
 }  // namespace
 
 extern "C" int vlt5_layernorm_bwd_blocks(int rows) {
     int b = (rows + 3) / 4;
-    return b < 256 ? (b < 1 ? 1 : b) : 256;
+    return b < 128 ? (b < 1 ? 1 : b) : 128;
 }
 
 extern "C" int vlt5_layernorm_fwd(const float* x, const float* w, void* y_bf16, float* y_f32, float* rstd, int rows, int d,
@@ -158,7 +166,7 @@ extern "C" int vlt5_layernorm_bwd(const float* dy, const float* x, const float* 
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 4 * d * sizeof(float), (hipStream_t)stream, dy, x, w, rstd, dx,
                        dw_partial, rows, d, accum_dx, thr, drop_seed, in_group, in_group_stride);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, dw_partial, dw, nblk, d,
+    hipLaunchKernelGGL(colsum_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)stream, dw_partial, dw, nblk, d,
                        d, accum_dw);
     LAUNCH_CHECK();
     return VLT5_OK;
@@ -166,7 +174,7 @@ extern "C" int vlt5_layernorm_bwd(const float* dy, const float* x, const float* 
 
 extern "C" int vlt5_colsum(const float* partial, float* out, int nblk, int width, int row_stride, int accum, void* stream) {
     if (!partial || !out || nblk <= 0 || width <= 0 || row_stride < width) return VLT5_ERR_ARG;
-    hipLaunchKernelGGL(colsum_kernel, dim3((width + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, out, nblk, width,
+    hipLaunchKernelGGL(colsum_kernel, dim3((width + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, out, nblk, width,
                        row_stride, accum);
     LAUNCH_CHECK();
     return VLT5_OK;

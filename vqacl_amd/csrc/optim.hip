@@ -23,11 +23,10 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
     if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 __global__ void sqnorm_final_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ total, int accum) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float s = accum ? total[0] : 0.f;
-        for (int i = 0; i < nblk; ++i) s += partial[i];
-        total[0] = s;
-    }
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 64) s += partial[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) total[0] = accum ? total[0] + s : s;
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

@@ -131,7 +131,7 @@ def relbias_build(table, lut, H, Lq, Lk):
 def relbias_bwd(dS, lut, nbuckets):
     nmat, H, Lq, Lk = dS.shape
     dtable = torch.empty(nbuckets, H, device=dS.device, dtype=torch.float32)
-    scratch = torch.empty(H * Lq * Lk, device=dS.device, dtype=torch.float32)
+    scratch = torch.empty(16 * H * Lq * Lk, device=dS.device, dtype=torch.float32)
     check(lib().vlt5_relbias_bwd(ptr(dS), ptr(lut), ptr(dtable), ptr(scratch), nmat, H, Lq, Lk, nbuckets, 0, stream_ptr()),
           "vlt5_relbias_bwd")
     return dtable
@@ -184,8 +184,9 @@ def proto_class_mean(pool, onehot):
     Cn = onehot.shape[1]
     proto = torch.empty(Cn, d, device=pool.device, dtype=torch.float32)
     cnt = torch.empty(Cn, device=pool.device, dtype=torch.float32)
-    check(lib().vlt5_proto_class_mean(ptr(pool), ptr(_need(onehot.contiguous(), torch.float32)), ptr(proto), ptr(cnt), B, Cn, d,
-                                      stream_ptr()), "vlt5_proto_class_mean")
+    onehot = _need(onehot.contiguous(), torch.float32)       # held in a local until the launch is enqueued
+    check(lib().vlt5_proto_class_mean(ptr(pool), ptr(onehot), ptr(proto), ptr(cnt), B, Cn, d, stream_ptr()),
+          "vlt5_proto_class_mean")
     return proto, cnt
 
 
@@ -199,6 +200,7 @@ def proto_retrieve(protos, pool, out_f32=None, sb=0, out_bf16=None, sb_bf16=0):
 
 def proto_memory_loss(pool, onehot, protos):
     out = torch.empty(1, device=pool.device, dtype=torch.float32)
-    check(lib().vlt5_proto_memory_loss(ptr(pool), ptr(onehot.contiguous()), ptr(protos), ptr(out), pool.shape[0], protos.shape[0],
+    onehot = onehot.contiguous()
+    check(lib().vlt5_proto_memory_loss(ptr(pool), ptr(onehot), ptr(protos), ptr(out), pool.shape[0], protos.shape[0],
                                        pool.shape[1], stream_ptr()), "vlt5_proto_memory_loss")
     return out
