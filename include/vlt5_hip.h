@@ -58,12 +58,21 @@ int vlt5_gemm_auto_split(int M, int N, int Kred, long long slab_bytes);
 int vlt5_layernorm_fwd(const float* x, const float* w, void* y_bf16, float* y_f32, float* rstd,
                        int rows, int d, float eps, float drop_p, uint32_t drop_seed,
                        int out_group, int out_group_stride, void* stream);
-/* dx (+)= d/dx, dw = sum_rows; dy row r is read at the remapped row as above (in_group*).
- * dw_partial: scratch f32 [vlt5_layernorm_bwd_blocks(rows)][d]. */
+/* dx (+)= d/dx; dy row r is read at the remapped row as above (in_group*).
+ * dw_partial: f32 [vlt5_layernorm_bwd_blocks(rows)][d] per-workgroup partial sums of the weight gradient.
+ * dw: if non-NULL a second launch reduces the partials into dw (+= if accum_dw) in a fixed order; if NULL the caller
+ *   reduces later (the engine reduces all norms of a phase with ONE vlt5_colsum_multi launch).
+ * dx_bf16 (optional): also emit bf16(dropout(dx)) with (dx_drop_p, dx_drop_seed), element index r*d+c -- the operand the
+ *   next sublayer's backward GEMMs read, saving a separate vlt5_drop_cast pass. */
 int vlt5_layernorm_bwd(const float* dy, const float* x, const float* w, const float* rstd,
                        float* dx, float* dw, float* dw_partial, int rows, int d,
                        int accum_dx, int accum_dw, float drop_p, uint32_t drop_seed,
-                       int in_group, int in_group_stride, void* stream);
+                       int in_group, int in_group_stride, void* dx_bf16, float dx_drop_p, uint32_t dx_drop_seed,
+                       void* stream);
+/* job j < njobs (<= 64): out_base[out_off[j] + c] = sum_{b < nblk[j]} partial[(j*slot_rows + b)*width + c], c < width.
+ * out_off / nblk are HOST arrays (passed by value to the kernel). */
+int vlt5_colsum_multi(const float* partial, float* out_base, const long long* out_off, const int* nblk, int njobs,
+                      int slot_rows, int width, void* stream);
 int vlt5_layernorm_bwd_blocks(int rows);
 
 /* ---- attention core: softmax(q k^T + bias + masks) v ------------------------------------------

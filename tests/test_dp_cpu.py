@@ -1,0 +1,86 @@
+"""Data-parallel path on CPU: world_size-2 gloo processes exercise the wrapper's collectives (weight broadcast,
+flat-gradient all-reduce over the bucket range, prototype sufficient-statistics all-reduce).  The kernels need a GPU,
+so gradients / pooled features are synthetic here; the numerical end-to-end DP check runs on the GPU (test_gpu_model)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import __graft_entry__ as ge
+        ge.build()
+        from vqacl_amd import VLT5VQA, VLT5Config
+        from vqacl_amd.parallel import DataParallelVLT5
+        from oracle import ref_cpu as R
+        torch.manual_seed(100 + rank)                       # different init per rank: the wrapper must broadcast rank 0's
+        model = VLT5VQA(VLT5Config(d_model=64, d_kv=16, num_heads=4, d_ff=128, num_layers=2, vocab_size=400, feat_dim=64),
+                        device="cpu")
+        before = model.flat_params().clone()
+        dp = DataParallelVLT5(model)
+        gathered = [torch.zeros_like(before) for _ in range(world)]
+        dist.all_gather(gathered, model.flat_params())
+        assert torch.equal(gathered[0], gathered[1]), "weights must be identical after construction"
+        if rank == 1:
+            assert not torch.equal(before, model.flat_params())
+
+        # buckets: contiguous, ordered, cover exactly the gradient-bearing region, exclude prototype_fc*
+        assert dp.bucket_start[0] == 0 and all(a == b for a, b in zip(dp.bucket_start[1:], dp.bucket_end[:-1]))
+        used_end = max(off + n for (off, n, b, d, used) in model._pinfo.values() if used)
+        assert dp.bucket_end[-1] == used_end
+        unused_start = min(off for (off, n, b, d, used) in model._pinfo.values() if not used)
+        assert unused_start >= used_end
+        assert len(dp.bucket_end) == model._nbuckets == 2 + 2 + 2
+
+        # gradient all-reduce = mean over ranks on the used region, untouched beyond it
+        g = model.flat_grads()
+        g.copy_(torch.arange(g.numel(), dtype=torch.float32) * (rank + 1))
+        dp.reduce_flat(g)
+        exp = torch.arange(g.numel(), dtype=torch.float32) * 1.5
+        assert torch.allclose(g[:used_end], exp[:used_end])
+        assert torch.equal(g[used_end:], (torch.arange(g.numel(), dtype=torch.float32) * (rank + 1))[used_end:])
+
+        # prototype statistics: N ranks x b  ==  1 process x N*b  
+        gen = torch.Generator().manual_seed(7)
+        pool_all = torch.randn(8, 64, generator=gen)
+        ids = torch.tensor([0, 0, 1, 2, 2, 2, 9, 1])
+        onehot_all = torch.zeros(8, 10).scatter_(1, ids[:, None], 1.0)
+        lo, hi = rank * 4, rank * 4 + 4
+        local_proto, local_cnt = R.calculate_current_prototype(pool_all[lo:hi].unsqueeze(1), onehot_all[lo:hi])
+        proto, cnt = model.proto._allreduce_stats(local_proto, local_cnt)
+        ref_proto, ref_cnt = R.calculate_current_prototype(pool_all.unsqueeze(1), onehot_all)
+        assert torch.allclose(proto, ref_proto, atol=1e-6) and torch.equal(cnt, ref_cnt)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_data_parallel_wrapper_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

@@ -159,6 +159,15 @@ def test_layernorm_fwd_bwd(dev, rows, d):
     close(dw, w.grad, 1e-4, 1e-3, "ln dw")
     dx2, _ = ops.layernorm_bwd(gy.to(dev), x.detach().to(dev), w.detach().to(dev), rstd, dx=torch.ones(rows, d, device=dev))
     close(dx2, x.grad + 1.0, 1e-4, 1e-5, "ln dx accumulate")
+    # the deferred multi-job reduction (what the engine uses) agrees with the immediate one
+    _, dw2 = ops.layernorm_bwd(gy.to(dev), x.detach().to(dev), w.detach().to(dev), rstd, deferred_reduce=True)
+    assert torch.equal(dw, dw2)
+    # fused bf16(dropout(dx)) output == the stand-alone drop_cast kernel on the same dx
+    dx3, _, dxb = ops.layernorm_bwd(gy.to(dev), x.detach().to(dev), w.detach().to(dev), rstd, want_bf16=True, dx_drop_p=0.1,
+                                    dx_drop_seed=4242)
+    assert torch.equal(dxb, ops.drop_cast(dx3, 0.1, 4242))
+    frac = float((dxb == 0).float().mean())
+    assert abs(frac - 0.1) < 0.02, frac
 
 
 def test_layernorm_golden(dev):

@@ -318,3 +318,57 @@ def test_state_dict_roundtrip_and_greedy_decode(dev):
     agree = float((cur[:, :tok.shape[1]] == tok.cpu()).float().mean())
     print("greedy agreement with oracle:", agree)
     assert agree >= 0.75
+
+
+def test_data_parallel_overlap_path_on_one_gpu_and_rank_equivalence(dev):
+    """(1) The RCCL path (events recorded by the engine, comm stream, bucketed all-reduce over flat-gradient slices) with a
+    single-rank NCCL group on the real GPU: gradients must equal the non-DP run bit for bit.
+    (2) DP semantics: mean of the gradients of two half batches == gradient of the full batch (equal per-rank b)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from oracle import ref_cpu as R
+    from vqacl_amd.parallel import DataParallelVLT5
+    ocfg = R.tiny_cfg()
+    params = R.init_params(ocfg, seed=77)
+    batch = R.synthetic_batch(ocfg, B=8, L=12, V=36, T=4, seed=5)
+    plain = make_model(ocfg, params, dev)
+    plain.train()
+    plain.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
+    g_plain = plain.flat_grads().clone()
+
+    if not dist.is_initialized():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        model = make_model(ocfg, params, dev)
+        model.train()
+        dp = DataParallelVLT5(model, bucket_mb=0.05)           # tiny buckets: several collectives interleaved with backward
+        dp.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
+        torch.cuda.synchronize()
+        assert torch.equal(model.flat_grads(), g_plain)
+    finally:
+        dist.destroy_process_group()
+
+    # rank equivalence with fixed prototypes (under DP the prototype statistics are all-reduced, see test_dp_cpu)
+    m = make_model(ocfg, params, dev)
+    m.train()
+    m.Q_prototype = plain.Q_prototype
+    m.V_prototype = plain.V_prototype
+
+    def grads_of(sl):
+        for p in m.parameters():
+            p.grad = None
+        b = {k: v[sl] for k, v in batch.items()}
+        out = m(input_ids=b["input_ids"], vis_inputs=(b["vis_feats"], b["boxes"]), labels=b["target_ids"], proto_update=False,
+                scores=b["scores"])
+        out["loss_reduced"].backward()
+        return m.flat_grads().clone()
+    full = grads_of(slice(0, 8))
+    half = 0.5 * (grads_of(slice(0, 4)) + grads_of(slice(4, 8)))
+    assert cos(full, half) > 0.9995
+    assert abs(float(half.norm() / full.norm()) - 1.0) < 1e-2

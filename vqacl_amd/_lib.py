@@ -56,7 +56,8 @@ PROTOTYPES = {
     "vlt5_gemm_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
     "vlt5_gemm_auto_split": (c_i, [c_i, c_i, c_i, c_ll]),
     "vlt5_layernorm_fwd": (c_i, [vp, vp, vp, vp, vp, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),
-    "vlt5_layernorm_bwd": (c_i, [vp, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp]),
+    "vlt5_layernorm_bwd": (c_i, [vp, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, c_f, c_u32, vp]),
+    "vlt5_colsum_multi": (c_i, [vp, vp, C.POINTER(c_ll), C.POINTER(c_i), c_i, c_i, c_i, vp]),
     "vlt5_layernorm_bwd_blocks": (c_i, [c_i]),
     "vlt5_attn_fwd": (c_i, [C.POINTER(AttnDesc), vp]),
     "vlt5_attn_bwd": (c_i, [C.POINTER(AttnDesc), vp]),

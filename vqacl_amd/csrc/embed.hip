@@ -243,16 +243,17 @@ __global__ void relbias_sum_mats_kernel(const float* __restrict__ dS, float* __r
     for (int m = m0; m < m1; ++m) s += dS[(size_t)m * n + i];
     R[(size_t)blockIdx.y * n + i] = s;
 }
+// one wave per (bucket, head): lanes stride over the positions, fixed-order wave reduction
 __global__ void relbias_scatter_kernel(const float* __restrict__ R, const int* __restrict__ lut, float* __restrict__ dtable,
                                        int H, int npos, int nbuckets, int ngroups, int accum) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= H * nbuckets) return;
-    int bucket = i / H, h = i % H;
-    float s = accum ? dtable[i] : 0.f;
-    for (int pos = 0; pos < npos; ++pos)
+    const int i = blockIdx.x;                 // bucket * H + h
+    const int bucket = i / H, h = i % H;
+    float s = 0.f;
+    for (int pos = threadIdx.x; pos < npos; pos += 64)
         if (lut[pos] == bucket)
             for (int g = 0; g < ngroups; ++g) s += R[((size_t)g * H + h) * npos + pos];
-    dtable[i] = s;
+    s = wave_sum(s);
+    if (threadIdx.x == 0) dtable[i] = accum ? dtable[i] + s : s;
 }
 
 }  // namespace
@@ -346,7 +347,7 @@ extern "C" int vlt5_relbias_bwd(const float* dS, const int* lut, float* dtable, 
     const int per_group = (nmat + ngroups - 1) / ngroups;
     hipLaunchKernelGGL(relbias_sum_mats_kernel, dim3((n + 255) / 256, ngroups), dim3(256), 0, ST, dS, scratch, nmat, n, per_group);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(relbias_scatter_kernel, dim3((H * nbuckets + 63) / 64), dim3(64), 0, ST, scratch, lut, dtable, H, Lq * Lk,
+    hipLaunchKernelGGL(relbias_scatter_kernel, dim3(H * nbuckets), dim3(64), 0, ST, scratch, lut, dtable, H, Lq * Lk,
                        nbuckets, (nmat + per_group - 1) / per_group, accum);
     LAUNCH_CHECK();
     return VLT5_OK;

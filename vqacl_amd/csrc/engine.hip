@@ -49,22 +49,26 @@ void build_layout(const vlt5_config& c, Layout& L, bool names) {
         return o;
     };
     auto nm = [&](const char* fmt, int i) { char b[160]; snprintf(b, sizeof b, fmt, i); return std::string(b); };
+    // The (tiny) norm weights are placed together in the LAST bucket: their gradients are reduced once per backward phase
+    // by a single multi-job launch, i.e. later than the matrices of their layer.
+    std::vector<std::pair<long long*, std::string>> norms;
+    auto norm = [&](long long* slot, const std::string& name) { norms.push_back({slot, name}); };
     int bucket = 0;
     const int Ld = c.num_decoder_layers, Le = c.num_layers;
-    L.dec_final_ln = add("decoder.final_layer_norm.weight", d, 0, bucket);
+    norm(&L.dec_final_ln, "decoder.final_layer_norm.weight");
     for (int i = Ld - 1; i >= 0; --i) {
         auto& D = L.dec[i];
         D.wo = add(nm("decoder.block.%d.layer.2.DenseReluDense.wo.weight", i), d, ff, bucket);
         D.wi = add(nm("decoder.block.%d.layer.2.DenseReluDense.wi.weight", i), ff, d, bucket);
-        D.ln_f = add(nm("decoder.block.%d.layer.2.layer_norm.weight", i), d, 0, bucket);
+        norm(&D.ln_f, nm("decoder.block.%d.layer.2.layer_norm.weight", i));
         D.co = add(nm("decoder.block.%d.layer.1.EncDecAttention.o.weight", i), d, inner, bucket);
         D.cq = add(nm("decoder.block.%d.layer.1.EncDecAttention.q.weight", i), inner, d, bucket);
-        D.ln_c = add(nm("decoder.block.%d.layer.1.layer_norm.weight", i), d, 0, bucket);
+        norm(&D.ln_c, nm("decoder.block.%d.layer.1.layer_norm.weight", i));
         D.so = add(nm("decoder.block.%d.layer.0.SelfAttention.o.weight", i), d, inner, bucket);
         D.sqkv = add(nm("decoder.block.%d.layer.0.SelfAttention.q.weight", i), inner, d, bucket);
         add(nm("decoder.block.%d.layer.0.SelfAttention.k.weight", i), inner, d, bucket);
         add(nm("decoder.block.%d.layer.0.SelfAttention.v.weight", i), inner, d, bucket);
-        D.ln_s = add(nm("decoder.block.%d.layer.0.layer_norm.weight", i), d, 0, bucket);
+        norm(&D.ln_s, nm("decoder.block.%d.layer.0.layer_norm.weight", i));
         if (i == 0) L.dec_rel = add("decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", c.rel_buckets, c.num_heads, bucket);
         ++bucket;
     }
@@ -74,20 +78,21 @@ void build_layout(const vlt5_config& c, Layout& L, bool names) {
         add(nm("decoder.block.%d.layer.1.EncDecAttention.v.weight", i), inner, d, bucket);
     }
     ++bucket;
-    L.enc_final_ln = add("encoder.final_layer_norm.weight", d, 0, bucket);
+    norm(&L.enc_final_ln, "encoder.final_layer_norm.weight");
     for (int i = Le - 1; i >= 0; --i) {
         auto& E = L.enc[i];
         E.wo = add(nm("encoder.block.%d.layer.1.DenseReluDense.wo.weight", i), d, ff, bucket);
         E.wi = add(nm("encoder.block.%d.layer.1.DenseReluDense.wi.weight", i), ff, d, bucket);
-        E.ln_f = add(nm("encoder.block.%d.layer.1.layer_norm.weight", i), d, 0, bucket);
+        norm(&E.ln_f, nm("encoder.block.%d.layer.1.layer_norm.weight", i));
         E.so = add(nm("encoder.block.%d.layer.0.SelfAttention.o.weight", i), d, inner, bucket);
         E.sqkv = add(nm("encoder.block.%d.layer.0.SelfAttention.q.weight", i), inner, d, bucket);
         add(nm("encoder.block.%d.layer.0.SelfAttention.k.weight", i), inner, d, bucket);
         add(nm("encoder.block.%d.layer.0.SelfAttention.v.weight", i), inner, d, bucket);
-        E.ln_s = add(nm("encoder.block.%d.layer.0.layer_norm.weight", i), d, 0, bucket);
+        norm(&E.ln_s, nm("encoder.block.%d.layer.0.layer_norm.weight", i));
         if (i == 0) L.enc_rel = add("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", c.rel_buckets, c.num_heads, bucket);
         ++bucket;
     }
+    for (auto& pr : norms) *pr.first = add(pr.second, d, 0, bucket);
     const char* ve = "encoder.visual_embedding.";
     L.vis_wf = add(std::string(ve) + "feat_embedding.0.weight", d, c.feat_dim, bucket);
     L.vis_bf = add(std::string(ve) + "feat_embedding.0.bias", d, 0, bucket);
@@ -176,7 +181,7 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     if (3 * inner * d > wmax) wmax = 3 * inner * d;
     p.slab_bytes = 8 * wmax * 4;
     p.slab = take(p.slab_bytes);
-    p.ln_partial = take((size_t)256 * d * 4);
+    p.ln_partial = take((size_t)64 * 128 * d * 4);          // 64 norm slots x 128 workgroup partials
     p.vis_partial = take(((size_t)64 * 10 * d + 2 * (size_t)B * V) * 4);
     size_t rs = 16 * H * (size_t)(L > T ? L : T) * (L > T ? L : T) * 4;
     p.rel_scratch = take(rs);
@@ -197,6 +202,9 @@ struct Ctx {
     float* Gr;
     float pdrop;
     int d, inner, ff, H;
+    mutable int ln_jobs = 0;
+    mutable long long ln_out[64];
+    mutable int ln_nblk[64];
     Ctx(const vlt5_config& c_, const vlt5_step& s_, void* stream) : c(c_), s(s_), st((hipStream_t)stream) {
         build_layout(c, lay, false);
         make_plan(c, s.B, s.L, s.V, s.T, p);
@@ -251,6 +259,25 @@ struct Ctx {
         int sk = pick_split(N, K, M);
         if (sk > 1) { g.split_k = sk; g.workspace = w<void>(p.slab); }
         return vlt5_gemm_bf16(&g, st);
+    }
+    // T5LayerNorm backward into the running residual gradient `dx`; `emit_next` additionally writes bf16(dropout(dx)) into
+    // the shared `dyd` buffer for the sublayer processed next.  The weight gradient is left as per-workgroup partials in
+    // slot `ln_jobs`; ln_flush() reduces all slots of the phase with one launch.
+    int ln_bwd(const float* dy, const float* x, long long w_off, const float* rstd, float* dx, int rows, int accum_dx,
+               float dp, uint32_t dseed, int in_group, int in_group_stride, bool emit_next, uint32_t next_seed) const {
+        if (ln_jobs >= 64) return VLT5_ERR_ARG;
+        float* part = w<float>(p.ln_partial) + (size_t)ln_jobs * 128 * d;
+        ln_out[ln_jobs] = w_off;
+        ln_nblk[ln_jobs] = vlt5_layernorm_bwd_blocks(rows);
+        ++ln_jobs;
+        return vlt5_layernorm_bwd(dy, x, P + w_off, rstd, dx, nullptr, part, rows, d, accum_dx, 0, dp, dseed, in_group,
+                                  in_group_stride, emit_next ? w<void>(p.dyd) : nullptr, emit_next ? pdrop : 0.f, next_seed, st);
+    }
+    int ln_flush() const {
+        if (ln_jobs == 0) return VLT5_OK;
+        int rc = vlt5_colsum_multi(w<float>(p.ln_partial), Gr, ln_out, ln_nblk, ln_jobs, 128, d, st);
+        ln_jobs = 0;
+        return rc;
     }
     int record(int k) const {
         if (s.events && k >= 0 && k < s.n_events && s.events[k]) HIP_RET(hipEventRecord((hipEvent_t)s.events[k], st));
@@ -358,22 +385,22 @@ int decoder_fwd(const Ctx& k) {
     return VLT5_OK;
 }
 
-// backward of one  x_out = x_in + drop(W_o . drop(relu(W_i . LN(x_in))))  sublayer; dx is updated in place
+// backward of one  x_out = x_in + drop(W_o . drop(relu(W_i . LN(x_in))))  sublayer; dx is updated in place.
+// On entry `dyd` already holds bf16(dropout_out(dx)) (emitted by the producer of dx); on exit it holds the operand of
+// the sublayer processed next (dropout site `next_seed`).
 int ffn_bwd(const Ctx& k, int M, float* dx, const float* x_in, const float* rstd, const bf16_t* xn, const bf16_t* h, long long wi,
-            long long wo, long long ln, uint32_t seed_h, uint32_t seed_out) {
+            long long wo, long long ln, uint32_t next_seed) {
     const Plan& p = k.p;
     const int d = k.d, ff = k.ff;
     bf16_t* dyd = k.w<bf16_t>(p.dyd);
     bf16_t* dh = k.w<bf16_t>(p.dh);
     float* tmp = k.w<float>(p.tmp);
-    (void)seed_h;
-    RC(vlt5_drop_cast(dx, dyd, M, d, k.pdrop, seed_out, k.st));
     RC(k.lin_wgrad(dyd, d, h, ff, k.Gr + wo, M, d, ff));
     const float gs = k.pdrop > 0.f ? drop_scale(drop_thr16(k.pdrop)) : 1.f;
     RC(k.lin_dgrad(dyd, k.Pb + wo, dh, M, d, ff, 0, 1.f, h, gs));
     RC(k.lin_wgrad(dh, ff, xn, d, k.Gr + wi, M, ff, d));
     RC(k.lin_dgrad(dh, k.Pb + wi, tmp, M, ff, d, 1));
-    RC(vlt5_layernorm_bwd(tmp, x_in, k.P + ln, rstd, dx, k.Gr + ln, k.w<float>(p.ln_partial), M, d, 1, 0, 0.f, 0, 0, 0, k.st));
+    RC(k.ln_bwd(tmp, x_in, ln, rstd, dx, M, 1, 0.f, 0, 0, 0, true, next_seed));
     return VLT5_OK;
 }
 
@@ -389,15 +416,14 @@ int decoder_bwd(const Ctx& k) {
     bf16_t* dqkv = k.w<bf16_t>(p.dqkv);
     bf16_t* dq_c = k.w<bf16_t>(p.dq_c);
     bf16_t* dlog = k.w<bf16_t>(p.dlogits);
-    float* lnp = k.w<float>(p.ln_partial);
     const long long* ids = k.w<long long>(p.dec_ids);
     RC(vlt5_ce_bwd(k.w<float>(p.logits), s.labels, k.w<float>(p.lse_ce), s.d_loss_tok ? s.d_loss_tok : k.w<float>(p.row_w),
                    s.d_loss_tok ? nullptr : s.gout, dlog, Md, c.vocab, k.st));
     // lm_head (tied to shared): dShared = alpha * dlogits^T dec_out ; d dec_out = alpha * dlogits shared
     RC(k.lin_wgrad(dlog, c.vocab, k.w<bf16_t>(p.dec_out), d, k.Gr + L.shared, Md, c.vocab, d, alpha, 0));
     RC(k.lin_dgrad(dlog, k.Pb + L.shared, tmp, Md, c.vocab, d, 1, alpha));
-    RC(vlt5_layernorm_bwd(tmp, k.w<float>(p.y[3 * Ld]), k.P + L.dec_final_ln, k.w<float>(p.yr[3 * Ld]), dx, k.Gr + L.dec_final_ln, lnp,
-                          Md, d, 0, 0, k.pdrop, k.seed(SITE_DEC_FINAL), 0, 0, k.st));
+    RC(k.ln_bwd(tmp, k.w<float>(p.y[3 * Ld]), L.dec_final_ln, k.w<float>(p.yr[3 * Ld]), dx, Md, 0, k.pdrop, k.seed(SITE_DEC_FINAL), 0, 0,
+                true, k.seed(SITE_DEC_BASE + (Ld - 1) * 8 + D_FFN_OUT)));
     for (int l = Ld - 1; l >= 0; --l) {
         const auto& D = L.dec[l];
         const uint32_t sb = SITE_DEC_BASE + l * 8;
@@ -405,9 +431,8 @@ int decoder_bwd(const Ctx& k) {
         bf16_t* kv = k.w<bf16_t>(p.kv_all) + (size_t)l * 2 * inner;
         bf16_t* dkv = k.w<bf16_t>(p.dkv_all) + (size_t)l * 2 * inner;
         RC(ffn_bwd(k, Md, dx, k.w<float>(p.y[3 * l + 2]), k.w<float>(p.yr[3 * l + 2]), k.w<bf16_t>(p.yn_f[l]), k.w<bf16_t>(p.hd[l]),
-                   D.wi, D.wo, D.ln_f, k.seed(sb + D_FFN_H), k.seed(sb + D_FFN_OUT)));
+                   D.wi, D.wo, D.ln_f, k.seed(sb + D_COUT)));
         // cross-attention sublayer
-        RC(vlt5_drop_cast(dx, dyd, Md, d, k.pdrop, k.seed(sb + D_COUT), k.st));
         RC(k.lin_wgrad(dyd, d, k.w<bf16_t>(p.ctx_c[l]), inner, k.Gr + D.co, Md, d, inner));
         RC(k.lin_dgrad(dyd, k.Pb + D.co, dctx, Md, d, inner, 0));
         RC(attn_call(k, true, k.w<bf16_t>(p.qc[l]), (long long)T * inner, inner, kv, kv + inner, (long long)Sx * kvw, kvw, nullptr,
@@ -415,10 +440,8 @@ int decoder_bwd(const Ctx& k) {
                      (long long)T * inner, inner, dkv, dkv + inner, (long long)Sx * kvw, kvw, nullptr));
         RC(k.lin_wgrad(dq_c, inner, k.w<bf16_t>(p.yn_c[l]), d, k.Gr + D.cq, Md, inner, d));
         RC(k.lin_dgrad(dq_c, k.Pb + D.cq, tmp, Md, inner, d, 1));
-        RC(vlt5_layernorm_bwd(tmp, k.w<float>(p.y[3 * l + 1]), k.P + D.ln_c, k.w<float>(p.yr[3 * l + 1]), dx, k.Gr + D.ln_c, lnp, Md, d,
-                              1, 0, 0.f, 0, 0, 0, k.st));
+        RC(k.ln_bwd(tmp, k.w<float>(p.y[3 * l + 1]), D.ln_c, k.w<float>(p.yr[3 * l + 1]), dx, Md, 1, 0.f, 0, 0, 0, true, k.seed(sb + D_SOUT)));
         // causal self-attention sublayer
-        RC(vlt5_drop_cast(dx, dyd, Md, d, k.pdrop, k.seed(sb + D_SOUT), k.st));
         RC(k.lin_wgrad(dyd, d, k.w<bf16_t>(p.ctx_s[l]), inner, k.Gr + D.so, Md, d, inner));
         RC(k.lin_dgrad(dyd, k.Pb + D.so, dctx, Md, d, inner, 0));
         RC(attn_call(k, true, qkv, (long long)T * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)T * 3 * inner,
@@ -427,8 +450,8 @@ int decoder_bwd(const Ctx& k) {
                      (long long)T * 3 * inner, 3 * inner, k.w<float>(p.dS_dec) + (size_t)l * B * k.H * T * T));
         RC(k.lin_wgrad(dqkv, 3 * inner, k.w<bf16_t>(p.yn_a[l]), d, k.Gr + D.sqkv, Md, 3 * inner, d));
         RC(k.lin_dgrad(dqkv, k.Pb + D.sqkv, tmp, Md, 3 * inner, d, 1));
-        RC(vlt5_layernorm_bwd(tmp, k.w<float>(p.y[3 * l]), k.P + D.ln_s, k.w<float>(p.yr[3 * l]), dx, k.Gr + D.ln_s, lnp, Md, d, 1, 0,
-                              0.f, 0, 0, 0, k.st));
+        RC(k.ln_bwd(tmp, k.w<float>(p.y[3 * l]), D.ln_s, k.w<float>(p.yr[3 * l]), dx, Md, 1, 0.f, 0, 0, 0, l > 0,
+                    l > 0 ? k.seed(SITE_DEC_BASE + (l - 1) * 8 + D_FFN_OUT) : 0u));
         if (l == 0)
             RC(vlt5_relbias_bwd(k.w<float>(p.dS_dec), s.dec_lut, k.Gr + L.dec_rel, k.w<float>(p.rel_scratch), Ld * B, k.H, T, T,
                                 c.rel_buckets, 0, k.st));
@@ -438,6 +461,7 @@ int decoder_bwd(const Ctx& k) {
     // cross-attention K/V projections of all layers at once
     RC(k.lin_wgrad(k.w<bf16_t>(p.dkv_all), kvw, k.w<bf16_t>(p.enc_ext), d, k.Gr + L.cross_kv, Mx, kvw, d));
     RC(k.lin_dgrad(k.w<bf16_t>(p.dkv_all), k.Pb + L.cross_kv, k.w<void>(p.d_enc_ext), Mx, kvw, d, 1));
+    RC(k.ln_flush());
     RC(k.record(Ld));
     return VLT5_OK;
 }
@@ -450,17 +474,15 @@ int encoder_bwd(const Ctx& k) {
     bf16_t* dyd = k.w<bf16_t>(p.dyd);
     bf16_t* dctx = k.w<bf16_t>(p.dctx);
     bf16_t* dqkv = k.w<bf16_t>(p.dqkv);
-    float* lnp = k.w<float>(p.ln_partial);
     // the 2 prototype rows of every sample are detached (src/modeling_t5_our.py:615): only rows 0..S-1 flow back
-    RC(vlt5_layernorm_bwd(k.w<float>(p.d_enc_ext), k.w<float>(p.x[2 * Le]), k.P + L.enc_final_ln, k.w<float>(p.xr[2 * Le]), dx,
-                          k.Gr + L.enc_final_ln, lnp, M, d, 0, 0, k.pdrop, k.seed(SITE_ENC_FINAL), S, Sx, k.st));
+    RC(k.ln_bwd(k.w<float>(p.d_enc_ext), k.w<float>(p.x[2 * Le]), L.enc_final_ln, k.w<float>(p.xr[2 * Le]), dx, M, 0, k.pdrop,
+                k.seed(SITE_ENC_FINAL), S, Sx, true, k.seed(SITE_ENC_BASE + (Le - 1) * 8 + E_FFN_OUT)));
     for (int l = Le - 1; l >= 0; --l) {
         const auto& E = L.enc[l];
         const uint32_t sb = SITE_ENC_BASE + l * 8;
         bf16_t* qkv = k.w<bf16_t>(p.qkv[l]);
         RC(ffn_bwd(k, M, dx, k.w<float>(p.x[2 * l + 1]), k.w<float>(p.xr[2 * l + 1]), k.w<bf16_t>(p.xn_f[l]), k.w<bf16_t>(p.h[l]), E.wi,
-                   E.wo, E.ln_f, k.seed(sb + E_FFN_H), k.seed(sb + E_FFN_OUT)));
-        RC(vlt5_drop_cast(dx, dyd, M, d, k.pdrop, k.seed(sb + E_ATTN_OUT), k.st));
+                   E.wo, E.ln_f, k.seed(sb + E_ATTN_OUT)));
         RC(k.lin_wgrad(dyd, d, k.w<bf16_t>(p.ctx[l]), inner, k.Gr + E.so, M, d, inner));
         RC(k.lin_dgrad(dyd, k.Pb + E.so, dctx, M, d, inner, 0));
         RC(attn_call(k, true, qkv, (long long)S * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)S * 3 * inner,
@@ -469,8 +491,8 @@ int encoder_bwd(const Ctx& k) {
                      (long long)S * 3 * inner, 3 * inner, k.w<float>(p.dS_enc) + (size_t)l * B * k.H * s.L * s.L));
         RC(k.lin_wgrad(dqkv, 3 * inner, k.w<bf16_t>(p.xn_a[l]), d, k.Gr + E.sqkv, M, 3 * inner, d));
         RC(k.lin_dgrad(dqkv, k.Pb + E.sqkv, tmp, M, 3 * inner, d, 1));
-        RC(vlt5_layernorm_bwd(tmp, k.w<float>(p.x[2 * l]), k.P + E.ln_s, k.w<float>(p.xr[2 * l]), dx, k.Gr + E.ln_s, lnp, M, d, 1, 0, 0.f,
-                              0, 0, 0, k.st));
+        RC(k.ln_bwd(tmp, k.w<float>(p.x[2 * l]), E.ln_s, k.w<float>(p.xr[2 * l]), dx, M, 1, 0.f, 0, 0, 0, l > 0,
+                    l > 0 ? k.seed(SITE_ENC_BASE + (l - 1) * 8 + E_FFN_OUT) : 0u));
         if (l == 0)
             RC(vlt5_relbias_bwd(k.w<float>(p.dS_enc), s.enc_lut, k.Gr + L.enc_rel, k.w<float>(p.rel_scratch), Le * B, k.H, s.L, s.L,
                                 c.rel_buckets, 0, k.st));
@@ -492,6 +514,7 @@ int encoder_bwd(const Ctx& k) {
     RC(vlt5_colsum(vpart + 8 * d, k.Gr + L.vis_img, nsp, d, 10 * d, 0, k.st));
     RC(vlt5_colsum(vpart + 9 * d, k.Gr + L.vis_bf, nsp, d, 10 * d, 0, k.st));
     RC(k.lin_wgrad(k.w<bf16_t>(p.vis_dG), d, k.w<bf16_t>(p.feats_bf16), c.feat_dim, k.Gr + L.vis_wf, B * s.V, d, c.feat_dim));
+    RC(k.ln_flush());
     RC(k.record(Ld + 1 + Le));
     return VLT5_OK;
 }

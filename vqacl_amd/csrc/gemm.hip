@@ -120,6 +120,35 @@ __device__ __forceinline__ bf16x8_t frag_km(const char* tile, int r0, int ks, in
     return f;
 }
 
+// ---- direct global -> LDS staging (global_load_lds_dwordx4): no staging VGPRs, no ds_write.  The LDS destination of a
+// wave-instruction is linear (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE address
+// inside the same 128-byte row segment (same cache line, coalescing unchanged).  Only for full k-tiles; rows past the edge
+// are clamped to a valid row (their products land in outputs the epilogue never stores).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <int R>
+__device__ __forceinline__ void glds_rm(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, char* tile, int tid) {
+    const int wave_base = (tid & ~63);
+#pragma unroll
+    for (int i = 0; i < R / 32; ++i) {
+        const int c = tid + i * 256;
+        const int row = c >> 3, kc = (c & 7) ^ (row & 7);
+        const int gr = min(row0 + row, rmax - 1);
+        __builtin_amdgcn_global_load_lds(base + (size_t)gr * ld + k0 + kc * 8, (lds_ptr_t)(tile + (i * 256 + wave_base) * 16), 16, 0, 0);
+    }
+}
+template <int R>
+__device__ __forceinline__ void glds_km(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, char* tile, int tid) {
+    constexpr int CPR = R / 8;
+    const int wave_base = (tid & ~63);
+#pragma unroll
+    for (int i = 0; i < R / 32; ++i) {
+        const int c = tid + i * 256;
+        const int k = c / CPR, rc = (c % CPR) ^ km_swz<R>(k);
+        const int gr = min(row0 + rc * 8, rmax - 8);
+        __builtin_amdgcn_global_load_lds(base + (size_t)(k0 + k) * ld + gr, (lds_ptr_t)(tile + (i * 256 + wave_base) * 16), 16, 0, 0);
+    }
+}
+
 template <int BM, int BN, bool AKM, bool BKM>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     constexpr int FM = BM / 32, FN = BN / 32;                 // 16x16 fragments per wave
@@ -169,17 +198,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         if (BKM) lstore_km<BN>(bt, rb, tid); else lstore_rm<BN>(bt, rb, tid);
     };
 
+    auto glds = [&](int kt, int s) {                        // asynchronous: completion is awaited with vmcnt(0)
+        char* at = smem + s * STAGE_BYTES;
+        char* bt = at + A_BYTES;
+        if (AKM) glds_km<BM>(p.A, p.lda, m0, kt * BK, p.M, at, tid); else glds_rm<BM>(p.A, p.lda, m0, kt * BK, p.M, at, tid);
+        if (BKM) glds_km<BN>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid); else glds_rm<BN>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid);
+    };
+    auto full_tile = [&](int kt) { return (kt + 1) * BK <= p.K; };
+
     if (kt0 < kt1) {
-        gload(kt0);
-        lstore(0);
+        if (full_tile(kt0)) {
+            glds(kt0, 0);
+        } else {
+            gload(kt0);
+            lstore(0);
+        }
     }
+    __builtin_amdgcn_s_waitcnt(0);            // vmcnt(0): the direct-to-LDS loads have landed
     __syncthreads();
 
     int cur = 0;
     const int lrow = lane & 15, lg = lane >> 4;
     for (int kt = kt0; kt < kt1; ++kt) {
         const bool more = (kt + 1) < kt1;
-        if (more) gload(kt + 1);
+        const bool direct = more && full_tile(kt + 1);     // block-uniform
+        if (more) {
+            if (direct) glds(kt + 1, cur ^ 1);
+            else gload(kt + 1);
+        }
         const char* at = smem + cur * STAGE_BYTES;
         const char* bt = at + A_BYTES;
 #pragma unroll
@@ -203,17 +249,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
-        if (more) lstore(cur ^ 1);
+        if (more && !direct) lstore(cur ^ 1);
+        __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         cur ^= 1;
     }
 
     // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4 -----------
+    // The auxiliary operands (residual, gate, C for accumulation) of all FN fragments of a row block are requested first
+    // and consumed afterwards, so their latencies overlap instead of forming a chain of dependent round trips.
     const float dscale = drop_scale(p.drop_thr);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * (BM / 2) + i * 16 + lrow;
         if (m >= p.M) continue;
+        float4 rs[FN], cc[FN];
+        uint2 gt[FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
+            rs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            cc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            gt[j] = make_uint2(0u, 0u);
+            if (n < p.N) {
+                if (p.resid) rs[j] = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
+                if (p.gate) gt[j] = *reinterpret_cast<const uint2*>(p.gate + (size_t)m * p.ldg + n);
+                if (p.accum) cc[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Cbase) + (size_t)m * p.ldc + n);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
@@ -230,8 +293,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
             if (p.gate) {
-                uint2 g = *reinterpret_cast<const uint2*>(p.gate + (size_t)m * p.ldg + n);
-                uint32_t gw[2] = {g.x, g.y};
+                uint32_t gw[2] = {gt[j].x, gt[j].y};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     bf16_t h = (bf16_t)((gw[r >> 1] >> ((r & 1) * 16)) & 0xffffu);
@@ -243,16 +305,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = drop_keep(p.drop_seed, idx + r, p.drop_thr) ? v[r] * dscale : 0.f;
             }
-            if (p.resid) {
-                float4 q = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
-                v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
-            }
+            v[0] += rs[j].x + cc[j].x; v[1] += rs[j].y + cc[j].y; v[2] += rs[j].z + cc[j].z; v[3] += rs[j].w + cc[j].w;
             if (p.out_f32) {
                 float* c = reinterpret_cast<float*>(Cbase) + (size_t)m * p.ldc + n;
-                if (p.accum) {
-                    float4 q = *reinterpret_cast<const float4*>(c);
-                    v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
-                }
                 *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 bf16_t* c = reinterpret_cast<bf16_t*>(Cbase) + (size_t)m * p.ldc + n;
@@ -313,12 +368,14 @@ extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
     a.ktiles_per_split = 0; a.c_split_stride = 0;
 
     int bm = d->tile_m, bn = d->tile_n;
-    if (bm == 0 || bn == 0) {                       // heuristic: largest tile that still gives >= ~2 blocks per CU
-        long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
-        long t12864 = (long)((d->M + 127) / 128) * ((d->N + 63) / 64);
-        int sk = d->split_k > 1 ? d->split_k : 1;
-        if (t128 * sk >= 448) { bm = 128; bn = 128; }
-        else if (t12864 * sk >= 384) { bm = 128; bn = 64; }
+    if (bm == 0 || bn == 0) {
+        // heuristic from tools/gemm_sweep.py on MI355X: the largest tile that still yields >= 3 workgroups per CU
+        // (the GEMMs of this model are small: a 4480 x 768 output is 210 tiles of 128 x 128 for 256 CUs)
+        const int sk = d->split_k > 1 ? d->split_k : 1;
+        auto tiles = [&](int tm, int tn) { return (long)((d->M + tm - 1) / tm) * ((d->N + tn - 1) / tn) * sk; };
+        if (tiles(128, 128) >= 768) { bm = 128; bn = 128; }
+        else if (tiles(64, 128) >= 768) { bm = 64; bn = 128; }
+        else if (tiles(128, 64) >= 768) { bm = 128; bn = 64; }
         else { bm = 64; bn = 64; }
     }
     if (!((bm == 128 || bm == 64) && (bn == 128 || bn == 64))) return VLT5_ERR_ARG;

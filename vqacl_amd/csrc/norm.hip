@@ -52,7 +52,8 @@ constexpr int LN_MAXCH = 8;   // d <= 2048
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ rstd,
                                                      float* __restrict__ dx, float* __restrict__ dwp, int rows, int d,
-                                                     int accum_dx, uint32_t thr, uint32_t seed, int group, int gstride) {
+                                                     int accum_dx, uint32_t thr, uint32_t seed, int group, int gstride,
+                                                     bf16_t* __restrict__ dxb, uint32_t thr2, uint32_t seed2) {
     extern __shared__ float red[];                       // [4][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 dwacc[LN_MAXCH];
@@ -107,6 +108,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
                 }
                 *reinterpret_cast<float4*>(dp) = o;
+                if (dxb) {                      // bf16(dropout(dx)) = the A operand of the next sublayer's backward GEMMs
+                    float q[4] = {o.x, o.y, o.z, o.w};
+                    if (thr2) {
+                        const float dsc2 = drop_scale(thr2);
+                        uint32_t idx = (uint32_t)row * (uint32_t)d + (uint32_t)c;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) q[e] = drop_keep(seed2, idx + e, thr2) ? q[e] * dsc2 : 0.f;
+                    }
+                    uint2 pk;
+                    pk.x = pack_bf16x2(q[0], q[1]);
+                    pk.y = pack_bf16x2(q[2], q[3]);
+                    *reinterpret_cast<uint2*>(dxb + (size_t)row * d + c) = pk;
+                }
             }
         }
     }
@@ -137,6 +151,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
     }
 }
 
+struct MultiColsum { long long out_off[64]; int nblk[64]; };
+// job j (blockIdx.y): out[out_off[j] + c] = sum_blk partial[(j*slot_rows + blk)*width + c]   -- one launch for all norms
+__global__ __launch_bounds__(256) void colsum_multi_kernel(const float* __restrict__ partial, float* __restrict__ out_base,
+                                                           MultiColsum t, int slot_rows, int width) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, j = blockIdx.y;
+    const int c = blockIdx.x * 64 + lane;
+    const float* pj = partial + (size_t)j * slot_rows * width;
+    float s = 0.f;
+    if (c < width)
+        for (int b = grp; b < t.nblk[j]; b += 4) s += pj[(size_t)b * width + c];
+    sh[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && c < width) out_base[t.out_off[j] + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+
 }  // namespace
 
 extern "C" int vlt5_layernorm_bwd_blocks(int rows) {
@@ -158,16 +188,32 @@ extern "C" int vlt5_layernorm_fwd(const float* x, const float* w, void* y_bf16, 
 
 extern "C" int vlt5_layernorm_bwd(const float* dy, const float* x, const float* w, const float* rstd, float* dx, float* dw,
                                   float* dw_partial, int rows, int d, int accum_dx, int accum_dw, float drop_p,
-                                  uint32_t drop_seed, int in_group, int in_group_stride, void* stream) {
-    if (!dy || !x || !w || !rstd || !dx || !dw || !dw_partial || rows <= 0) return VLT5_ERR_ARG;
+                                  uint32_t drop_seed, int in_group, int in_group_stride, void* dx_bf16, float dx_drop_p,
+                                  uint32_t dx_drop_seed, void* stream) {
+    if (!dy || !x || !w || !rstd || !dx || !dw_partial || rows <= 0) return VLT5_ERR_ARG;
     if ((d & 3) || d > 256 * LN_MAXCH) return VLT5_ERR_ALIGN;
     uint32_t thr = drop_p > 0.f ? drop_thr16(drop_p) : 0u;
+    uint32_t thr2 = dx_drop_p > 0.f ? drop_thr16(dx_drop_p) : 0u;
     int nblk = vlt5_layernorm_bwd_blocks(rows);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 4 * d * sizeof(float), (hipStream_t)stream, dy, x, w, rstd, dx,
-                       dw_partial, rows, d, accum_dx, thr, drop_seed, in_group, in_group_stride);
+                       dw_partial, rows, d, accum_dx, thr, drop_seed, in_group, in_group_stride, (bf16_t*)dx_bf16, thr2,
+                       dx_drop_seed);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)stream, dw_partial, dw, nblk, d,
-                       d, accum_dw);
+    if (dw) {
+        hipLaunchKernelGGL(colsum_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)stream, dw_partial, dw, nblk, d, d,
+                           accum_dw);
+        LAUNCH_CHECK();
+    }
+    return VLT5_OK;
+}
+
+extern "C" int vlt5_colsum_multi(const float* partial, float* out_base, const long long* out_off, const int* nblk, int njobs,
+                                 int slot_rows, int width, void* stream) {
+    if (!partial || !out_base || !out_off || !nblk || njobs < 1 || njobs > 64 || slot_rows < 1 || width < 1) return VLT5_ERR_ARG;
+    MultiColsum t;
+    for (int j = 0; j < njobs; ++j) { t.out_off[j] = out_off[j]; t.nblk[j] = nblk[j]; }
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((width + 63) / 64, njobs), dim3(256), 0, (hipStream_t)stream, partial, out_base,
+                       t, slot_rows, width);
     LAUNCH_CHECK();
     return VLT5_OK;
 }

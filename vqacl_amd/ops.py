@@ -61,15 +61,24 @@ def layernorm_fwd(x, w, eps=1e-6, want_f32=False, drop_p=0.0, drop_seed=0):
     return yb, yf, rstd
 
 
-def layernorm_bwd(dy, x, w, rstd, dx=None, drop_p=0.0, drop_seed=0):
+def layernorm_bwd(dy, x, w, rstd, dx=None, drop_p=0.0, drop_seed=0, want_bf16=False, dx_drop_p=0.0, dx_drop_seed=0,
+                  deferred_reduce=False):
     rows, d = x.shape
     accum = dx is not None
     if dx is None:
         dx = torch.empty_like(x)
     dw = torch.empty(d, device=x.device, dtype=torch.float32)
     part = torch.empty(lib().vlt5_layernorm_bwd_blocks(rows), d, device=x.device, dtype=torch.float32)
-    check(lib().vlt5_layernorm_bwd(ptr(dy), ptr(x), ptr(w), ptr(rstd), ptr(dx), ptr(dw), ptr(part), rows, d, int(accum), 0,
-                                   drop_p, drop_seed, 0, 0, stream_ptr()), "vlt5_layernorm_bwd")
+    dxb = torch.empty(rows, d, device=x.device, dtype=BF16) if want_bf16 else None
+    check(lib().vlt5_layernorm_bwd(ptr(dy), ptr(x), ptr(w), ptr(rstd), ptr(dx), ptr(None if deferred_reduce else dw), ptr(part),
+                                   rows, d, int(accum), 0, drop_p, drop_seed, 0, 0, ptr(dxb), dx_drop_p, dx_drop_seed,
+                                   stream_ptr()), "vlt5_layernorm_bwd")
+    if deferred_reduce:                 # the engine's way: one multi-job reduction launch for many norms
+        off = (L.c_ll * 1)(0)
+        nb = (L.c_i * 1)(part.shape[0])
+        check(lib().vlt5_colsum_multi(ptr(part), ptr(dw), off, nb, 1, part.shape[0], d, stream_ptr()), "vlt5_colsum_multi")
+    if want_bf16:
+        return dx, dw, dxb
     return dx, dw
 
 
@@ -204,3 +213,11 @@ def proto_memory_loss(pool, onehot, protos):
     check(lib().vlt5_proto_memory_loss(ptr(pool), ptr(onehot), ptr(protos), ptr(out), pool.shape[0], protos.shape[0],
                                        pool.shape[1], stream_ptr()), "vlt5_proto_memory_loss")
     return out
+
+
+def drop_cast(src, drop_p=0.0, drop_seed=0):
+    """bf16(dropout(src)) with the engine's counter-based mask (element index = row*cols + col)."""
+    rows, cols = src.shape
+    dst = torch.empty(rows, cols, device=src.device, dtype=BF16)
+    check(lib().vlt5_drop_cast(ptr(_need(src, torch.float32)), ptr(dst), rows, cols, drop_p, drop_seed, stream_ptr()), "vlt5_drop_cast")
+    return dst
