@@ -174,7 +174,7 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     ms = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
@@ -187,6 +187,25 @@ def main():
            "samples_per_sec_per_gpu": round(value / world, 2), "final_loss": round(final_loss, 4),
            "step_tflops_per_gpu": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms, 2),
            "step_frac_of_mfma_peak": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
+    if rank == 0 and world == 1:
+        # PCIe-inclusive rate (never `value`): the boundary normally hands over pinned HOST tensors (collate_fn output);
+        # train_step then copies 23.6 MB of fp32 region features per batch of 80 before the engine starts.
+        host = {k: v.cpu().pin_memory() for k, v in batch.items()}
+
+        def step_host():
+            res = handle.train_step(host, 0, 0.5, 0.3)
+            res["loss"].backward()
+            opt.step()
+            for p in model.parameters():
+                p.grad = None
+        for _ in range(2):
+            step_host()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step_host()
+        torch.cuda.synchronize()
+        out["samples_per_sec_pcie_inclusive"] = round(5 * B / (time.perf_counter() - t1), 2)
     if rank == 0 and world == 1 and not args.no_roofline:
         rows = time_gemms(cfg, B, L, V, T, dev)
         launches = sum(r["count"] for r in rows)
