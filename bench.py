@@ -27,16 +27,20 @@ MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense b
 
 
 def gemm_schedule(cfg, B, L, V, T):
-    """Every GEMM launch of one train step as (count, M, N, K, a_kmajor, b_kmajor, out_f32): mirrors csrc/engine.hip."""
+    """Every GEMM launch of one train step as (count, batch, M, N, K, a_kmajor, b_kmajor, out_f32): mirrors csrc/engine.hip
+    (the weight-gradient GEMMs of all layers of a stack run as one batched launch per weight kind)."""
     d, inner, ff, Le, Ld, vocab, fd = cfg.d_model, cfg.num_heads * cfg.d_kv, cfg.d_ff, cfg.num_layers, cfg.num_decoder_layers, cfg.vocab_size, cfg.feat_dim
     S, Sx = L + V, L + V + 2
     M, Mx, Md = B * S, B * Sx, B * T
     sch = []
 
-    def lin(count, rows, n_out, k_in, dgrad_f32=True):
-        sch.append((count, rows, n_out, k_in, 0, 0, 0))            # forward
-        sch.append((count, rows, k_in, n_out, 0, 1, int(dgrad_f32)))   # dgrad
-        sch.append((count, n_out, k_in, rows, 1, 1, 1))            # wgrad
+    def lin(layers, rows, n_out, k_in, dgrad_f32=True, batched_wgrad=True):
+        sch.append((layers, 1, rows, n_out, k_in, 0, 0, 0))            # forward
+        sch.append((layers, 1, rows, k_in, n_out, 0, 1, int(dgrad_f32)))   # dgrad
+        if batched_wgrad:
+            sch.append((1, layers, n_out, k_in, rows, 1, 1, 1))        # wgrad, grid.z = layers
+        else:
+            sch.append((layers, 1, n_out, k_in, rows, 1, 1, 1))
     lin(Le, M, 3 * inner, d)
     lin(Le, M, d, inner, False)
     lin(Le, M, ff, d)
@@ -47,36 +51,38 @@ def gemm_schedule(cfg, B, L, V, T):
     lin(Ld, Md, d, inner, False)
     lin(Ld, Md, ff, d)
     lin(Ld, Md, d, ff, False)
-    lin(1, Mx, Ld * 2 * inner, d)
-    lin(1, Md, vocab, d)
-    sch.append((1, B * V, d, fd, 0, 0, 1))
-    sch.append((1, d, fd, B * V, 1, 1, 1))
+    lin(1, Mx, Ld * 2 * inner, d, True, False)
+    lin(1, Md, vocab, d, True, False)
+    sch.append((1, 1, B * V, d, fd, 0, 0, 1))
+    sch.append((1, 1, d, fd, B * V, 1, 1, 1))
     return sch
 
 
 def time_gemms(cfg, B, L, V, T, dev, reps=10):
-    """HIP-event timing of each distinct GEMM launch shape on the current stream; returns per-instantiation totals."""
+    """HIP-event timing of each distinct GEMM launch of the step on the current stream (same tile / split-K / batching
+    policy as the engine)."""
     from vqacl_amd import ops
     from vqacl_amd._lib import lib
     BF = torch.bfloat16
     rows = []
-    for count, M, N, K, akm, bkm, of32 in gemm_schedule(cfg, B, L, V, T):
-        A = torch.randn((K, M) if akm else (M, K), device=dev).to(BF)
-        Bm = torch.randn((K, N) if bkm else (N, K), device=dev).to(BF)
-        out = torch.empty(M, N, device=dev, dtype=torch.float32 if of32 else BF)
-        # same split-K policy as csrc/engine.hip (plain f32 outputs of dgrad / wgrad GEMMs)
-        sk = lib().vlt5_gemm_auto_split(M, N, K, 8 * max(cfg.d_ff, 3 * cfg.num_heads * cfg.d_kv) * cfg.d_model * 4) if (of32 and bkm) else 1
-        kw = dict(a_kmajor=bool(akm), b_kmajor=bool(bkm), out=out, split_k=sk)
+    slab = 8 * max(cfg.d_ff, 3 * cfg.num_heads * cfg.d_kv) * cfg.d_model * 4
+    for count, batch, M, N, K, akm, bkm, of32 in gemm_schedule(cfg, B, L, V, T):
+        A = torch.randn((batch, K, M) if akm else (batch, M, K), device=dev).to(BF)
+        Bm = torch.randn((batch, K, N) if bkm else (batch, N, K), device=dev).to(BF)
+        out = torch.empty(batch, M, N, device=dev, dtype=torch.float32 if of32 else BF)
+        sk = lib().vlt5_gemm_auto_split(M, N, K, slab) if (of32 and bkm and batch == 1) else 1
+        kw = dict(a_kmajor=bool(akm), b_kmajor=bool(bkm), out=out[0], split_k=sk, batch=batch,
+                  batch_strides=(A.stride(0), Bm.stride(0), out.stride(0)))
         for _ in range(2):
-            ops.gemm(A, Bm, M, N, K, **kw)
+            ops.gemm(A[0], Bm[0], M, N, K, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            ops.gemm(A, Bm, M, N, K, **kw)
+            ops.gemm(A[0], Bm[0], M, N, K, **kw)
         e1.record()
         e1.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        rows.append(dict(count=count, M=M, N=N, K=K, akm=akm, bkm=bkm, ms=ms, gflop=2.0 * M * N * K / 1e9))
+        rows.append(dict(count=count, batch=batch, M=M, N=N, K=K, akm=akm, bkm=bkm, ms=ms, gflop=2.0 * batch * M * N * K / 1e9))
         del A, Bm, out
     return rows
 
@@ -218,7 +224,7 @@ def main():
                            "launches_per_step": launches, "avg_launch_us": round(tot_ms / launches * 1e3, 2),
                            "gflop_per_launch": round(tot_gflop / launches, 3), "gemm_ms_per_step": round(tot_ms, 3)}
         worst = sorted(rows, key=lambda r: -r["count"] * r["ms"])[:6]
-        out["roofline"]["top_shapes"] = [dict(M=r["M"], N=r["N"], K=r["K"], akm=r["akm"], bkm=r["bkm"], count=r["count"],
+        out["roofline"]["top_shapes"] = [dict(M=r["M"], N=r["N"], K=r["K"], akm=r["akm"], bkm=r["bkm"], count=r["count"], batch=r["batch"],
                                               us=round(r["ms"] * 1e3, 1), tflops=round(r["gflop"] / r["ms"], 1)) for r in worst]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

@@ -45,6 +45,8 @@ typedef struct {
     int relu, out_f32, accum;                /* accum: C += (f32 only) */
     int split_k; void* workspace;            /* split_k>1: f32 slabs [split_k][M*ldc], plain epilogue, ldc==N */
     int tile_m, tile_n;                      /* 0 = heuristic; else 64 or 128 */
+    int batch;                               /* > 1: batch of equal-shaped GEMMs (grid.z); entry z uses A + z*batch_stride_a, ... */
+    long long batch_stride_a, batch_stride_b, batch_stride_c;   /* element strides (may be negative); resid uses batch_stride_c */
 } vlt5_gemm_desc;
 int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream);
 long long vlt5_gemm_workspace_bytes(int M, int ldc, int split_k);

@@ -31,7 +31,8 @@ def main():
     BF = torch.bfloat16
     res = []
     seen = set()
-    for count, M, N, K, akm, bkm, of32 in gemm_schedule(cfg, B, 20, 36, 5):
+    for count, batch, M, N, K, akm, bkm, of32 in gemm_schedule(cfg, B, 20, 36, 5):
+        count = count * batch
         key = (M, N, K, akm, bkm)
         if key in seen:
             continue

@@ -23,7 +23,8 @@ class GemmDesc(C.Structure):
                 ("a_kmajor", c_i), ("b_kmajor", c_i), ("alpha", c_f), ("bias", vp), ("resid", vp), ("ldr", c_i),
                 ("gate", vp), ("ldg", c_i), ("gate_scale", c_f), ("drop_p", c_f), ("drop_seed", c_u32),
                 ("relu", c_i), ("out_f32", c_i), ("accum", c_i), ("split_k", c_i), ("workspace", vp),
-                ("tile_m", c_i), ("tile_n", c_i)]
+                ("tile_m", c_i), ("tile_n", c_i), ("batch", c_i), ("batch_stride_a", c_ll), ("batch_stride_b", c_ll),
+                ("batch_stride_c", c_ll)]
 
 
 class AttnDesc(C.Structure):

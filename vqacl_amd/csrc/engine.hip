@@ -124,8 +124,11 @@ struct Plan {
     size_t yn_a[MAXL], dqkv_s[MAXL], lse_s[MAXL], ctx_s[MAXL], yn_c[MAXL], qc[MAXL], lse_c[MAXL], ctx_c[MAXL], yn_f[MAXL], hd[MAXL];
     size_t dec_out, logits, lse_ce, loss_tok, row_w, loss;
     // backward scratch
-    size_t dx, tmp, dyd, dh, dctx, dqkv, dq_c, dkv_all, d_enc_ext, dS_enc, dS_dec, dlogits, slab, ln_partial, vis_partial,
-        rel_scratch, vis_dG, small;
+    size_t dx, tmp, dctx, dkv_all, d_enc_ext, dS_enc, dS_dec, dlogits, slab, ln_partial, vis_partial, rel_scratch, vis_dG, small;
+    // per-layer gradient operands kept until the end of the phase: the weight-gradient GEMMs of all layers run as ONE
+    // batched launch per weight kind (grid.z = layer)
+    size_t e_dyd_f[MAXL], e_dh[MAXL], e_dyd_a[MAXL], e_dqkv[MAXL];
+    size_t d_dyd_f[MAXL], d_dh[MAXL], d_dyd_c[MAXL], d_dq_c[MAXL], d_dyd_s[MAXL], d_dqkv[MAXL];
     size_t slab_bytes;
 };
 
@@ -167,11 +170,15 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     const size_t Mmax = Mx > Md ? Mx : Md;
     p.dx = take(Mmax * d * 4);
     p.tmp = take(Mmax * d * 4);
-    p.dyd = take(Mmax * d * 2);
-    p.dh = take(Mmax * ff * 2);
     p.dctx = take(Mmax * inner * 2);
-    p.dqkv = take(Mmax * 3 * inner * 2);
-    p.dq_c = take(Md * inner * 2);
+    for (int l = 0; l < Le; ++l) {
+        p.e_dyd_f[l] = take(M * d * 2); p.e_dh[l] = take(M * ff * 2); p.e_dyd_a[l] = take(M * d * 2);
+        p.e_dqkv[l] = take(M * 3 * inner * 2);
+    }
+    for (int l = 0; l < Ld; ++l) {
+        p.d_dyd_f[l] = take(Md * d * 2); p.d_dh[l] = take(Md * ff * 2); p.d_dyd_c[l] = take(Md * d * 2);
+        p.d_dq_c[l] = take(Md * inner * 2); p.d_dyd_s[l] = take(Md * d * 2); p.d_dqkv[l] = take(Md * 3 * inner * 2);
+    }
     p.dkv_all = take(Mx * (size_t)Ld * 2 * inner * 2);
     p.d_enc_ext = take(Mx * d * 4);
     p.dS_enc = take((size_t)Le * B * H * L * L * 4);
@@ -261,23 +268,41 @@ struct Ctx {
         return vlt5_gemm_bf16(&g, st);
     }
     // T5LayerNorm backward into the running residual gradient `dx`; `emit_next` additionally writes bf16(dropout(dx)) into
-    // the shared `dyd` buffer for the sublayer processed next.  The weight gradient is left as per-workgroup partials in
+    // `next_dst` (the per-layer operand buffer of the sublayer processed next).  The weight gradient is left as per-workgroup partials in
     // slot `ln_jobs`; ln_flush() reduces all slots of the phase with one launch.
     int ln_bwd(const float* dy, const float* x, long long w_off, const float* rstd, float* dx, int rows, int accum_dx,
-               float dp, uint32_t dseed, int in_group, int in_group_stride, bool emit_next, uint32_t next_seed) const {
+               float dp, uint32_t dseed, int in_group, int in_group_stride, bf16_t* next_dst, uint32_t next_seed) const {
         if (ln_jobs >= 64) return VLT5_ERR_ARG;
         float* part = w<float>(p.ln_partial) + (size_t)ln_jobs * 128 * d;
         ln_out[ln_jobs] = w_off;
         ln_nblk[ln_jobs] = vlt5_layernorm_bwd_blocks(rows);
         ++ln_jobs;
         return vlt5_layernorm_bwd(dy, x, P + w_off, rstd, dx, nullptr, part, rows, d, accum_dx, 0, dp, dseed, in_group,
-                                  in_group_stride, emit_next ? w<void>(p.dyd) : nullptr, emit_next ? pdrop : 0.f, next_seed, st);
+                                  in_group_stride, next_dst, next_dst ? pdrop : 0.f, next_seed, st);
     }
     int ln_flush() const {
         if (ln_jobs == 0) return VLT5_OK;
         int rc = vlt5_colsum_multi(w<float>(p.ln_partial), Gr, ln_out, ln_nblk, ln_jobs, 128, d, st);
         ln_jobs = 0;
         return rc;
+    }
+    // dW_l[N,K] = dY_l[M,N]^T X_l[M,K] for `layers` layers at once; per-layer byte strides of the operand buffers and the
+    // element stride of the gradient entries are constant by construction of the plan / layout.
+    int wgrad_batched(size_t dy0, size_t dy1, int ldy, size_t x0, size_t x1, int ldx, long long g0, long long g1, int layers,
+                      int M, int N, int K) const {
+        vlt5_gemm_desc g;
+        memset(&g, 0, sizeof g);
+        g.A = w<void>(dy0); g.B = w<void>(x0); g.C = Gr + g0; g.M = N; g.N = K; g.K = M; g.lda = ldy; g.ldb = ldx; g.ldc = K;
+        g.a_kmajor = 1; g.b_kmajor = 1; g.alpha = 1.f; g.out_f32 = 1;
+        g.batch = layers;
+        g.batch_stride_a = layers > 1 ? ((long long)dy1 - (long long)dy0) / 2 : 0;
+        g.batch_stride_b = layers > 1 ? ((long long)x1 - (long long)x0) / 2 : 0;
+        g.batch_stride_c = layers > 1 ? (g1 - g0) : 0;
+        if (layers == 1) {
+            int sk = pick_split(N, K, M);
+            if (sk > 1) { g.split_k = sk; g.workspace = w<void>(p.slab); }
+        }
+        return vlt5_gemm_bf16(&g, st);
     }
     int record(int k) const {
         if (s.events && k >= 0 && k < s.n_events && s.events[k]) HIP_RET(hipEventRecord((hipEvent_t)s.events[k], st));
@@ -385,36 +410,29 @@ int decoder_fwd(const Ctx& k) {
     return VLT5_OK;
 }
 
-// backward of one  x_out = x_in + drop(W_o . drop(relu(W_i . LN(x_in))))  sublayer; dx is updated in place.
-// On entry `dyd` already holds bf16(dropout_out(dx)) (emitted by the producer of dx); on exit it holds the operand of
-// the sublayer processed next (dropout site `next_seed`).
-int ffn_bwd(const Ctx& k, int M, float* dx, const float* x_in, const float* rstd, const bf16_t* xn, const bf16_t* h, long long wi,
-            long long wo, long long ln, uint32_t next_seed) {
+// backward (data path only) of one  x_out = x_in + drop(W_o . drop(relu(W_i . LN(x_in))))  sublayer; dx is updated in place.
+// `dyd` holds bf16(dropout_out(dx)) on entry (emitted by the producer of dx); `dh` receives the hidden gradient; both are
+// kept for the batched weight-gradient GEMMs at the end of the phase.  `next_dst` receives the operand of the next sublayer.
+int ffn_bwd(const Ctx& k, int M, float* dx, const float* x_in, const float* rstd, const bf16_t* h, const bf16_t* dyd, bf16_t* dh,
+            long long wi, long long wo, long long ln, bf16_t* next_dst, uint32_t next_seed) {
     const Plan& p = k.p;
     const int d = k.d, ff = k.ff;
-    bf16_t* dyd = k.w<bf16_t>(p.dyd);
-    bf16_t* dh = k.w<bf16_t>(p.dh);
     float* tmp = k.w<float>(p.tmp);
-    RC(k.lin_wgrad(dyd, d, h, ff, k.Gr + wo, M, d, ff));
     const float gs = k.pdrop > 0.f ? drop_scale(drop_thr16(k.pdrop)) : 1.f;
     RC(k.lin_dgrad(dyd, k.Pb + wo, dh, M, d, ff, 0, 1.f, h, gs));
-    RC(k.lin_wgrad(dh, ff, xn, d, k.Gr + wi, M, ff, d));
     RC(k.lin_dgrad(dh, k.Pb + wi, tmp, M, ff, d, 1));
-    RC(k.ln_bwd(tmp, x_in, ln, rstd, dx, M, 1, 0.f, 0, 0, 0, true, next_seed));
+    RC(k.ln_bwd(tmp, x_in, ln, rstd, dx, M, 1, 0.f, 0, 0, 0, next_dst, next_seed));
     return VLT5_OK;
 }
 
 int decoder_bwd(const Ctx& k) {
     const Plan& p = k.p; const Layout& L = k.lay; const vlt5_config& c = k.c; const vlt5_step& s = k.s;
-    const int d = k.d, inner = k.inner, Md = p.Md, Mx = p.Mx, Sx = p.Sx, B = s.B, T = s.T, Ld = c.num_decoder_layers;
+    const int d = k.d, inner = k.inner, ff = k.ff, Md = p.Md, Mx = p.Mx, Sx = p.Sx, B = s.B, T = s.T, Ld = c.num_decoder_layers;
     const int kvw = Ld * 2 * inner;
     const float alpha = 1.0f / sqrtf((float)d);
     float* dx = k.w<float>(p.dx);
     float* tmp = k.w<float>(p.tmp);
-    bf16_t* dyd = k.w<bf16_t>(p.dyd);
     bf16_t* dctx = k.w<bf16_t>(p.dctx);
-    bf16_t* dqkv = k.w<bf16_t>(p.dqkv);
-    bf16_t* dq_c = k.w<bf16_t>(p.dq_c);
     bf16_t* dlog = k.w<bf16_t>(p.dlogits);
     const long long* ids = k.w<long long>(p.dec_ids);
     RC(vlt5_ce_bwd(k.w<float>(p.logits), s.labels, k.w<float>(p.lse_ce), s.d_loss_tok ? s.d_loss_tok : k.w<float>(p.row_w),
@@ -423,81 +441,89 @@ int decoder_bwd(const Ctx& k) {
     RC(k.lin_wgrad(dlog, c.vocab, k.w<bf16_t>(p.dec_out), d, k.Gr + L.shared, Md, c.vocab, d, alpha, 0));
     RC(k.lin_dgrad(dlog, k.Pb + L.shared, tmp, Md, c.vocab, d, 1, alpha));
     RC(k.ln_bwd(tmp, k.w<float>(p.y[3 * Ld]), L.dec_final_ln, k.w<float>(p.yr[3 * Ld]), dx, Md, 0, k.pdrop, k.seed(SITE_DEC_FINAL), 0, 0,
-                true, k.seed(SITE_DEC_BASE + (Ld - 1) * 8 + D_FFN_OUT)));
+                k.w<bf16_t>(p.d_dyd_f[Ld - 1]), k.seed(SITE_DEC_BASE + (Ld - 1) * 8 + D_FFN_OUT)));
     for (int l = Ld - 1; l >= 0; --l) {
         const auto& D = L.dec[l];
         const uint32_t sb = SITE_DEC_BASE + l * 8;
         bf16_t* qkv = k.w<bf16_t>(p.dqkv_s[l]);
         bf16_t* kv = k.w<bf16_t>(p.kv_all) + (size_t)l * 2 * inner;
         bf16_t* dkv = k.w<bf16_t>(p.dkv_all) + (size_t)l * 2 * inner;
-        RC(ffn_bwd(k, Md, dx, k.w<float>(p.y[3 * l + 2]), k.w<float>(p.yr[3 * l + 2]), k.w<bf16_t>(p.yn_f[l]), k.w<bf16_t>(p.hd[l]),
-                   D.wi, D.wo, D.ln_f, k.seed(sb + D_COUT)));
+        bf16_t* dyd_c = k.w<bf16_t>(p.d_dyd_c[l]);
+        bf16_t* dyd_s = k.w<bf16_t>(p.d_dyd_s[l]);
+        bf16_t* dq_c = k.w<bf16_t>(p.d_dq_c[l]);
+        bf16_t* dqkv = k.w<bf16_t>(p.d_dqkv[l]);
+        RC(ffn_bwd(k, Md, dx, k.w<float>(p.y[3 * l + 2]), k.w<float>(p.yr[3 * l + 2]), k.w<bf16_t>(p.hd[l]), k.w<bf16_t>(p.d_dyd_f[l]),
+                   k.w<bf16_t>(p.d_dh[l]), D.wi, D.wo, D.ln_f, dyd_c, k.seed(sb + D_COUT)));
         // cross-attention sublayer
-        RC(k.lin_wgrad(dyd, d, k.w<bf16_t>(p.ctx_c[l]), inner, k.Gr + D.co, Md, d, inner));
-        RC(k.lin_dgrad(dyd, k.Pb + D.co, dctx, Md, d, inner, 0));
+        RC(k.lin_dgrad(dyd_c, k.Pb + D.co, dctx, Md, d, inner, 0));
         RC(attn_call(k, true, k.w<bf16_t>(p.qc[l]), (long long)T * inner, inner, kv, kv + inner, (long long)Sx * kvw, kvw, nullptr,
                      k.w<float>(p.lse_c[l]), nullptr, 0, 0, k.w<float>(p.mask_ext), -1e9f, 0, T, Sx, k.seed(sb + D_CPROBS), dctx, dq_c,
                      (long long)T * inner, inner, dkv, dkv + inner, (long long)Sx * kvw, kvw, nullptr));
-        RC(k.lin_wgrad(dq_c, inner, k.w<bf16_t>(p.yn_c[l]), d, k.Gr + D.cq, Md, inner, d));
         RC(k.lin_dgrad(dq_c, k.Pb + D.cq, tmp, Md, inner, d, 1));
-        RC(k.ln_bwd(tmp, k.w<float>(p.y[3 * l + 1]), D.ln_c, k.w<float>(p.yr[3 * l + 1]), dx, Md, 1, 0.f, 0, 0, 0, true, k.seed(sb + D_SOUT)));
+        RC(k.ln_bwd(tmp, k.w<float>(p.y[3 * l + 1]), D.ln_c, k.w<float>(p.yr[3 * l + 1]), dx, Md, 1, 0.f, 0, 0, 0, dyd_s, k.seed(sb + D_SOUT)));
         // causal self-attention sublayer
-        RC(k.lin_wgrad(dyd, d, k.w<bf16_t>(p.ctx_s[l]), inner, k.Gr + D.so, Md, d, inner));
-        RC(k.lin_dgrad(dyd, k.Pb + D.so, dctx, Md, d, inner, 0));
+        RC(k.lin_dgrad(dyd_s, k.Pb + D.so, dctx, Md, d, inner, 0));
         RC(attn_call(k, true, qkv, (long long)T * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)T * 3 * inner,
                      3 * inner, nullptr, k.w<float>(p.lse_s[l]), k.w<float>(p.dec_bias), T, T, nullptr, 0.f, 1, T, T,
                      k.seed(sb + D_SPROBS), dctx, dqkv, (long long)T * 3 * inner, 3 * inner, dqkv + inner, dqkv + 2 * inner,
                      (long long)T * 3 * inner, 3 * inner, k.w<float>(p.dS_dec) + (size_t)l * B * k.H * T * T));
-        RC(k.lin_wgrad(dqkv, 3 * inner, k.w<bf16_t>(p.yn_a[l]), d, k.Gr + D.sqkv, Md, 3 * inner, d));
         RC(k.lin_dgrad(dqkv, k.Pb + D.sqkv, tmp, Md, 3 * inner, d, 1));
-        RC(k.ln_bwd(tmp, k.w<float>(p.y[3 * l]), D.ln_s, k.w<float>(p.yr[3 * l]), dx, Md, 1, 0.f, 0, 0, 0, l > 0,
-                    l > 0 ? k.seed(SITE_DEC_BASE + (l - 1) * 8 + D_FFN_OUT) : 0u));
-        if (l == 0)
-            RC(vlt5_relbias_bwd(k.w<float>(p.dS_dec), s.dec_lut, k.Gr + L.dec_rel, k.w<float>(p.rel_scratch), Ld * B, k.H, T, T,
-                                c.rel_buckets, 0, k.st));
-        RC(k.record(Ld - 1 - l));
+        RC(k.ln_bwd(tmp, k.w<float>(p.y[3 * l]), D.ln_s, k.w<float>(p.yr[3 * l]), dx, Md, 1, 0.f, 0, 0, 0,
+                    l > 0 ? k.w<bf16_t>(p.d_dyd_f[l - 1]) : nullptr, l > 0 ? k.seed(SITE_DEC_BASE + (l - 1) * 8 + D_FFN_OUT) : 0u));
     }
+    RC(vlt5_relbias_bwd(k.w<float>(p.dS_dec), s.dec_lut, k.Gr + L.dec_rel, k.w<float>(p.rel_scratch), Ld * B, k.H, T, T,
+                        c.rel_buckets, 0, k.st));
+    // weight gradients of all decoder layers, one batched GEMM per weight kind
+    const int l1 = Ld > 1 ? 1 : 0;
+    RC(k.wgrad_batched(p.d_dyd_f[0], p.d_dyd_f[l1], d, p.hd[0], p.hd[l1], ff, L.dec[0].wo, L.dec[l1].wo, Ld, Md, d, ff));
+    RC(k.wgrad_batched(p.d_dh[0], p.d_dh[l1], ff, p.yn_f[0], p.yn_f[l1], d, L.dec[0].wi, L.dec[l1].wi, Ld, Md, ff, d));
+    RC(k.wgrad_batched(p.d_dyd_c[0], p.d_dyd_c[l1], d, p.ctx_c[0], p.ctx_c[l1], inner, L.dec[0].co, L.dec[l1].co, Ld, Md, d, inner));
+    RC(k.wgrad_batched(p.d_dq_c[0], p.d_dq_c[l1], inner, p.yn_c[0], p.yn_c[l1], d, L.dec[0].cq, L.dec[l1].cq, Ld, Md, inner, d));
+    RC(k.wgrad_batched(p.d_dyd_s[0], p.d_dyd_s[l1], d, p.ctx_s[0], p.ctx_s[l1], inner, L.dec[0].so, L.dec[l1].so, Ld, Md, d, inner));
+    RC(k.wgrad_batched(p.d_dqkv[0], p.d_dqkv[l1], 3 * inner, p.yn_a[0], p.yn_a[l1], d, L.dec[0].sqkv, L.dec[l1].sqkv, Ld, Md, 3 * inner, d));
     RC(vlt5_embed_bwd(ids, dx, (long long)T * d, d, k.Gr + L.shared, B, T, d, c.vocab, k.pdrop, k.seed(SITE_DEC_EMBED), T, 0, k.st));
     // cross-attention K/V projections of all layers at once
     RC(k.lin_wgrad(k.w<bf16_t>(p.dkv_all), kvw, k.w<bf16_t>(p.enc_ext), d, k.Gr + L.cross_kv, Mx, kvw, d));
     RC(k.lin_dgrad(k.w<bf16_t>(p.dkv_all), k.Pb + L.cross_kv, k.w<void>(p.d_enc_ext), Mx, kvw, d, 1));
     RC(k.ln_flush());
-    RC(k.record(Ld));
+    for (int b = 0; b <= Ld; ++b) RC(k.record(b));          // decoder-side gradient buckets are complete
     return VLT5_OK;
 }
 
 int encoder_bwd(const Ctx& k) {
     const Plan& p = k.p; const Layout& L = k.lay; const vlt5_config& c = k.c; const vlt5_step& s = k.s;
-    const int d = k.d, inner = k.inner, M = p.M, S = p.S, Sx = p.Sx, B = s.B, Le = c.num_layers, Ld = c.num_decoder_layers;
+    const int d = k.d, inner = k.inner, ff = k.ff, M = p.M, S = p.S, Sx = p.Sx, B = s.B, Le = c.num_layers, Ld = c.num_decoder_layers;
     float* dx = k.w<float>(p.dx);
     float* tmp = k.w<float>(p.tmp);
-    bf16_t* dyd = k.w<bf16_t>(p.dyd);
     bf16_t* dctx = k.w<bf16_t>(p.dctx);
-    bf16_t* dqkv = k.w<bf16_t>(p.dqkv);
     // the 2 prototype rows of every sample are detached (src/modeling_t5_our.py:615): only rows 0..S-1 flow back
     RC(k.ln_bwd(k.w<float>(p.d_enc_ext), k.w<float>(p.x[2 * Le]), L.enc_final_ln, k.w<float>(p.xr[2 * Le]), dx, M, 0, k.pdrop,
-                k.seed(SITE_ENC_FINAL), S, Sx, true, k.seed(SITE_ENC_BASE + (Le - 1) * 8 + E_FFN_OUT)));
+                k.seed(SITE_ENC_FINAL), S, Sx, k.w<bf16_t>(p.e_dyd_f[Le - 1]), k.seed(SITE_ENC_BASE + (Le - 1) * 8 + E_FFN_OUT)));
     for (int l = Le - 1; l >= 0; --l) {
         const auto& E = L.enc[l];
         const uint32_t sb = SITE_ENC_BASE + l * 8;
         bf16_t* qkv = k.w<bf16_t>(p.qkv[l]);
-        RC(ffn_bwd(k, M, dx, k.w<float>(p.x[2 * l + 1]), k.w<float>(p.xr[2 * l + 1]), k.w<bf16_t>(p.xn_f[l]), k.w<bf16_t>(p.h[l]), E.wi,
-                   E.wo, E.ln_f, k.seed(sb + E_ATTN_OUT)));
-        RC(k.lin_wgrad(dyd, d, k.w<bf16_t>(p.ctx[l]), inner, k.Gr + E.so, M, d, inner));
-        RC(k.lin_dgrad(dyd, k.Pb + E.so, dctx, M, d, inner, 0));
+        bf16_t* dyd_a = k.w<bf16_t>(p.e_dyd_a[l]);
+        bf16_t* dqkv = k.w<bf16_t>(p.e_dqkv[l]);
+        RC(ffn_bwd(k, M, dx, k.w<float>(p.x[2 * l + 1]), k.w<float>(p.xr[2 * l + 1]), k.w<bf16_t>(p.h[l]), k.w<bf16_t>(p.e_dyd_f[l]),
+                   k.w<bf16_t>(p.e_dh[l]), E.wi, E.wo, E.ln_f, dyd_a, k.seed(sb + E_ATTN_OUT)));
+        RC(k.lin_dgrad(dyd_a, k.Pb + E.so, dctx, M, d, inner, 0));
         RC(attn_call(k, true, qkv, (long long)S * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)S * 3 * inner,
                      3 * inner, nullptr, k.w<float>(p.lse[l]), k.w<float>(p.enc_bias), s.L, s.L, k.w<float>(p.mask), -10000.f, 0, S, S,
                      k.seed(sb + E_PROBS), dctx, dqkv, (long long)S * 3 * inner, 3 * inner, dqkv + inner, dqkv + 2 * inner,
                      (long long)S * 3 * inner, 3 * inner, k.w<float>(p.dS_enc) + (size_t)l * B * k.H * s.L * s.L));
-        RC(k.lin_wgrad(dqkv, 3 * inner, k.w<bf16_t>(p.xn_a[l]), d, k.Gr + E.sqkv, M, 3 * inner, d));
         RC(k.lin_dgrad(dqkv, k.Pb + E.sqkv, tmp, M, 3 * inner, d, 1));
-        RC(k.ln_bwd(tmp, k.w<float>(p.x[2 * l]), E.ln_s, k.w<float>(p.xr[2 * l]), dx, M, 1, 0.f, 0, 0, 0, l > 0,
-                    l > 0 ? k.seed(SITE_ENC_BASE + (l - 1) * 8 + E_FFN_OUT) : 0u));
-        if (l == 0)
-            RC(vlt5_relbias_bwd(k.w<float>(p.dS_enc), s.enc_lut, k.Gr + L.enc_rel, k.w<float>(p.rel_scratch), Le * B, k.H, s.L, s.L,
-                                c.rel_buckets, 0, k.st));
-        RC(k.record(Ld + 1 + (Le - 1 - l)));
+        RC(k.ln_bwd(tmp, k.w<float>(p.x[2 * l]), E.ln_s, k.w<float>(p.xr[2 * l]), dx, M, 1, 0.f, 0, 0, 0,
+                    l > 0 ? k.w<bf16_t>(p.e_dyd_f[l - 1]) : nullptr, l > 0 ? k.seed(SITE_ENC_BASE + (l - 1) * 8 + E_FFN_OUT) : 0u));
     }
+    RC(vlt5_relbias_bwd(k.w<float>(p.dS_enc), s.enc_lut, k.Gr + L.enc_rel, k.w<float>(p.rel_scratch), Le * B, k.H, s.L, s.L,
+                        c.rel_buckets, 0, k.st));
+    // weight gradients of all encoder layers, one batched GEMM per weight kind
+    const int l1 = Le > 1 ? 1 : 0;
+    RC(k.wgrad_batched(p.e_dyd_f[0], p.e_dyd_f[l1], d, p.h[0], p.h[l1], ff, L.enc[0].wo, L.enc[l1].wo, Le, M, d, ff));
+    RC(k.wgrad_batched(p.e_dh[0], p.e_dh[l1], ff, p.xn_f[0], p.xn_f[l1], d, L.enc[0].wi, L.enc[l1].wi, Le, M, ff, d));
+    RC(k.wgrad_batched(p.e_dyd_a[0], p.e_dyd_a[l1], d, p.ctx[0], p.ctx[l1], inner, L.enc[0].so, L.enc[l1].so, Le, M, d, inner));
+    RC(k.wgrad_batched(p.e_dqkv[0], p.e_dqkv[l1], 3 * inner, p.xn_a[0], p.xn_a[l1], d, L.enc[0].sqkv, L.enc[l1].sqkv, Le, M, 3 * inner, d));
     // inputs: text rows -> shared (scatter-add), visual rows -> visual embedding parameters
     RC(vlt5_embed_bwd(s.input_ids, dx, (long long)S * d, d, k.Gr + L.shared, B, s.L, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, 0, k.st));
     float* vpart = k.w<float>(p.vis_partial);
@@ -515,7 +541,7 @@ int encoder_bwd(const Ctx& k) {
     RC(vlt5_colsum(vpart + 9 * d, k.Gr + L.vis_bf, nsp, d, 10 * d, 0, k.st));
     RC(k.lin_wgrad(k.w<bf16_t>(p.vis_dG), d, k.w<bf16_t>(p.feats_bf16), c.feat_dim, k.Gr + L.vis_wf, B * s.V, d, c.feat_dim));
     RC(k.ln_flush());
-    RC(k.record(Ld + 1 + Le));
+    for (int b = Ld + 1; b <= Ld + 1 + Le; ++b) RC(k.record(b));     // encoder-side buckets + embeddings/norms are complete
     return VLT5_OK;
 }
 

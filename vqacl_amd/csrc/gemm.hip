@@ -35,6 +35,7 @@ struct GemmArgs {
     uint32_t drop_thr, drop_seed;
     int relu, out_f32, accum;
     int ktiles_per_split; long long c_split_stride;
+    long long batch_a, batch_b, batch_c;          // element strides between batch entries (blockIdx.z)
 };
 
 constexpr int BK = 64;
@@ -171,7 +172,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const int m0 = (tile_id / gx) * BM, n0 = (tile_id % gx) * BN;
     const int nk_total = (p.K + BK - 1) / BK;
     int kt0 = 0, kt1 = nk_total;
-    char* Cbase = reinterpret_cast<char*>(p.C);
+    char* Cbase = reinterpret_cast<char*>(p.C) + (long long)blockIdx.z * p.batch_c * (p.out_f32 ? 4 : 2);
+    p.A += (long long)blockIdx.z * p.batch_a;
+    p.B += (long long)blockIdx.z * p.batch_b;
+    if (p.resid) p.resid += (long long)blockIdx.z * p.batch_c;
     if (p.ktiles_per_split > 0) {
         kt0 = blockIdx.y * p.ktiles_per_split;
         kt1 = min(nk_total, kt0 + p.ktiles_per_split);
@@ -333,8 +337,8 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
 }
 
 template <int BM, int BN>
-int launch_tile(const GemmArgs& a, int akm, int bkm, int splits, hipStream_t st) {
-    dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM), splits > 1 ? splits : 1, 1);
+int launch_tile(const GemmArgs& a, int akm, int bkm, int splits, int batch, hipStream_t st) {
+    dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM), splits > 1 ? splits : 1, batch > 1 ? batch : 1);
     size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
     if (!akm && !bkm)      hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), grid, dim3(256), lds, st, a);
     else if (!akm && bkm)  hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true>), grid, dim3(256), lds, st, a);
@@ -366,12 +370,15 @@ extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
     a.drop_thr = d->drop_p > 0.f ? drop_thr16(d->drop_p) : 0u; a.drop_seed = d->drop_seed;
     a.relu = d->relu; a.out_f32 = d->out_f32; a.accum = d->accum;
     a.ktiles_per_split = 0; a.c_split_stride = 0;
+    a.batch_a = d->batch_stride_a; a.batch_b = d->batch_stride_b; a.batch_c = d->batch_stride_c;
+    const int batch = d->batch > 1 ? d->batch : 1;
+    if (batch > 1 && (d->split_k > 1 || d->gate)) return VLT5_ERR_ARG;
 
     int bm = d->tile_m, bn = d->tile_n;
     if (bm == 0 || bn == 0) {
         // heuristic from tools/gemm_sweep.py on MI355X: the largest tile that still yields >= 3 workgroups per CU
         // (the GEMMs of this model are small: a 4480 x 768 output is 210 tiles of 128 x 128 for 256 CUs)
-        const int sk = d->split_k > 1 ? d->split_k : 1;
+        const int sk = (d->split_k > 1 ? d->split_k : 1) * batch;
         auto tiles = [&](int tm, int tn) { return (long)((d->M + tm - 1) / tm) * ((d->N + tn - 1) / tn) * sk; };
         if (tiles(128, 128) >= 768) { bm = 128; bn = 128; }
         else if (tiles(64, 128) >= 768) { bm = 64; bn = 128; }
@@ -391,10 +398,10 @@ extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
         a.accum = 0;
     }
     int rc;
-    if (bm == 128 && bn == 128) rc = launch_tile<128, 128>(a, d->a_kmajor, d->b_kmajor, splits, st);
-    else if (bm == 128 && bn == 64) rc = launch_tile<128, 64>(a, d->a_kmajor, d->b_kmajor, splits, st);
-    else if (bm == 64 && bn == 128) rc = launch_tile<64, 128>(a, d->a_kmajor, d->b_kmajor, splits, st);
-    else rc = launch_tile<64, 64>(a, d->a_kmajor, d->b_kmajor, splits, st);
+    if (bm == 128 && bn == 128) rc = launch_tile<128, 128>(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
+    else if (bm == 128 && bn == 64) rc = launch_tile<128, 64>(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
+    else if (bm == 64 && bn == 128) rc = launch_tile<64, 128>(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
+    else rc = launch_tile<64, 64>(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
     if (rc) return rc;
     if (splits > 1) {
         long long n = (long long)d->M * d->ldc;

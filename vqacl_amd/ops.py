@@ -23,7 +23,7 @@ def _need(t, dtype=None):
 
 def gemm(A, B, M, N, K, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, alpha=1.0, bias=None, relu=False,
          resid=None, gate=None, gate_scale=1.0, drop_p=0.0, drop_seed=0, accum=False, split_k=1, tile=(0, 0),
-         lda=None, ldb=None, ldc=None):
+         lda=None, ldb=None, ldc=None, batch=1, batch_strides=(0, 0, 0)):
     """C[M,N] = epi(alpha * sum_k A[m,k] B[n,k]); A,B bf16 2-D tensors, k-major flags as in vlt5_gemm_desc."""
     _need(A, BF16), _need(B, BF16)
     if out is None:
@@ -47,6 +47,8 @@ def gemm(A, B, M, N, K, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=Fal
         ws = torch.empty(lib().vlt5_gemm_workspace_bytes(M, g.ldc, split_k), device=A.device, dtype=torch.uint8)
         g.split_k, g.workspace = split_k, ptr(ws)
     g.tile_m, g.tile_n = tile
+    g.batch = batch
+    g.batch_stride_a, g.batch_stride_b, g.batch_stride_c = batch_strides
     check(lib().vlt5_gemm_bf16(C.byref(g), stream_ptr()), "vlt5_gemm_bf16")
     return out
 
