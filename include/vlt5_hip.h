@@ -163,7 +163,7 @@ int vlt5_proto_update(const float* curQ, const float* curV, const float* numQ, c
 /* cosine_similarity_multi + gather: idx[b] = argmax_c cos(tanh P_c, tanh pool_b) (first max wins);
  * the selected row is written as f32 (out_f32 + b*sb, may be NULL) and bf16 (out_bf16 + b*sb_bf16, may be NULL) */
 int vlt5_proto_retrieve(const float* protos, const float* pool, long long* idx, float* out_f32, long long sb,
-                        void* out_bf16, long long sb_bf16, int B, int C, int d, void* stream);
+                        void* out_bf16, long long sb_bf16, float* scratch /* f32 [C*d] */, int B, int C, int d, void* stream);
 /* memory_loss (nextqa/modeling_t5_nextqa.py:544-555): out[0] = mean_b ||pool_b - (onehot P)_b||^2 */
 int vlt5_proto_memory_loss(const float* pool, const float* onehot, const float* protos, float* out, int B, int C, int d, void* stream);
 

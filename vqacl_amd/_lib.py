@@ -78,7 +78,7 @@ PROTOTYPES = {
     "vlt5_proto_pool": (c_i, [vp, c_ll, c_i, c_i, c_i, c_i, vp, vp, vp]),
     "vlt5_proto_class_mean": (c_i, [vp, vp, vp, vp, c_i, c_i, c_i, vp]),
     "vlt5_proto_update": (c_i, [vp] * 9 + [c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, vp]),
-    "vlt5_proto_retrieve": (c_i, [vp, vp, vp, vp, c_ll, vp, c_ll, c_i, c_i, c_i, vp]),
+    "vlt5_proto_retrieve": (c_i, [vp, vp, vp, vp, c_ll, vp, c_ll, vp, c_i, c_i, c_i, vp]),
     "vlt5_proto_memory_loss": (c_i, [vp, vp, vp, vp, c_i, c_i, c_i, vp]),
     "vlt5_sqnorm": (c_i, [vp, c_ll, vp, vp, c_i, vp]),
     "vlt5_sqnorm_blocks": (c_i, [c_ll]),

@@ -188,7 +188,7 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     if (3 * inner * d > wmax) wmax = 3 * inner * d;
     p.slab_bytes = 8 * wmax * 4;
     p.slab = take(p.slab_bytes);
-    p.ln_partial = take((size_t)64 * 128 * d * 4);          // 64 norm slots x 128 workgroup partials
+    p.ln_partial = take((size_t)64 * 320 * d * 4);          // 64 norm slots x <= 320 workgroup partials
     p.vis_partial = take(((size_t)64 * 10 * d + 2 * (size_t)B * V) * 4);
     size_t rs = 16 * H * (size_t)(L > T ? L : T) * (L > T ? L : T) * 4;
     p.rel_scratch = take(rs);
@@ -273,7 +273,7 @@ struct Ctx {
     int ln_bwd(const float* dy, const float* x, long long w_off, const float* rstd, float* dx, int rows, int accum_dx,
                float dp, uint32_t dseed, int in_group, int in_group_stride, bf16_t* next_dst, uint32_t next_seed) const {
         if (ln_jobs >= 64) return VLT5_ERR_ARG;
-        float* part = w<float>(p.ln_partial) + (size_t)ln_jobs * 128 * d;
+        float* part = w<float>(p.ln_partial) + (size_t)ln_jobs * 320 * d;
         ln_out[ln_jobs] = w_off;
         ln_nblk[ln_jobs] = vlt5_layernorm_bwd_blocks(rows);
         ++ln_jobs;
@@ -282,7 +282,7 @@ struct Ctx {
     }
     int ln_flush() const {
         if (ln_jobs == 0) return VLT5_OK;
-        int rc = vlt5_colsum_multi(w<float>(p.ln_partial), Gr, ln_out, ln_nblk, ln_jobs, 128, d, st);
+        int rc = vlt5_colsum_multi(w<float>(p.ln_partial), Gr, ln_out, ln_nblk, ln_jobs, 320, d, st);
         ln_jobs = 0;
         return rc;
     }

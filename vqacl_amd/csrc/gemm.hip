@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;        // stage s: A tile at s*STAGE_BYTES, B tile right after it
+    constexpr int NSTAGE = (BM + BN <= 192) ? 3 : 2;      // 72 KB (2 workgroups/CU) for 64x128, 48 KB for 64x64, 64 KB for 128x128
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -208,29 +209,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         if (AKM) glds_km<BM>(p.A, p.lda, m0, kt * BK, p.M, at, tid); else glds_rm<BM>(p.A, p.lda, m0, kt * BK, p.M, at, tid);
         if (BKM) glds_km<BN>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid); else glds_rm<BN>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid);
     };
-    auto full_tile = [&](int kt) { return (kt + 1) * BK <= p.K; };
-
-    if (kt0 < kt1) {
-        if (full_tile(kt0)) {
-            glds(kt0, 0);
-        } else {
-            gload(kt0);
-            lstore(0);
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0);            // vmcnt(0): the direct-to-LDS loads have landed
-    __syncthreads();
-
-    int cur = 0;
     const int lrow = lane & 15, lg = lane >> 4;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const bool more = (kt + 1) < kt1;
-        const bool direct = more && full_tile(kt + 1);     // block-uniform
-        if (more) {
-            if (direct) glds(kt + 1, cur ^ 1);
-            else gload(kt + 1);
-        }
-        const char* at = smem + cur * STAGE_BYTES;
+    auto compute = [&](int stage) {
+        const char* at = smem + stage * STAGE_BYTES;
         const char* bt = at + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -253,10 +234,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
-        if (more && !direct) lstore(cur ^ 1);
-        __builtin_amdgcn_s_waitcnt(0);
+    };
+
+    // Main loop over the full k-tiles: NSTAGE-deep ring of LDS stages filled by direct global->LDS loads.  With 3 stages
+    // the loads of tile i+2 are issued while tile i is computed and tile i+1 is still in flight: the counted
+    // s_waitcnt vmcnt(LPT) at the top of an iteration only waits for the OLDER group, so a whole iteration of MFMAs covers
+    // the memory latency.  One raw s_barrier per k-step (it both publishes tile i and retires the reads of tile i-1, whose
+    // stage is the one refilled next).  A partial last k-tile (K % 64 != 0) goes through registers with zero fill.
+    constexpr int LPT = BM / 32 + BN / 32;                 // glds instructions per tile per wave
+    const bool has_tail = (kt1 == nk_total) && (p.K % BK != 0) && (kt1 > kt0);
+    const int nmain = (kt1 - kt0) - (has_tail ? 1 : 0);
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+        if (s0 < nmain) glds(kt0 + s0, s0);
+    int stage = 0, fill = NSTAGE - 1;                      // stage of tile i, stage that tile i+NSTAGE-1 goes to
+    for (int i = 0; i < nmain; ++i) {
+        if (NSTAGE == 3 && i + 1 < nmain) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else                               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (i + NSTAGE - 1 < nmain) glds(kt0 + i + NSTAGE - 1, fill);
+        compute(stage);
+        stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
+        fill = (fill + 1 == NSTAGE) ? 0 : fill + 1;
+    }
+    if (has_tail) {
+        gload(kt1 - 1);
+        lstore(stage);                                     // this stage was last read >= 2 barriers ago
         __syncthreads();
-        cur ^= 1;
+        compute(stage);
     }
 
     // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4 -----------
@@ -336,16 +341,28 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
     *reinterpret_cast<float4*>(out + i) = s;
 }
 
+template <int BM, int BN, bool AKM, bool BKM>
+int launch_one(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_set = false;                           // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
+    if (!attr_set) {
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AKM, BKM>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AKM, BKM>), grid, dim3(256), lds, st, a);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+
 template <int BM, int BN>
 int launch_tile(const GemmArgs& a, int akm, int bkm, int splits, int batch, hipStream_t st) {
     dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM), splits > 1 ? splits : 1, batch > 1 ? batch : 1);
-    size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
-    if (!akm && !bkm)      hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), grid, dim3(256), lds, st, a);
-    else if (!akm && bkm)  hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true>), grid, dim3(256), lds, st, a);
-    else if (akm && bkm)   hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, dim3(256), lds, st, a);
-    else                   hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false>), grid, dim3(256), lds, st, a);
-    LAUNCH_CHECK();
-    return VLT5_OK;
+    constexpr int NSTAGE = (BM + BN <= 192) ? 3 : 2;
+    size_t lds = (size_t)NSTAGE * (BM + BN) * BK * 2;
+    if (!akm && !bkm) return launch_one<BM, BN, false, false>(a, grid, lds, st);
+    if (!akm && bkm) return launch_one<BM, BN, false, true>(a, grid, lds, st);
+    if (akm && bkm) return launch_one<BM, BN, true, true>(a, grid, lds, st);
+    return launch_one<BM, BN, true, false>(a, grid, lds, st);
 }
 
 }  // namespace
@@ -376,14 +393,13 @@ extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
 
     int bm = d->tile_m, bn = d->tile_n;
     if (bm == 0 || bn == 0) {
-        // heuristic from tools/gemm_sweep.py on MI355X: the largest tile that still yields >= 3 workgroups per CU
-        // (the GEMMs of this model are small: a 4480 x 768 output is 210 tiles of 128 x 128 for 256 CUs)
+        // heuristic from tools/gemm_sweep.py on MI355X (profiles/): the GEMMs of this model are small -- a 4480 x 768
+        // output is only 210 tiles of 128 x 128 for 256 CUs
         const int sk = (d->split_k > 1 ? d->split_k : 1) * batch;
         auto tiles = [&](int tm, int tn) { return (long)((d->M + tm - 1) / tm) * ((d->N + tn - 1) / tn) * sk; };
-        if (tiles(128, 128) >= 768) { bm = 128; bn = 128; }
-        else if (tiles(64, 128) >= 768) { bm = 64; bn = 128; }
-        else if (tiles(128, 64) >= 768) { bm = 128; bn = 64; }
-        else { bm = 64; bn = 64; }
+        if (tiles(128, 128) >= 768) { bm = 128; bn = 128; }            // >= 3 workgroups per CU of the big tile
+        else if (tiles(64, 128) >= 256) { bm = 64; bn = 128; }         // 3-stage ring, 2 workgroups per CU
+        else { bm = 64; bn = 64; }                                     // small-M (decoder) problems: most workgroups
     }
     if (!((bm == 128 || bm == 64) && (bn == 128 || bn == 64))) return VLT5_ERR_ARG;
 
@@ -418,7 +434,7 @@ extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
 extern "C" int vlt5_gemm_auto_split(int M, int N, int Kred, long long slab_bytes) {
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
     const int ksteps = (Kred + 63) / 64;
-    if (Kred < 1024 || tiles >= 256) return 1;
+    if (Kred < 1024 || tiles >= 128) return 1;
     int sk = (int)((512 + tiles / 2) / tiles);
     if (sk > 8) sk = 8;
     if (sk > ksteps / 4) sk = ksteps / 4;

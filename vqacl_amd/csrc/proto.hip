@@ -20,16 +20,23 @@ __global__ void pool_kernel(const float* __restrict__ hidden, long long sb, int 
     }
 }
 
-__global__ void class_mean_kernel(const float* __restrict__ pool, const float* __restrict__ onehot, float* __restrict__ proto,
-                                  float* __restrict__ cnt, int B, int C, int d) {
+// one block per class; the (few) members of the class are listed in LDS first so the column loop only visits them
+__global__ __launch_bounds__(256) void class_mean_kernel(const float* __restrict__ pool, const float* __restrict__ onehot,
+                                                         float* __restrict__ proto, float* __restrict__ cnt, int B, int C, int d) {
+    extern __shared__ float wgt[];                 // [B] one-hot column of this class
     const int cls = blockIdx.x;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) wgt[b] = onehot[(size_t)b * C + cls];
+    __syncthreads();
     float n = 0.f;
-    for (int b = 0; b < B; ++b) n += onehot[(size_t)b * C + cls];
+    for (int b = 0; b < B; ++b) n += wgt[b];
     if (threadIdx.x == 0) cnt[cls] = n;
     const float div = n <= 0.f ? 1.f : n;
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += onehot[(size_t)b * C + cls] * pool[(size_t)b * d + c];
+        for (int b = 0; b < B; ++b) {
+            const float w = wgt[b];
+            if (w != 0.f) s += w * pool[(size_t)b * d + c];
+        }
         proto[(size_t)cls * d + c] = s / div;
     }
 }
@@ -59,34 +66,44 @@ __global__ void proto_update_kernel(const float* __restrict__ curQ, const float*
     if (i < CV) Vnum[i] = first ? numV[i] : Vnum[i] + numV[i];
 }
 
-// one block per sample: cosine similarity against every prototype, first-max argmax, gather
-__global__ __launch_bounds__(256) void retrieve_kernel(const float* __restrict__ protos, const float* __restrict__ pool,
-                                                       long long* __restrict__ idx, float* __restrict__ out_f32, long long sb,
-                                                       bf16_t* __restrict__ out_bf16, long long sb16, int B, int C, int d) {
-    extern __shared__ float sim[];                         // [C]
-    __shared__ float nb_sh;
+// tanh-normalised prototypes, computed once per call: An[c] = tanh(P_c) / max(||tanh(P_c)||, 1e-12)
+__global__ __launch_bounds__(256) void proto_normalize_kernel(const float* __restrict__ protos, float* __restrict__ An, int C, int d) {
+    __shared__ float sh[4];
+    const int cls = blockIdx.x;
+    const float* pr = protos + (size_t)cls * d;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < d; c += 256) { float t = tanhf(pr[c]); s += t * t; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float inv = 1.0f / fmaxf(sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3])), 1e-12f);
+    for (int c = threadIdx.x; c < d; c += 256) An[(size_t)cls * d + c] = tanhf(pr[c]) * inv;
+}
+
+// one block per sample: cosine similarity against every (pre-normalised) prototype, first-max argmax, gather
+__global__ __launch_bounds__(256) void retrieve_kernel(const float* __restrict__ protos, const float* __restrict__ An,
+                                                       const float* __restrict__ pool, long long* __restrict__ idx,
+                                                       float* __restrict__ out_f32, long long sb, bf16_t* __restrict__ out_bf16,
+                                                       long long sb16, int B, int C, int d) {
+    extern __shared__ float lds[];                         // [d] tanh(x) then [C] similarities
+    float* tx = lds;
+    float* sim = lds + d;
+    __shared__ float part[4];
     __shared__ int best_sh;
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* x = pool + (size_t)b * d;
-    if (wave == 0) {
-        float s = 0.f;
-        for (int c = lane; c < d; c += 64) { float t = tanhf(x[c]); s += t * t; }
-        s = wave_sum(s);
-        if (lane == 0) nb_sh = fmaxf(sqrtf(s), 1e-12f);
-    }
+    float s = 0.f;
+    for (int c = threadIdx.x; c < d; c += 256) { float t = tanhf(x[c]); tx[c] = t; s += t * t; }
+    s = wave_sum(s);
+    if (lane == 0) part[wave] = s;
     __syncthreads();
-    const float nb = nb_sh;
+    const float nb = fmaxf(sqrtf((part[0] + part[1]) + (part[2] + part[3])), 1e-12f);
     for (int cls = wave; cls < C; cls += 4) {
-        const float* pr = protos + (size_t)cls * d;
-        float dot = 0.f, na = 0.f;
-        for (int c = lane; c < d; c += 64) {
-            float ta = tanhf(pr[c]), tb = tanhf(x[c]);
-            dot += ta * tb;
-            na += ta * ta;
-        }
+        const float* a = An + (size_t)cls * d;
+        float dot = 0.f;
+        for (int c = lane; c < d; c += 64) dot += a[c] * tx[c];
         dot = wave_sum(dot);
-        na = wave_sum(na);
-        if (lane == 0) sim[cls] = dot / (fmaxf(sqrtf(na), 1e-12f) * nb);
+        if (lane == 0) sim[cls] = dot / nb;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -137,7 +154,7 @@ extern "C" int vlt5_proto_pool(const float* hidden, long long sb, int B, int S, 
 extern "C" int vlt5_proto_class_mean(const float* pool, const float* onehot, float* proto, float* cnt, int B, int C, int d,
                                      void* stream) {
     if (!pool || !onehot || !proto || !cnt || B <= 0 || C <= 0) return VLT5_ERR_ARG;
-    hipLaunchKernelGGL(class_mean_kernel, dim3(C), dim3(256), 0, ST, pool, onehot, proto, cnt, B, C, d);
+    hipLaunchKernelGGL(class_mean_kernel, dim3(C), dim3(256), B * sizeof(float), ST, pool, onehot, proto, cnt, B, C, d);
     LAUNCH_CHECK();
     return VLT5_OK;
 }
@@ -154,9 +171,11 @@ extern "C" int vlt5_proto_update(const float* curQ, const float* curV, const flo
     return VLT5_OK;
 }
 extern "C" int vlt5_proto_retrieve(const float* protos, const float* pool, long long* idx, float* out_f32, long long sb,
-                                   void* out_bf16, long long sb_bf16, int B, int C, int d, void* stream) {
-    if (!protos || !pool || !idx || B <= 0 || C <= 0) return VLT5_ERR_ARG;
-    hipLaunchKernelGGL(retrieve_kernel, dim3(B), dim3(256), C * sizeof(float), ST, protos, pool, idx, out_f32, sb,
+                                   void* out_bf16, long long sb_bf16, float* scratch, int B, int C, int d, void* stream) {
+    if (!protos || !pool || !idx || !scratch || B <= 0 || C <= 0) return VLT5_ERR_ARG;
+    hipLaunchKernelGGL(proto_normalize_kernel, dim3(C), dim3(256), 0, ST, protos, scratch, C, d);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(retrieve_kernel, dim3(B), dim3(256), (d + C) * sizeof(float), ST, protos, scratch, pool, idx, out_f32, sb,
                        (bf16_t*)out_bf16, sb_bf16, B, C, d);
     LAUNCH_CHECK();
     return VLT5_OK;

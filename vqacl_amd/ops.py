@@ -204,8 +204,9 @@ def proto_class_mean(pool, onehot):
 def proto_retrieve(protos, pool, out_f32=None, sb=0, out_bf16=None, sb_bf16=0):
     B, d = pool.shape
     idx = torch.empty(B, device=pool.device, dtype=torch.int64)
+    scratch = torch.empty(protos.shape[0], d, device=pool.device, dtype=torch.float32)
     check(lib().vlt5_proto_retrieve(ptr(_need(protos, torch.float32)), ptr(pool), ptr(idx), ptr(out_f32), sb, ptr(out_bf16), sb_bf16,
-                                    B, protos.shape[0], d, stream_ptr()), "vlt5_proto_retrieve")
+                                    ptr(scratch), B, protos.shape[0], d, stream_ptr()), "vlt5_proto_retrieve")
     return idx
 
 
