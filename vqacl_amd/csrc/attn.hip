@@ -3,13 +3,14 @@
 //   P = softmax(Q K^T + bias + key-mask + causal-mask)   (no 1/sqrt(d): T5)      [fp32]
 //   ctx = dropout(P) V
 //
-// Everything of one (b,h) lives on chip: Q, K, V^T tiles in LDS (the whole K/V of a head is
+// Everything of one (b,h) lives on chip: Q, K, V tiles in LDS (the whole K/V of a head is
 // 2 x 64 x 64 bf16 = 16 KB), scores and probabilities in registers.  Four waves, wave w owns query
 // rows 16w..16w+15.  MFMAs are issued with swapped operands (keys as the A operand, queries as B)
 // so a lane holds S[i = lane&15][j = 16*jb + 4*(lane>>4) + r]: a score row is spread over only
 // 4 lanes -> the softmax reductions are 15 in-lane ops + 2 wave shuffles, and the probabilities are
 // already in the B-operand layout of the P.V MFMA (the key "slots" of lane group g are
-// {32kk + 4g .. +3, 32kk + 16 + 4g .. +3}; V^T is read with the same slot pattern), so P never
+// {32kk + 4g .. +3, 32kk + 16 + 4g .. +3}; V^T is gathered with that slot pattern from the natural V tile by the
+// transpose read ds_read_b64_tr_b16), so P never
 // leaves registers.  The backward recomputes P from the saved row log-sum-exp and regenerates the
 // dropout mask from the counter-based hash.
 #include "common.h"
@@ -35,34 +36,43 @@ struct AttnArgs {
     float* dbias;
 };
 
-// stage a [T x dk] bf16 matrix (row stride st) into a natural [64][TS] tile and/or a transposed [64 d][TS] tile
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, long long st, int T, int dk, bf16_t* nat,
-                                           bf16_t* tr, int tid) {
+// stage a [T x dk] bf16 matrix (row stride st) into a natural [64][TS] LDS tile (zero filled outside T x dk)
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, long long st, int T, int dk, bf16_t* nat, int tid) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         int c = tid + it * 256;
         int row = c >> 3, dc = c & 7;
         uint4 z = make_uint4(0, 0, 0, 0);
         if (row < T && dc * 8 < dk) z = *reinterpret_cast<const uint4*>(src + (long long)row * st + dc * 8);
-        if (nat) *reinterpret_cast<uint4*>(nat + row * TS + dc * 8) = z;
-        if (tr) {
-            uint32_t w[4] = {z.x, z.y, z.z, z.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) tr[(dc * 8 + e) * TS + row] = (bf16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-        }
+        *reinterpret_cast<uint4*>(nat + row * TS + dc * 8) = z;
     }
 }
 
-__device__ __forceinline__ bf16x8_t lds_frag(const bf16_t* tile, int row, int chunk) {     // 8 consecutive elements
+__device__ __forceinline__ bf16x8_t lds_frag(const bf16_t* tile, int row, int chunk) {     // 8 consecutive elements of a row
     return *reinterpret_cast<const bf16x8_t*>(tile + row * TS + chunk * 8);
 }
-// transposed-operand fragment with the "P slot" pattern: 4 elements at col0 and 4 at col0+16
-__device__ __forceinline__ bf16x8_t lds_frag_slots(const bf16_t* tile, int row, int col0) {
-    uint2 a = *reinterpret_cast<const uint2*>(tile + row * TS + col0);
-    uint2 b = *reinterpret_cast<const uint2*>(tile + row * TS + col0 + 16);
-    union { uint32_t u[4]; bf16x8_t v; } r;
-    r.u[0] = a.x; r.u[1] = a.y; r.u[2] = b.x; r.u[3] = b.y;
-    return r.v;
+// Transposed fragments straight from a NATURAL tile T[k][r] with the gfx950 transpose read (ds_read_b64_tr_b16): within a
+// 16-lane group, lane i points at T[k0 + (i>>2)][r0 + 4*(i&3)] and receives T[k0 .. k0+3][r0 + i].
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ s16x4_t tr4(const bf16_t* tile, int k0, int r0, int lane) {
+    const int i = lane & 15;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(tile + (k0 + (i >> 2)) * TS + r0 + 4 * (i & 3)));
+}
+__device__ __forceinline__ bf16x8_t join8(s16x4_t lo, s16x4_t hi) {
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+// rows r0..r0+15 of T^T, k-slots in the "P slot" pattern of lane group g: {32kk+4g .. +3, 32kk+16+4g .. +3}
+__device__ __forceinline__ bf16x8_t frag_tr_slots(const bf16_t* tile, int r0, int kk, int lane) {
+    const int g = lane >> 4;
+    return join8(tr4(tile, kk * 32 + 4 * g, r0, lane), tr4(tile, kk * 32 + 16 + 4 * g, r0, lane));
+}
+// rows r0..r0+15 of T^T, k = 32*ks + 8g .. +7 (the standard MFMA operand order)
+__device__ __forceinline__ bf16x8_t frag_tr_std(const bf16_t* tile, int r0, int ks, int lane) {
+    const int g = lane >> 4;
+    return join8(tr4(tile, ks * 32 + 8 * g, r0, lane), tr4(tile, ks * 32 + 8 * g + 4, r0, lane));
 }
 __device__ __forceinline__ bf16x8_t pack_slots(const float (&lo)[4], const float (&hi)[4]) {
     union { uint32_t u[4]; bf16x8_t v; } r;
@@ -120,12 +130,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + TILE_BYTES);
-    bf16_t* Vt = reinterpret_cast<bf16_t*>(smem + 2 * TILE_BYTES);
+    bf16_t* Vs = reinterpret_cast<bf16_t*>(smem + 2 * TILE_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
-    stage_tile(p.q + b * p.q_sb + (long long)h * p.dk, p.q_st, p.Tq, p.dk, Qs, nullptr, tid);
-    stage_tile(p.k + b * p.k_sb + (long long)h * p.dk, p.k_st, p.Tk, p.dk, Ks, nullptr, tid);
-    stage_tile(p.v + b * p.v_sb + (long long)h * p.dk, p.v_st, p.Tk, p.dk, nullptr, Vt, tid);
+    stage_tile(p.q + b * p.q_sb + (long long)h * p.dk, p.q_st, p.Tq, p.dk, Qs, tid);
+    stage_tile(p.k + b * p.k_sb + (long long)h * p.dk, p.k_st, p.Tk, p.dk, Ks, tid);
+    stage_tile(p.v + b * p.v_sb + (long long)h * p.dk, p.v_st, p.Tk, p.dk, Vs, tid);
     __syncthreads();
     const int i0 = wave * 16;
     if (i0 >= p.Tq) return;
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             if (kk * 32 < p.Tk) {
-                bf16x8_t fv = lds_frag_slots(Vt, db * 16 + lr, kk * 32 + g * 4);
+                bf16x8_t fv = frag_tr_slots(Vs, db * 16, kk, lane);        // V^T[d][j] gathered from the natural V tile
                 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[kk], o, 0, 0, 0);
             }
         }
@@ -187,18 +197,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + TILE_BYTES);
     bf16_t* Vs = reinterpret_cast<bf16_t*>(smem + 2 * TILE_BYTES);
     bf16_t* dOs = reinterpret_cast<bf16_t*>(smem + 3 * TILE_BYTES);
-    bf16_t* Qt = reinterpret_cast<bf16_t*>(smem + 4 * TILE_BYTES);
-    bf16_t* Kt = reinterpret_cast<bf16_t*>(smem + 5 * TILE_BYTES);
-    bf16_t* dOt = reinterpret_cast<bf16_t*>(smem + 6 * TILE_BYTES);
-    bf16_t* Pt = Vs;      // [j][i], reuses the V tile after phase A
-    bf16_t* dSt = dOs;    // [j][i], reuses the dO tile after phase A
+    bf16_t* Ps = Ks;      // Pd[i][j] (natural), reuses the K tile after phase A
+    bf16_t* dSs = Vs;     // dS[i][j] (natural), reuses the V tile after phase A
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const long long hoff = (long long)h * p.dk;
-    stage_tile(p.q + b * p.q_sb + hoff, p.q_st, p.Tq, p.dk, Qs, Qt, tid);
-    stage_tile(p.k + b * p.k_sb + hoff, p.k_st, p.Tk, p.dk, Ks, Kt, tid);
-    stage_tile(p.v + b * p.v_sb + hoff, p.v_st, p.Tk, p.dk, Vs, nullptr, tid);
-    stage_tile(p.d_ctx + b * p.do_sb + hoff, p.do_st, p.Tq, p.dk, dOs, dOt, tid);
+    stage_tile(p.q + b * p.q_sb + hoff, p.q_st, p.Tq, p.dk, Qs, tid);
+    stage_tile(p.k + b * p.k_sb + hoff, p.k_st, p.Tk, p.dk, Ks, tid);
+    stage_tile(p.v + b * p.v_sb + hoff, p.v_st, p.Tk, p.dk, Vs, tid);
+    stage_tile(p.d_ctx + b * p.do_sb + hoff, p.do_st, p.Tq, p.dk, dOs, tid);
     __syncthreads();
 
     const int i0 = wave * 16;
@@ -257,14 +264,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
                 if (p.dbias && i < p.bias_q && j < p.bias_k && i < p.Tq && j < p.Tk)
                     p.dbias[(((size_t)b * p.H + h) * p.bias_q + i) * p.bias_k + j] = ds[jb][r];
             }
-        // dQ[i][d] = sum_j dS[i][j] K[j][d]
+        // dQ[i][d] = sum_j dS[i][j] K[j][d]   (K^T gathered from the natural K tile with transpose reads)
         bf16x8_t dsf[2] = {pack_slots(ds[0], ds[1]), pack_slots(ds[2], ds[3])};
         for (int db = 0; db < ndb; ++db) {
             f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 if (kk * 32 < p.Tk) {
-                    bf16x8_t fk = lds_frag_slots(Kt, db * 16 + lr, kk * 32 + g * 4);
+                    bf16x8_t fk = frag_tr_slots(Ks, db * 16, kk, lane);
                     o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, dsf[kk], o, 0, 0, 0);
                 }
             }
@@ -277,17 +284,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
             }
         }
     }
-    __syncthreads();                     // every wave is done with Vs / dOs -> reuse them as Pt / dSt
+    __syncthreads();                     // every wave is done with the K / V tiles -> reuse them for Pd / dS
+    // natural [i][j] layout: 4 consecutive j per (lane, jb) -> one 8-byte store each
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = jb * 16 + g * 4 + r;
-            Pt[j * TS + i] = f32_to_bf16(pd[jb][r]);
-            dSt[j * TS + i] = f32_to_bf16(ds[jb][r]);
-        }
+    for (int jb = 0; jb < 4; ++jb) {
+        uint2 a, c;
+        a.x = pack_bf16x2(pd[jb][0], pd[jb][1]); a.y = pack_bf16x2(pd[jb][2], pd[jb][3]);
+        c.x = pack_bf16x2(ds[jb][0], ds[jb][1]); c.y = pack_bf16x2(ds[jb][2], ds[jb][3]);
+        *reinterpret_cast<uint2*>(Ps + i * TS + jb * 16 + g * 4) = a;
+        *reinterpret_cast<uint2*>(dSs + i * TS + jb * 16 + g * 4) = c;
+    }
     __syncthreads();
-    // phase B: wave w owns key rows 16w..16w+15;  dV = Pd^T dO,  dK = dS^T Q  (reduction over the queries)
+    // phase B: wave w owns key rows 16w..16w+15;  dV = Pd^T dO,  dK = dS^T Q  (reduction over the queries i);
+    // all four operands are transposed views of natural tiles -> ds_read_b64_tr_b16
     const int j0 = wave * 16;
     if (j0 >= p.Tk) return;
     const int j = j0 + lr;
@@ -295,10 +304,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
     for (int db = 0; db < ndb; ++db) {
         f32x4_t av = (f32x4_t){0.f, 0.f, 0.f, 0.f}, ak = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         for (int ks = 0; ks < nis; ++ks) {
-            bf16x8_t fp = lds_frag(Pt, j0 + lr, ks * 4 + g);
-            bf16x8_t fs = lds_frag(dSt, j0 + lr, ks * 4 + g);
-            bf16x8_t fo = lds_frag(dOt, db * 16 + lr, ks * 4 + g);
-            bf16x8_t fq = lds_frag(Qt, db * 16 + lr, ks * 4 + g);
+            bf16x8_t fp = frag_tr_std(Ps, j0, ks, lane);          // Pd^T[j][i]
+            bf16x8_t fs = frag_tr_std(dSs, j0, ks, lane);         // dS^T[j][i]
+            bf16x8_t fo = frag_tr_std(dOs, db * 16, ks, lane);    // dO^T[d][i]
+            bf16x8_t fq = frag_tr_std(Qs, db * 16, ks, lane);     // Q^T[d][i]
             av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo, fp, av, 0, 0, 0);
             ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, fs, ak, 0, 0, 0);
         }
@@ -357,7 +366,7 @@ extern "C" int vlt5_attn_bwd(const vlt5_attn_desc* d, void* stream) {
     AttnArgs a;
     int rc = fill_args(d, a, true);
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.B * a.H), dim3(256), 7 * TILE_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.B * a.H), dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return VLT5_OK;
 }
