@@ -374,3 +374,34 @@ def test_data_parallel_overlap_path_on_one_gpu_and_rank_equivalence(dev):
     half = 0.5 * (grads_of(slice(0, 4)) + grads_of(slice(4, 8)))
     assert cos(full, half) > 0.9995
     assert abs(float(half.norm() / full.norm()) - 1.0) < 1e-2
+
+
+@pytest.mark.parametrize("name,kw,B,L,V,T", [
+    ("nextqa-16clips", dict(), 3, 23, 16, 6),            # BASELINE config 4 as the reference ships it (16 clips, L<=23, T<=6)
+    ("nextqa-32frames", dict(), 3, 23, 32, 6),           # BASELINE config 4 as BASELINE.json words it
+    ("t5-large", dict(d_model=1024, num_heads=16, d_ff=4096, num_layers=24, num_decoder_layers=24), 2, 20, 36, 5),   # config 5
+])
+def test_other_baseline_configs_vs_oracle(dev, name, kw, B, L, V, T):
+    """Shape variants of the same kernels: NExT-QA (8 question types, boxes all (0,0,1,1)) and VL-T5-large (the reference
+    itself would crash there: it hard-codes 768, SURVEY 0.8 -- the oracle generalises d_model)."""
+    from oracle import ref_cpu as R
+    torch.set_num_threads(8)
+    ocfg = R.Cfg(dropout=0.0, n_ques=8 if name.startswith("nextqa") else 10, **kw)
+    params = R.init_params(ocfg, seed=321)
+    batch = R.synthetic_batch(ocfg, B=B, L=L, V=V, T=T, seed=99, task_id=0)
+    if name.startswith("nextqa"):
+        batch["boxes"] = torch.tensor([0.0, 0.0, 1.0, 1.0]).expand(B, V, 4).contiguous()
+    model = make_model(ocfg, params, dev)
+    model.train()
+    oracle = R.OracleModel(ocfg, params)
+    o = oracle.train_step(batch, 0, 0.5, 0.3, training=True)
+    o["loss"].backward()
+    res = model.train_step(batch, 0, 0.5, 0.3)
+    res["loss"].backward()
+    logits = model._ws_view(model.cfg.c_struct(), (B, L, V, T), 2, torch.float32, (B, T, ocfg.vocab_size))
+    e = rel_max_err(logits, o["logits"])
+    print(name, "logits rel max err", e, "loss", float(res["loss"]), float(o["loss"]))
+    assert e < 4e-2
+    assert abs(float(res["loss"]) - float(o["loss"])) < 3e-2
+    worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()}, min_cos=0.95)
+    print(name, "worst gradient cosine:", worst)

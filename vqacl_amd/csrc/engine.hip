@@ -272,7 +272,7 @@ struct Ctx {
     // slot `ln_jobs`; ln_flush() reduces all slots of the phase with one launch.
     int ln_bwd(const float* dy, const float* x, long long w_off, const float* rstd, float* dx, int rows, int accum_dx,
                float dp, uint32_t dseed, int in_group, int in_group_stride, bf16_t* next_dst, uint32_t next_seed) const {
-        if (ln_jobs >= 64) return VLT5_ERR_ARG;
+        if (ln_jobs >= 64) { int rc = ln_flush(); if (rc) return rc; }     // deep stacks (t5-large: 73 norms per phase)
         float* part = w<float>(p.ln_partial) + (size_t)ln_jobs * 320 * d;
         ln_out[ln_jobs] = w_off;
         ln_nblk[ln_jobs] = vlt5_layernorm_bwd_blocks(rows);
