@@ -490,6 +490,19 @@ int decoder_bwd(const Ctx& k) {
     return VLT5_OK;
 }
 
+// weight gradients of encoder layers [lo, hi): one batched GEMM per weight kind (grid.z = layer)
+int enc_wgrads(const Ctx& k, int lo, int hi) {
+    const Plan& p = k.p; const Layout& L = k.lay;
+    const int n = hi - lo, d = k.d, inner = k.inner, ff = k.ff, M = p.M;
+    if (n <= 0) return VLT5_OK;
+    const int l1 = n > 1 ? lo + 1 : lo;
+    RC(k.wgrad_batched(p.e_dyd_f[lo], p.e_dyd_f[l1], d, p.h[lo], p.h[l1], ff, L.enc[lo].wo, L.enc[l1].wo, n, M, d, ff));
+    RC(k.wgrad_batched(p.e_dh[lo], p.e_dh[l1], ff, p.xn_f[lo], p.xn_f[l1], d, L.enc[lo].wi, L.enc[l1].wi, n, M, ff, d));
+    RC(k.wgrad_batched(p.e_dyd_a[lo], p.e_dyd_a[l1], d, p.ctx[lo], p.ctx[l1], inner, L.enc[lo].so, L.enc[l1].so, n, M, d, inner));
+    RC(k.wgrad_batched(p.e_dqkv[lo], p.e_dqkv[l1], 3 * inner, p.xn_a[lo], p.xn_a[l1], d, L.enc[lo].sqkv, L.enc[l1].sqkv, n, M, 3 * inner, d));
+    return VLT5_OK;
+}
+
 int encoder_bwd(const Ctx& k) {
     const Plan& p = k.p; const Layout& L = k.lay; const vlt5_config& c = k.c; const vlt5_step& s = k.s;
     const int d = k.d, inner = k.inner, ff = k.ff, M = p.M, S = p.S, Sx = p.Sx, B = s.B, Le = c.num_layers, Ld = c.num_decoder_layers;
@@ -515,15 +528,16 @@ int encoder_bwd(const Ctx& k) {
         RC(k.lin_dgrad(dqkv, k.Pb + E.sqkv, tmp, M, 3 * inner, d, 1));
         RC(k.ln_bwd(tmp, k.w<float>(p.x[2 * l]), E.ln_s, k.w<float>(p.xr[2 * l]), dx, M, 1, 0.f, 0, 0, 0,
                     l > 0 ? k.w<bf16_t>(p.e_dyd_f[l - 1]) : nullptr, l > 0 ? k.seed(SITE_ENC_BASE + (l - 1) * 8 + E_FFN_OUT) : 0u));
+        if (Le > 1 && l == Le / 2) {
+            // upper half of the stack: its weight gradients are complete early, so a data-parallel all-reduce of these
+            // buckets overlaps with the backward of the lower half
+            RC(enc_wgrads(k, Le / 2, Le));
+            for (int b = Ld + 1; b <= Ld + 1 + (Le - 1 - l); ++b) RC(k.record(b));
+        }
     }
     RC(vlt5_relbias_bwd(k.w<float>(p.dS_enc), s.enc_lut, k.Gr + L.enc_rel, k.w<float>(p.rel_scratch), Le * B, k.H, s.L, s.L,
                         c.rel_buckets, 0, k.st));
-    // weight gradients of all encoder layers, one batched GEMM per weight kind
-    const int l1 = Le > 1 ? 1 : 0;
-    RC(k.wgrad_batched(p.e_dyd_f[0], p.e_dyd_f[l1], d, p.h[0], p.h[l1], ff, L.enc[0].wo, L.enc[l1].wo, Le, M, d, ff));
-    RC(k.wgrad_batched(p.e_dh[0], p.e_dh[l1], ff, p.xn_f[0], p.xn_f[l1], d, L.enc[0].wi, L.enc[l1].wi, Le, M, ff, d));
-    RC(k.wgrad_batched(p.e_dyd_a[0], p.e_dyd_a[l1], d, p.ctx[0], p.ctx[l1], inner, L.enc[0].so, L.enc[l1].so, Le, M, d, inner));
-    RC(k.wgrad_batched(p.e_dqkv[0], p.e_dqkv[l1], 3 * inner, p.xn_a[0], p.xn_a[l1], d, L.enc[0].sqkv, L.enc[l1].sqkv, Le, M, 3 * inner, d));
+    RC(enc_wgrads(k, 0, Le > 1 ? Le / 2 : Le));          // lower half of the stack (the upper half was flushed mid-way)
     // inputs: text rows -> shared (scatter-add), visual rows -> visual embedding parameters
     RC(vlt5_embed_bwd(s.input_ids, dx, (long long)S * d, d, k.Gr + L.shared, B, s.L, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, 0, k.st));
     float* vpart = k.w<float>(p.vis_partial);
@@ -541,7 +555,7 @@ int encoder_bwd(const Ctx& k) {
     RC(vlt5_colsum(vpart + 9 * d, k.Gr + L.vis_bf, nsp, d, 10 * d, 0, k.st));
     RC(k.lin_wgrad(k.w<bf16_t>(p.vis_dG), d, k.w<bf16_t>(p.feats_bf16), c.feat_dim, k.Gr + L.vis_wf, B * s.V, d, c.feat_dim));
     RC(k.ln_flush());
-    for (int b = Ld + 1; b <= Ld + 1 + Le; ++b) RC(k.record(b));     // encoder-side buckets + embeddings/norms are complete
+    for (int b = Ld + 1 + (Le > 1 ? Le - Le / 2 : 0); b <= Ld + 1 + Le; ++b) RC(k.record(b));     // lower half + embeddings/norms
     return VLT5_OK;
 }
 

@@ -377,7 +377,7 @@ class VLT5(nn.Module):
     # ------------------------------------------------------------------ forward ----------------------
     def forward(self, input_ids=None, vis_inputs=None, labels=None, decoder_input_ids=None, cate_labels=None,
                 ques_labels=None, proto_update=False, memory=False, current_task_id=0, proto_alpha=0.5, proto_beta=0.3,
-                return_dict=True, reduce_loss=False, scores=None, **kwargs):
+                return_dict=True, reduce_loss=False, scores=None, _reuse_encoder=False, **kwargs):
         """Same keyword surface as the reference `VLT5.forward` (modeling_t5_our.py:514-713).  `scores` (optional,
         ours) fuses the train_step reduction of vqa_model.py:46-54 into the engine: the output then also carries the
         reduced scalar under 'loss_reduced'."""
@@ -406,19 +406,25 @@ class VLT5(nn.Module):
         c = self.cfg.c_struct()
         cs = self._make_step(st)
         stream = stream_ptr()
-        check(lib().vlt5_encoder_fwd(C.byref(c), C.byref(cs), stream), "vlt5_encoder_fwd")
         enc_f32 = self._ws_view(c, dims, L.WS_ENC_OUT, torch.float32, (B, Sx, d))
         enc_b16 = self._ws_view(c, dims, L.WS_ENC_EXT, torch.bfloat16, (B, Sx, d))
-        # SS/SI prototype head (modeling_t5_our.py:583-615)
-        poolQ, poolV = ops.proto_pool(enc_f32, S, self.L)
         loss_mem_Q = loss_mem_V = 0
-        if proto_update:
-            ql = ques_labels.to(dev, torch.float32).contiguous()
-            cl = cate_labels.to(dev, torch.float32).contiguous()
-            if memory:
-                loss_mem_Q, loss_mem_V = self.proto.memory_loss(poolQ, poolV, ql, cl)
-            self.proto.update(poolQ, poolV, ql, cl, int(current_task_id), float(proto_alpha), float(proto_beta))
-        idxQ, idxV = self.proto.retrieve(poolQ, poolV, enc_f32, enc_b16, S)
+        if _reuse_encoder:
+            # greedy decoding: the encoder output (and the retrieved prototype rows) of this batch are still in the workspace;
+            # the encoder-side layout of the arena does not depend on T (tests/test_host_cpu.py)
+            idxQ, idxV = self._cached_idx
+        else:
+            check(lib().vlt5_encoder_fwd(C.byref(c), C.byref(cs), stream), "vlt5_encoder_fwd")
+            # SS/SI prototype head (modeling_t5_our.py:583-615)
+            poolQ, poolV = ops.proto_pool(enc_f32, S, self.L)
+            if proto_update:
+                ql = ques_labels.to(dev, torch.float32).contiguous()
+                cl = cate_labels.to(dev, torch.float32).contiguous()
+                if memory:
+                    loss_mem_Q, loss_mem_V = self.proto.memory_loss(poolQ, poolV, ql, cl)
+                self.proto.update(poolQ, poolV, ql, cl, int(current_task_id), float(proto_alpha), float(proto_beta))
+            idxQ, idxV = self.proto.retrieve(poolQ, poolV, enc_f32, enc_b16, S)
+            self._cached_idx = (idxQ, idxV)
         check(lib().vlt5_decoder_fwd(C.byref(c), C.byref(cs), stream), "vlt5_decoder_fwd")
         st["loss_tok"] = self._ws_view(c, dims, L.WS_LOSS_TOK, torch.float32, (B * T,))
         st["loss"] = self._ws_view(c, dims, L.WS_LOSS, torch.float32, (1,))[0]

@@ -45,7 +45,8 @@ class VLT5VQA(VLT5):
     @torch.no_grad()
     def test_step(self, batch, **kwargs):
         """Greedy decoding (the reference forwards no generation kwargs, so `--num_beams` is ignored: vqa_model.py:112-116).
-        Teacher-forced re-decoding of the growing prefix through the training kernels: O(T^2) decoder work, T <= 20."""
+        The encoder and the prototype retrieval run once; each step re-decodes the growing prefix through the training
+        decoder kernels (O(T^2) decoder work, T <= 20, no KV cache yet)."""
         self.eval()
         token_ids = self.greedy_generate(batch["input_ids"], (batch["vis_feats"], batch["boxes"]),
                                          max_length=kwargs.get("max_length", 20))
@@ -61,10 +62,14 @@ class VLT5VQA(VLT5):
         pad, start = self.cfg.pad_token_id, self.cfg.decoder_start_token_id
         tokens = torch.full((B, 1), start, dtype=torch.long, device=device)
         done = torch.zeros(B, dtype=torch.bool, device=device)
-        for _ in range(max_length - 1):
+        input_ids = input_ids.to(device)
+        vis_inputs = (vis_inputs[0].to(device), vis_inputs[1].to(device))
+        self._workspace(B, input_ids.shape[1], vis_inputs[0].shape[1], max_length)    # size the arena once for the longest prefix
+        for step in range(max_length - 1):
             # labels whose shift-right equals the current prefix: prefix[1:] followed by one dummy position
             labels = torch.cat([tokens[:, 1:], torch.full((B, 1), pad, dtype=torch.long, device=device)], dim=1)
-            out = self(input_ids=input_ids, vis_inputs=vis_inputs, labels=labels, proto_update=False)
+            # the encoder runs once; later steps only re-run the decoder on the grown prefix
+            out = self(input_ids=input_ids, vis_inputs=vis_inputs, labels=labels, proto_update=False, _reuse_encoder=step > 0)
             nxt = out["logits"][:, -1, :].argmax(dim=-1)
             nxt = torch.where(done, torch.full_like(nxt, pad), nxt)
             tokens = torch.cat([tokens, nxt[:, None]], dim=1)
