@@ -131,7 +131,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("VQACL_FORCE_DIST") == "1"     # the env switch exercises the RCCL path on 1 GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if distributed:
@@ -193,7 +193,7 @@ def main():
            "samples_per_sec_per_gpu": round(value / world, 2), "final_loss": round(final_loss, 4),
            "step_tflops_per_gpu": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms, 2),
            "step_frac_of_mfma_peak": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not distributed:
         # PCIe-inclusive rate (never `value`): the boundary normally hands over pinned HOST tensors (collate_fn output);
         # train_step then copies 23.6 MB of fp32 region features per batch of 80 before the engine starts.
         host = {k: v.cpu().pin_memory() for k, v in batch.items()}
@@ -212,7 +212,7 @@ def main():
             step_host()
         torch.cuda.synchronize()
         out["samples_per_sec_pcie_inclusive"] = round(5 * B / (time.perf_counter() - t1), 2)
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and world == 1 and not distributed and not args.no_roofline:
         rows = time_gemms(cfg, B, L, V, T, dev)
         launches = sum(r["count"] for r in rows)
         tot_ms = sum(r["count"] * r["ms"] for r in rows)
@@ -234,7 +234,7 @@ def main():
         worst = sorted(rows, key=lambda r: -r["count"] * r["ms"])[:6]
         out["roofline"]["top_shapes"] = [dict(M=r["M"], N=r["N"], K=r["K"], akm=r["akm"], bkm=r["bkm"], count=r["count"], batch=r["batch"],
                                               us=round(r["ms"] * 1e3, 1), tflops=round(r["gflop"] / r["ms"], 1)) for r in worst]
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not distributed and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out))

@@ -18,17 +18,25 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (row >= rows) return;
     const float* xr = x + (size_t)row * d;
     float ss = 0.f;
-    for (int c = lane * 4; c < d; c += 256) {
-        float4 v = *reinterpret_cast<const float4*>(xr + c);
-        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    float4 xv[8];                                   // this lane's slice of the row (d <= 2048), read from HBM once
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int c = lane * 4 + k * 256;
+        if (c < d) {
+            xv[k] = *reinterpret_cast<const float4*>(xr + c);
+            ss += xv[k].x * xv[k].x + xv[k].y * xv[k].y + xv[k].z * xv[k].z + xv[k].w * xv[k].w;
+        }
     }
     ss = wave_sum(ss);
     const float rs = rsqrtf(ss / (float)d + eps);
     if (lane == 0 && rstd_out) rstd_out[row] = rs;
     const int orow = remap_row(row, group, gstride);
     const float dsc = drop_scale(thr);
-    for (int c = lane * 4; c < d; c += 256) {
-        float4 v = *reinterpret_cast<const float4*>(xr + c);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = lane * 4 + k * 256;
+        if (c >= d) continue;
+        float4 v = xv[k];
         float4 g = *reinterpret_cast<const float4*>(w + c);
         float o[4] = {g.x * (v.x * rs), g.y * (v.y * rs), g.z * (v.z * rs), g.w * (v.w * rs)};
         if (thr) {
@@ -46,9 +54,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-constexpr int LN_MAXCH = 8;   // d <= 2048
+constexpr int LN_MAXCH_MAX = 8;   // d <= 2048 (4 chunks of 256 columns per lane suffice for d <= 1024: fewer registers)
 
 // grid-stride over rows; each wave keeps dw partials for its columns, block-reduced through LDS
+template <int LN_MAXCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ rstd,
                                                      float* __restrict__ dx, float* __restrict__ dwp, int rows, int d,
@@ -61,27 +70,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int k = 0; k < LN_MAXCH; ++k) dwacc[k] = make_float4(0, 0, 0, 0);
     const float dsc = drop_scale(thr);
     const float inv_d = 1.0f / (float)d;
+    // the norm weight is the same for every row: keep this lane's columns in registers
+    float4 wreg[LN_MAXCH];
+#pragma unroll
+    for (int k = 0; k < LN_MAXCH; ++k) {
+        int c = lane * 4 + k * 256;
+        wreg[k] = (c < d) ? *reinterpret_cast<const float4*>(w + c) : make_float4(0, 0, 0, 0);
+    }
+    const float dsc2 = drop_scale(thr2);
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float* xr = x + (size_t)row * d;
         const float* gr = dy + (size_t)remap_row(row, group, gstride) * d;
         const float rs = rstd[row];
+        // single pass over HBM: this lane's slice of the row (x and the masked upstream gradient) stays in registers
+        float4 xv[LN_MAXCH], gv[LN_MAXCH];
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < LN_MAXCH; ++k) {
             int c = lane * 4 + k * 256;
             if (c < d) {
-                float4 xv = *reinterpret_cast<const float4*>(xr + c);
-                float4 gv = *reinterpret_cast<const float4*>(gr + c);
-                float4 wv = *reinterpret_cast<const float4*>(w + c);
-                float g[4] = {gv.x, gv.y, gv.z, gv.w};
+                xv[k] = *reinterpret_cast<const float4*>(xr + c);
+                float4 t = *reinterpret_cast<const float4*>(gr + c);
                 if (thr) {
                     uint32_t idx = (uint32_t)row * (uint32_t)d + (uint32_t)c;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g[q] = drop_keep(seed, idx + q, thr) ? g[q] * dsc : 0.f;
+                    t.x = drop_keep(seed, idx, thr) ? t.x * dsc : 0.f;
+                    t.y = drop_keep(seed, idx + 1, thr) ? t.y * dsc : 0.f;
+                    t.z = drop_keep(seed, idx + 2, thr) ? t.z * dsc : 0.f;
+                    t.w = drop_keep(seed, idx + 3, thr) ? t.w * dsc : 0.f;
                 }
-                s += g[0] * wv.x * xv.x + g[1] * wv.y * xv.y + g[2] * wv.z * xv.z + g[3] * wv.w * xv.w;
-                dwacc[k].x += g[0] * xv.x * rs; dwacc[k].y += g[1] * xv.y * rs;
-                dwacc[k].z += g[2] * xv.z * rs; dwacc[k].w += g[3] * xv.w * rs;
+                gv[k] = t;
+                s += t.x * wreg[k].x * xv[k].x + t.y * wreg[k].y * xv[k].y + t.z * wreg[k].z * xv[k].z + t.w * wreg[k].w * xv[k].w;
+                dwacc[k].x += t.x * xv[k].x * rs; dwacc[k].y += t.y * xv[k].y * rs;
+                dwacc[k].z += t.z * xv[k].z * rs; dwacc[k].w += t.w * xv[k].w * rs;
             }
         }
         s = wave_sum(s);
@@ -90,18 +110,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         for (int k = 0; k < LN_MAXCH; ++k) {
             int c = lane * 4 + k * 256;
             if (c < d) {
-                float4 xv = *reinterpret_cast<const float4*>(xr + c);
-                float4 gv = *reinterpret_cast<const float4*>(gr + c);
-                float4 wv = *reinterpret_cast<const float4*>(w + c);
-                float g[4] = {gv.x, gv.y, gv.z, gv.w};
-                if (thr) {
-                    uint32_t idx = (uint32_t)row * (uint32_t)d + (uint32_t)c;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g[q] = drop_keep(seed, idx + q, thr) ? g[q] * dsc : 0.f;
-                }
                 float4 o;
-                o.x = rs * g[0] * wv.x - xv.x * coef; o.y = rs * g[1] * wv.y - xv.y * coef;
-                o.z = rs * g[2] * wv.z - xv.z * coef; o.w = rs * g[3] * wv.w - xv.w * coef;
+                o.x = rs * gv[k].x * wreg[k].x - xv[k].x * coef; o.y = rs * gv[k].y * wreg[k].y - xv[k].y * coef;
+                o.z = rs * gv[k].z * wreg[k].z - xv[k].z * coef; o.w = rs * gv[k].w * wreg[k].w - xv[k].w * coef;
                 float* dp = dx + (size_t)row * d + c;
                 if (accum_dx) {
                     float4 q = *reinterpret_cast<const float4*>(dp);
@@ -111,7 +122,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 if (dxb) {                      // bf16(dropout(dx)) = the A operand of the next sublayer's backward GEMMs
                     float q[4] = {o.x, o.y, o.z, o.w};
                     if (thr2) {
-                        const float dsc2 = drop_scale(thr2);
                         uint32_t idx = (uint32_t)row * (uint32_t)d + (uint32_t)c;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) q[e] = drop_keep(seed2, idx + e, thr2) ? q[e] * dsc2 : 0.f;
@@ -178,7 +188,7 @@ extern "C" int vlt5_layernorm_fwd(const float* x, const float* w, void* y_bf16, 
                                   float eps, float drop_p, uint32_t drop_seed, int out_group, int out_group_stride,
                                   void* stream) {
     if (!x || !w || (!y_bf16 && !y_f32) || rows <= 0 || d <= 0) return VLT5_ERR_ARG;
-    if (d & 3) return VLT5_ERR_ALIGN;
+    if ((d & 3) || d > 2048) return VLT5_ERR_ALIGN;
     uint32_t thr = drop_p > 0.f ? drop_thr16(drop_p) : 0u;
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16_t*)y_bf16, y_f32,
                        rstd, rows, d, eps, thr, drop_seed, out_group, out_group_stride);
@@ -191,13 +201,18 @@ extern "C" int vlt5_layernorm_bwd(const float* dy, const float* x, const float* 
                                   uint32_t drop_seed, int in_group, int in_group_stride, void* dx_bf16, float dx_drop_p,
                                   uint32_t dx_drop_seed, void* stream) {
     if (!dy || !x || !w || !rstd || !dx || !dw_partial || rows <= 0) return VLT5_ERR_ARG;
-    if ((d & 3) || d > 256 * LN_MAXCH) return VLT5_ERR_ALIGN;
+    if ((d & 3) || d > 256 * LN_MAXCH_MAX) return VLT5_ERR_ALIGN;
     uint32_t thr = drop_p > 0.f ? drop_thr16(drop_p) : 0u;
     uint32_t thr2 = dx_drop_p > 0.f ? drop_thr16(dx_drop_p) : 0u;
     int nblk = vlt5_layernorm_bwd_blocks(rows);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 4 * d * sizeof(float), (hipStream_t)stream, dy, x, w, rstd, dx,
-                       dw_partial, rows, d, accum_dx, thr, drop_seed, in_group, in_group_stride, (bf16_t*)dx_bf16, thr2,
-                       dx_drop_seed);
+    if (d <= 1024)
+        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(256), 4 * d * sizeof(float), (hipStream_t)stream, dy, x, w, rstd, dx,
+                           dw_partial, rows, d, accum_dx, thr, drop_seed, in_group, in_group_stride, (bf16_t*)dx_bf16, thr2,
+                           dx_drop_seed);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<8>, dim3(nblk), dim3(256), 4 * d * sizeof(float), (hipStream_t)stream, dy, x, w, rstd, dx,
+                           dw_partial, rows, d, accum_dx, thr, drop_seed, in_group, in_group_stride, (bf16_t*)dx_bf16, thr2,
+                           dx_drop_seed);
     LAUNCH_CHECK();
     if (dw) {
         hipLaunchKernelGGL(colsum_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)stream, dw_partial, dw, nblk, d, d,
