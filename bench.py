@@ -225,12 +225,15 @@ def main():
                            "gflop_per_launch": round(tot_gflop / launches, 3), "gemm_ms_per_step": round(tot_ms, 3)}
         # HBM traffic of the same kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
         # separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md): launch-weighted bytes per launch
-        pmc = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")
-        if os.path.exists(pmc):
-            g = [r for r in json.load(open(pmc)) if "gemm_kernel" in r["kernel"]]
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
+        if pmcs:
+            g = [r for r in json.load(open(pmcs[-1])) if "gemm_kernel" in r["kernel"]]
             if g:
                 out["roofline"]["traffic"] = round(sum(r["calls"] * r["hbm_mb"] for r in g) / sum(r["calls"] for r in g) * 1e6)
-                out["roofline"]["traffic_unit"] = "bytes/launch (PMC, profiles/r01_c_pmc_hbm_traffic.txt)"
+                out["roofline"]["traffic_unit"] = f"bytes/launch (PMC, profiles/{os.path.basename(pmcs[-1])})"
+                out["roofline"]["algorithmic_bytes_per_launch"] = round(sum(
+                    r["count"] * r["batch"] * 2 * (r["M"] * r["K"] + r["N"] * r["K"] + r["M"] * r["N"] * (2 if r["akm"] else 1)) for r in rows) / launches)
         worst = sorted(rows, key=lambda r: -r["count"] * r["ms"])[:6]
         out["roofline"]["top_shapes"] = [dict(M=r["M"], N=r["N"], K=r["K"], akm=r["akm"], bkm=r["bkm"], count=r["count"], batch=r["batch"],
                                               us=round(r["ms"] * 1e3, 1), tflops=round(r["gflop"] / r["ms"], 1)) for r in worst]
