@@ -405,3 +405,46 @@ def test_other_baseline_configs_vs_oracle(dev, name, kw, B, L, V, T):
     assert abs(float(res["loss"]) - float(o["loss"])) < 3e-2
     worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()}, min_cos=0.95)
     print(name, "worst gradient cosine:", worst)
+
+
+def test_loss_curve_tracks_oracle_over_a_dual_level_schedule(dev):
+    """20 optimizer steps of the Trainer's inner loop (vqacl.py:364-373): current-task batch then rehearsal batch, task switch
+    0 -> 1 half way (new optimizer per group, vqacl.py:329), dropout off: the engine's loss curve must track the oracle's."""
+    from oracle import ref_cpu as R
+    from vqacl_amd import FusedAdamW, reference_param_groups
+    ocfg = R.tiny_cfg()
+    params = R.init_params(ocfg, seed=55)
+    oracle = R.OracleModel(ocfg, params)
+    model = make_model(ocfg, params, dev)
+    model.train()
+    cur = {0: R.synthetic_batch(ocfg, B=8, L=12, V=36, T=4, seed=100, task_id=0),
+           1: R.synthetic_batch(ocfg, B=8, L=14, V=36, T=5, seed=101, task_id=1)}
+    mem = R.synthetic_batch(ocfg, B=8, L=12, V=36, T=4, seed=102, task_id=0)       # rehearsal samples of task 0
+    ref, got = [], []
+    for task in (0, 1):
+        oopt = R.HFAdamW(oracle.used, lr=2e-3, eps=1e-6, weight_decay=0.01)
+        opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=2e-3, eps=1e-6, max_grad_norm=5.0)
+        for it in range(5):
+            for batch in ([cur[task]] if task == 0 else [cur[task], mem]):
+                oracle.zero_grad()
+                o = oracle.train_step(batch, task, 0.5, 0.3)
+                o["loss"].backward()
+                R.clip_grad_norm(list(oracle.used.values()), 5.0)
+                oopt.step()
+                ref.append(float(o["loss"]))
+                res = model.train_step(batch, task, 0.5, 0.3)
+                res["loss"].backward()
+                opt.step()
+                for p in model.parameters():
+                    p.grad = None
+                got.append(float(res["loss"].detach()))
+    print("oracle", [round(x, 3) for x in ref])
+    print("engine", [round(x, 3) for x in got])
+    assert len(ref) == 15
+    for a, b in zip(got, ref):
+        assert abs(a - b) < 0.08, (got, ref)
+    assert got[4] < got[0] and got[-1] < got[5]
+    # after 15 bf16-vs-fp32 optimizer steps the weights have drifted a little: compare the prototypes norm-wise
+    for mine, ref_p in ((model.Q_prototype, oracle.state.Q_prototype), (model.V_prototype, oracle.state.V_prototype)):
+        fro = float((mine.cpu() - ref_p).norm() / ref_p.norm())
+        assert fro < 5e-2, fro
