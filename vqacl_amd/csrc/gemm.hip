@@ -22,6 +22,7 @@
 // fp32 output.  Split-K (grid.z) writes fp32 slabs that vlt5_reduce_slabs sums in a fixed order.
 #include "common.h"
 #include "vlt5_hip.h"
+#include <type_traits>
 
 namespace {
 
@@ -272,79 +273,146 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     // cost per launch before this change).
     const float dscale = drop_scale(p.drop_thr);
     const bool aux_f32 = (p.resid != nullptr) || p.accum;             // block-uniform
-    float4 aux[FM][FN];
-    float4 bs[FN];
+    if (!p.bias && !p.relu && !p.gate && !p.drop_thr && !aux_f32) {
+        // plain epilogue (QKV / cross-K/V / lm_head projections, every dgrad without gate, every weight gradient): straight-line
+        // scale + pack + store; keeps ~100 option-testing instructions per fragment off the tail of ~70 % of the launches
+        const int nb = n0 + wn * (BN / 2) + lg * 4;
+        if (p.out_f32) {
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
-        bs[j] = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * (BM / 2) + i * 16 + lrow;
+                if (m >= p.M) continue;
+                float* crow = reinterpret_cast<float*>(Cbase) + (size_t)m * p.ldc + nb;
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * (BM / 2) + i * 16 + lrow;
+                for (int j = 0; j < FN; ++j)
+                    if (nb + j * 16 < p.N)
+                        *reinterpret_cast<float4*>(crow + j * 16) = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha,
+                                                                                acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < p.M && n < p.N) {
-                if (aux_f32) {
-                    if (p.resid) t = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
-                    if (p.accum) {
-                        float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Cbase) + (size_t)m * p.ldc + n);
-                        t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * (BM / 2) + i * 16 + lrow;
+                if (m >= p.M) continue;
+                bf16_t* crow = reinterpret_cast<bf16_t*>(Cbase) + (size_t)m * p.ldc + nb;
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    if (nb + j * 16 < p.N) {
+                        uint2 o;
+                        o.x = pack_bf16x2(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha);
+                        o.y = pack_bf16x2(acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
+                        *reinterpret_cast<uint2*>(crow + j * 16) = o;
                     }
-                } else if (p.gate) {
-                    uint2 g2 = *reinterpret_cast<const uint2*>(p.gate + (size_t)m * p.ldg + n);
-                    t.x = __uint_as_float(g2.x); t.y = __uint_as_float(g2.y);
-                }
             }
-            aux[i][j] = t;
         }
+        return;
     }
-    // one explicit vmcnt(0) that EVERY path passes (the loads above sit in divergent branches; without it the compiler
-    // re-waits conservatively before each fragment's first use, i.e. between the stores)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // Fused epilogues.  The option set is block-uniform; the combinations the engine issues are compiled as straight-line
+    // specialisations (generic lambda + integral constants), everything else takes the fully generic instance.
+    const bool drop = p.drop_thr != 0, gate = p.gate != nullptr, bias = p.bias != nullptr, relu = p.relu != 0, f32 = p.out_f32 != 0;
+    auto run = [&](auto c_bias, auto c_relu, auto c_gate, auto c_drop, auto c_aux, auto c_f32, auto c_generic) {
+        constexpr bool kBias = decltype(c_bias)::value, kRelu = decltype(c_relu)::value, kGate = decltype(c_gate)::value;
+        constexpr bool kDrop = decltype(c_drop)::value, kAux = decltype(c_aux)::value, kF32 = decltype(c_f32)::value;
+        constexpr bool kGen = decltype(c_generic)::value;      // generic instance: a compiled-in option is still tested at run time
+        const bool do_bias = kBias && (!kGen || bias), do_relu = kRelu && (!kGen || relu), do_drop = kDrop && (!kGen || drop);
+        const bool do_aux = kAux && (!kGen || aux_f32);
+        float4 aux[FM][FN];
+        float4 bs[FN];
+        if constexpr (kBias) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * (BM / 2) + i * 16 + lrow;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
-            v[0] += bs[j].x; v[1] += bs[j].y; v[2] += bs[j].z; v[3] += bs[j].w;
-            if (p.relu) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (p.gate) {
-                uint32_t gw[2] = {__float_as_uint(aux[i][j].x), __float_as_uint(aux[i][j].y)};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    bf16_t h = (bf16_t)((gw[r >> 1] >> ((r & 1) * 16)) & 0xffffu);
-                    v[r] = (bf16_to_f32(h) > 0.f) ? v[r] * p.gate_scale : 0.f;
-                }
-            }
-            if (p.drop_thr) {
-                uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = drop_keep(p.drop_seed, idx + r, p.drop_thr) ? v[r] * dscale : 0.f;
-            }
-            if (aux_f32) { v[0] += aux[i][j].x; v[1] += aux[i][j].y; v[2] += aux[i][j].z; v[3] += aux[i][j].w; }
-            if (p.out_f32) {
-                float* c = reinterpret_cast<float*>(Cbase) + (size_t)m * p.ldc + n;
-                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                bf16_t* c = reinterpret_cast<bf16_t*>(Cbase) + (size_t)m * p.ldc + n;
-                uint2 o;
-                o.x = pack_bf16x2(v[0], v[1]);
-                o.y = pack_bf16x2(v[2], v[3]);
-                *reinterpret_cast<uint2*>(c) = o;
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
+                bs[j] = (do_bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+        if constexpr (kAux || kGate) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * (BM / 2) + i * 16 + lrow;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m < p.M && n < p.N && (do_aux || kGate)) {
+                        if constexpr (kAux) {
+                            if (p.resid) t = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
+                            if (p.accum) {
+                                float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Cbase) + (size_t)m * p.ldc + n);
+                                t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+                            }
+                        } else {
+                            uint2 g2 = *reinterpret_cast<const uint2*>(p.gate + (size_t)m * p.ldg + n);
+                            t.x = __uint_as_float(g2.x); t.y = __uint_as_float(g2.y);
+                        }
+                    }
+                    aux[i][j] = t;
+                }
+            }
+        }
+        // one explicit vmcnt(0) that EVERY path passes: the loads above sit in divergent branches, and a conservative re-wait
+        // before each fragment would land between the stores (vmcnt counts stores too on CDNA)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + lrow;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+                if constexpr (kBias) { v[0] += bs[j].x; v[1] += bs[j].y; v[2] += bs[j].z; v[3] += bs[j].w; }
+                if constexpr (kRelu) {
+                    if (do_relu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                }
+                if constexpr (kGate) {
+                    uint32_t gw[2] = {__float_as_uint(aux[i][j].x), __float_as_uint(aux[i][j].y)};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        bf16_t h = (bf16_t)((gw[r >> 1] >> ((r & 1) * 16)) & 0xffffu);
+                        v[r] = (bf16_to_f32(h) > 0.f) ? v[r] * p.gate_scale : 0.f;
+                    }
+                }
+                if constexpr (kDrop) {
+                    if (do_drop) {
+                        uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = drop_keep(p.drop_seed, idx + r, p.drop_thr) ? v[r] * dscale : 0.f;
+                    }
+                }
+                if constexpr (kAux) { v[0] += aux[i][j].x; v[1] += aux[i][j].y; v[2] += aux[i][j].z; v[3] += aux[i][j].w; }
+                if constexpr (kF32) {
+                    float* c = reinterpret_cast<float*>(Cbase) + (size_t)m * p.ldc + n;
+                    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    bf16_t* c = reinterpret_cast<bf16_t*>(Cbase) + (size_t)m * p.ldc + n;
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(c) = o;
+                }
+            }
+        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (aux_f32 && !gate && !bias && !relu && f32) {                 // residual GEMMs (attention O, FFN wo), accumulate
+        if (drop) run(F{}, F{}, F{}, T{}, T{}, T{}, F{}); else run(F{}, F{}, F{}, F{}, T{}, T{}, F{});
+    } else if (relu && !aux_f32 && !gate && !bias && !f32) {         // FFN wi: ReLU (+dropout) -> bf16
+        if (drop) run(F{}, T{}, F{}, T{}, F{}, F{}, F{}); else run(F{}, T{}, F{}, F{}, F{}, F{}, F{});
+    } else if (gate && !aux_f32 && !bias && !relu && !drop && !f32) {   // FFN hidden gradient, gated by the saved activation
+        run(F{}, F{}, T{}, F{}, F{}, F{}, F{});
+    } else if (bias && !aux_f32 && !gate && !relu && !drop && f32) {    // visual projection
+        run(T{}, F{}, F{}, F{}, F{}, T{}, F{});
+    } else if (gate) {                                                // anything else: options tested at run time
+        if (f32) run(T{}, T{}, T{}, T{}, F{}, T{}, T{}); else run(T{}, T{}, T{}, T{}, F{}, F{}, T{});
+    } else {
+        if (f32) run(T{}, T{}, F{}, T{}, T{}, T{}, T{}); else run(T{}, T{}, F{}, T{}, T{}, F{}, T{});
     }
 }
 
