@@ -49,7 +49,7 @@ def close_norm(a, b, rel_fro, rel_max, what=""):
 # ---------------------------------------------------------------------------------------------------------------
 # GEMM
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [(0, 0), (128, 128), (128, 64), (64, 128), (64, 64)])
+@pytest.mark.parametrize("tile", [(0, 0), (256, 256), (128, 128), (128, 64), (64, 128), (64, 64)])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (400, 768, 768), (20, 64, 64), (4480, 768, 768), (136, 2304, 200)])
 def test_gemm_forward_layout(dev, tile, M, N, K):
     from vqacl_amd import ops
@@ -64,7 +64,7 @@ def test_gemm_forward_layout(dev, tile, M, N, K):
     close(outb, ref, 1e-2, 5e-2, "gemm NT bf16")
 
 
-@pytest.mark.parametrize("tile", [(128, 128), (64, 64), (0, 0)])
+@pytest.mark.parametrize("tile", [(256, 256), (128, 128), (64, 64), (0, 0)])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 256), (400, 768, 2304), (4480, 768, 3072), (24, 64, 128)])
 def test_gemm_dgrad_layout(dev, tile, M, N, K):
     """dX[M,N] = dY[M,K] W[K,N]: the weight is read k-major."""
@@ -77,7 +77,7 @@ def test_gemm_dgrad_layout(dev, tile, M, N, K):
     close(out, ref, 2e-3, 3e-2, "gemm dgrad")
 
 
-@pytest.mark.parametrize("tile", [(128, 128), (64, 64), (0, 0)])
+@pytest.mark.parametrize("tile", [(256, 256), (128, 128), (64, 64), (0, 0)])
 @pytest.mark.parametrize("rows,N,K", [(256, 128, 64), (400, 768, 768), (4480, 768, 768), (20, 64, 128), (2880, 768, 2048)])
 def test_gemm_wgrad_layout(dev, tile, rows, N, K):
     """dW[N,K] = dY[rows,N]^T X[rows,K]: both operands read k-major, reduction over the rows."""
@@ -97,20 +97,27 @@ def test_gemm_wgrad_layout(dev, tile, rows, N, K):
         close(out3, ref + 1.0, 3e-3, 0.15, "gemm wgrad split-k accumulate")
 
 
-def test_gemm_epilogues(dev):
+@pytest.mark.parametrize("tile,M,N,K", [((0, 0), 200, 192, 128), ((256, 256), 600, 520, 192), ((128, 128), 300, 264, 64)])
+def test_gemm_epilogues(dev, tile, M, N, K):
     from vqacl_amd import ops
     g = torch.Generator().manual_seed(5)
-    M, N, K = 200, 192, 128
     A, B = rnd((M, K), g).to(BF), rnd((N, K), g).to(BF)
     bias, resid = rnd((N,), g), rnd((M, N), g)
     base = A.float() @ B.float().t()
-    out = ops.gemm(A.to(dev), B.to(dev), M, N, K, out_f32=True, alpha=0.5, bias=bias.to(dev), relu=True, resid=resid.to(dev))
+    out = ops.gemm(A.to(dev), B.to(dev), M, N, K, out_f32=True, alpha=0.5, bias=bias.to(dev), relu=True, resid=resid.to(dev), tile=tile)
     close(out, torch.relu(0.5 * base + bias) + resid, 2e-3, 2e-2, "alpha+bias+relu+resid")
     gate = rnd((M, N), g).to(BF)
-    out = ops.gemm(A.to(dev), B.to(dev), M, N, K, out_f32=True, gate=gate.to(dev), gate_scale=1.25)
+    out = ops.gemm(A.to(dev), B.to(dev), M, N, K, out_f32=True, gate=gate.to(dev), gate_scale=1.25, tile=tile)
+    outb = ops.gemm(A.to(dev), B.to(dev), M, N, K, gate=gate.to(dev), gate_scale=1.25, tile=tile)
+    close(outb, torch.where(gate.float() > 0, base * 1.25, torch.zeros_like(base)), 1e-2, 5e-2, "gate bf16")
+    outr = ops.gemm(A.to(dev), B.to(dev), M, N, K, relu=True, drop_p=0.0, tile=tile)
+    close(outr, torch.relu(base), 1e-2, 5e-2, "relu bf16")
+    outd = ops.gemm(A.to(dev), B.to(dev), M, N, K, out_f32=True, resid=resid.to(dev), drop_p=0.25, drop_seed=7, tile=tile)
+    ref_d = ops.gemm(A.to(dev), B.to(dev), M, N, K, out_f32=True, drop_p=0.25, drop_seed=7, tile=(64, 64))
+    close(outd, ref_d.cpu() + resid, 2e-3, 2e-2, "dropout then residual (mask independent of the tiling)")
     close(out, torch.where(gate.float() > 0, base * 1.25, torch.zeros_like(base)), 2e-3, 2e-2, "gate")
     acc = torch.full((M, N), 2.0, device=dev)
-    out = ops.gemm(A.to(dev), B.to(dev), M, N, K, out=acc, accum=True)
+    out = ops.gemm(A.to(dev), B.to(dev), M, N, K, out=acc, accum=True, tile=tile)
     close(out, base + 2.0, 2e-3, 2e-2, "accumulate")
 
 

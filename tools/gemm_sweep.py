@@ -24,8 +24,34 @@ def timed(fn, reps=8):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+def timed_graph(fn, reps=20):
+    """Same, but the launches are replayed from a HIP graph: no host launch cost between kernels (small GEMMs take less
+    GPU time than one ctypes call)."""
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(reps):
+                fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        g.replay()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / (3 * reps) * 1e3
+
+
 def main():
     B = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 80
+    auto_only = "--auto-only" in sys.argv            # only the heuristic's choice (for A/B runs of kernel variants)
+    torch_ref = "--torch-ref" in sys.argv            # also time torch.matmul (hipBLASLt/rocBLAS) on the same operands
+    tm = timed_graph if "--graph" in sys.argv else timed
     dev = torch.device("cuda")
     cfg = VLT5Config()
     BF = torch.bfloat16
@@ -41,14 +67,19 @@ def main():
         Bm = torch.randn((K, N) if bkm else (N, K), device=dev).to(BF)
         out = torch.empty(M, N, device=dev, dtype=torch.float32 if of32 else BF)
         row = dict(M=M, N=N, K=K, akm=akm, bkm=bkm, count=count, gflop=2.0 * M * N * K / 1e9, t={})
-        for tile in ((0, 0), (128, 128), (128, 64), (64, 128), (64, 64)):
+        for tile in (((0, 0),) if auto_only else ((0, 0), (256, 256), (128, 128), (128, 64), (64, 128), (64, 64))):
             splits = (1, 2, 4, 8) if (akm and bkm and of32 and M * N % 1 == 0 and K >= 1024) else (1,)
             for sk in splits:
                 if sk > 1 and tile == (0, 0):
                     continue
-                us = timed(lambda: ops.gemm(A, Bm, M, N, K, a_kmajor=bool(akm), b_kmajor=bool(bkm), out=out, tile=tile, split_k=sk))
+                us = tm(lambda: ops.gemm(A, Bm, M, N, K, a_kmajor=bool(akm), b_kmajor=bool(bkm), out=out, tile=tile, split_k=sk))
                 row["t"][f"{tile[0]}x{tile[1]}/sk{sk}"] = round(us, 1)
-        best = min((v, k) for k, v in row["t"].items() if not k.startswith("0x0"))
+        best = min((v, k) for k, v in row["t"].items() if auto_only or not k.startswith("0x0"))
+        if torch_ref:
+            At = A.t() if akm else A                                      # logical [M,K]
+            Bt = Bm if bkm else Bm.t()                                    # logical [K,N]
+            o2 = torch.empty(M, N, device=dev, dtype=BF)
+            row["t"]["torch"] = round(tm(lambda: torch.matmul(At, Bt, out=o2)), 1)
         row["best"] = best[1]
         row["best_us"] = best[0]
         row["best_tflops"] = round(row["gflop"] / best[0] * 1e3, 1)

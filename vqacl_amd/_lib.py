@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime the library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvlt5_hip.so")
+LIB_PATH = os.environ.get("VLT5_LIB") or os.path.join(_HERE, "libvlt5_hip.so")   # VLT5_LIB: A/B runs of kernel variants
 
 c_f = C.c_float
 c_i = C.c_int

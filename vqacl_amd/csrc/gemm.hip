@@ -24,6 +24,22 @@
 #include "vlt5_hip.h"
 #include <type_traits>
 
+// Optional per-workgroup timeline (debug builds only, -DGEMM_TIMELINE): wave 0 of every workgroup records the shader
+// clock at fixed points and writes 8 x u64 per workgroup to the buffer registered with vlt5dbg_set_timeline().
+#ifdef GEMM_TIMELINE
+__device__ unsigned long long* g_timeline = nullptr;
+#define TL_DECL unsigned long long tlv[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TL(i) do { if (threadIdx.x == 0) tlv[i] = __builtin_readcyclecounter(); } while (0)
+#define TL_FLUSH() do { if (threadIdx.x == 0 && g_timeline) { \
+        tlv[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 20); \
+        unsigned long long* o = g_timeline + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8; \
+        for (int q = 0; q < 8; ++q) o[q] = tlv[q]; } } while (0)
+#else
+#define TL_DECL
+#define TL(i)
+#define TL_FLUSH()
+#endif
+
 namespace {
 
 struct GemmArgs {
@@ -46,12 +62,12 @@ __device__ __forceinline__ uint32_t lds_off(int row, int kchunk) {            //
 }
 
 // ---- row-major operand: tile [R rows][64 k], 16-byte chunks along k ------------------------------
-template <int R>
+template <int R, int NT>
 __device__ __forceinline__ void gload_rm(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, int K,
                                          uint4 (&v)[4], int tid) {
 #pragma unroll
-    for (int i = 0; i < R / 32; ++i) {
-        int c = tid + i * 256;
+    for (int i = 0; i < R * 8 / NT; ++i) {
+        int c = tid + i * NT;
         int row = c >> 3, kc = c & 7;
         int gr = row0 + row, gk = k0 + kc * 8;
         uint4 z = make_uint4(0, 0, 0, 0);
@@ -59,11 +75,11 @@ __device__ __forceinline__ void gload_rm(const bf16_t* __restrict__ base, int ld
         v[i] = z;
     }
 }
-template <int R>
+template <int R, int NT>
 __device__ __forceinline__ void lstore_rm(char* tile, const uint4 (&v)[4], int tid) {
 #pragma unroll
-    for (int i = 0; i < R / 32; ++i) {
-        int c = tid + i * 256;
+    for (int i = 0; i < R * 8 / NT; ++i) {
+        int c = tid + i * NT;
         int row = c >> 3, kc = c & 7;
         *reinterpret_cast<uint4*>(tile + lds_off(row, kc)) = v[i];
     }
@@ -78,15 +94,15 @@ __device__ __forceinline__ void lstore_rm(char* tile, const uint4 (&v)[4], int t
 // distinct banks.
 template <int R>
 __device__ __forceinline__ int km_swz(int k) {
-    return R == 128 ? (((k & 3) << 1) | (((k >> 3) & 1) << 3)) : ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2));
+    return R >= 128 ? (((k & 3) << 1) | (((k >> 3) & 1) << 3)) : ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2));
 }
-template <int R>
+template <int R, int NT>
 __device__ __forceinline__ void gload_km(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, int K,
                                          uint4 (&v)[4], int tid) {
     constexpr int CPR = R / 8;                                  // 16-byte chunks per k-row
 #pragma unroll
-    for (int i = 0; i < R / 32; ++i) {
-        int c = tid + i * 256;
+    for (int i = 0; i < R * 8 / NT; ++i) {
+        int c = tid + i * NT;
         int k = c / CPR, rc = c % CPR;
         int gk = k0 + k, gr = row0 + rc * 8;
         uint4 z = make_uint4(0, 0, 0, 0);
@@ -94,12 +110,12 @@ __device__ __forceinline__ void gload_km(const bf16_t* __restrict__ base, int ld
         v[i] = z;
     }
 }
-template <int R>
+template <int R, int NT>
 __device__ __forceinline__ void lstore_km(char* tile, const uint4 (&v)[4], int tid) {
     constexpr int CPR = R / 8;
 #pragma unroll
-    for (int i = 0; i < R / 32; ++i) {
-        int c = tid + i * 256;
+    for (int i = 0; i < R * 8 / NT; ++i) {
+        int c = tid + i * NT;
         int k = c / CPR, rc = c % CPR;
         *reinterpret_cast<uint4*>(tile + k * (R * 2) + ((rc ^ km_swz<R>(k)) << 4)) = v[i];
     }
@@ -127,40 +143,79 @@ __device__ __forceinline__ bf16x8_t frag_km(const char* tile, int r0, int ks, in
 // inside the same 128-byte row segment (same cache line, coalescing unchanged).  Only for full k-tiles; rows past the edge
 // are clamped to a valid row (their products land in outputs the epilogue never stores).
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-template <int R>
+template <int R, int NT>
 __device__ __forceinline__ void glds_rm(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, char* tile, int tid) {
     const int wave_base = (tid & ~63);
 #pragma unroll
-    for (int i = 0; i < R / 32; ++i) {
-        const int c = tid + i * 256;
+    for (int i = 0; i < R * 8 / NT; ++i) {
+        const int c = tid + i * NT;
         const int row = c >> 3, kc = (c & 7) ^ (row & 7);
         const int gr = min(row0 + row, rmax - 1);
-        __builtin_amdgcn_global_load_lds(base + (size_t)gr * ld + k0 + kc * 8, (lds_ptr_t)(tile + (i * 256 + wave_base) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(base + (size_t)gr * ld + k0 + kc * 8, (lds_ptr_t)(tile + (i * NT + wave_base) * 16), 16, 0, 0);
     }
 }
-template <int R>
+template <int R, int NT>
 __device__ __forceinline__ void glds_km(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, char* tile, int tid) {
     constexpr int CPR = R / 8;
     const int wave_base = (tid & ~63);
 #pragma unroll
-    for (int i = 0; i < R / 32; ++i) {
-        const int c = tid + i * 256;
+    for (int i = 0; i < R * 8 / NT; ++i) {
+        const int c = tid + i * NT;
         const int k = c / CPR, rc = (c % CPR) ^ km_swz<R>(k);
         const int gr = min(row0 + rc * 8, rmax - 8);
-        __builtin_amdgcn_global_load_lds(base + (size_t)(k0 + k) * ld + gr, (lds_ptr_t)(tile + (i * 256 + wave_base) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(base + (size_t)(k0 + k) * ld + gr, (lds_ptr_t)(tile + (i * NT + wave_base) * 16), 16, 0, 0);
     }
 }
 
-template <int BM, int BN, bool AKM, bool BKM, int NS = ((BM + BN <= 192) ? 3 : 2)>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
-    constexpr int FM = BM / 32, FN = BN / 32;                 // 16x16 fragments per wave
+// piece i (0 .. R*8/NT-1) of a tile = NT consecutive 16-byte slots = one wave-instruction per wave
+template <int R, int NT>
+__device__ __forceinline__ void glds_rm_piece(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, char* tile, int tid, int i) {
+    const int wave_base = (tid & ~63);
+    const int c = tid + i * NT;
+    const int row = c >> 3, kc = (c & 7) ^ (row & 7);
+    const int gr = min(row0 + row, rmax - 1);
+    __builtin_amdgcn_global_load_lds(base + (size_t)gr * ld + k0 + kc * 8, (lds_ptr_t)(tile + (i * NT + wave_base) * 16), 16, 0, 0);
+}
+template <int R, int NT>
+__device__ __forceinline__ void glds_km_piece(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, char* tile, int tid, int i) {
+    constexpr int CPR = R / 8;
+    const int wave_base = (tid & ~63);
+    const int c = tid + i * NT;
+    const int k = c / CPR, rc = (c % CPR) ^ km_swz<R>(k);
+    const int gr = min(row0 + rc * 8, rmax - 8);
+    __builtin_amdgcn_global_load_lds(base + (size_t)(k0 + k) * ld + gr, (lds_ptr_t)(tile + (i * NT + wave_base) * 16), 16, 0, 0);
+}
+
+// scheduling pattern of the interleaved k-step of the 8-wave kernel (see kstep_big): instruction groups in issue order
+template <int FM, int FN, int RA, int RB, int I>
+__device__ __forceinline__ void pin_ks0() {                 // ks = 0 MFMAs of fragment row I, then the ks = 1 fragments it frees room for
+    __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, RA + (I < FN ? RB : 0), 0);
+    if constexpr (I & 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    if constexpr (I + 1 < FM) pin_ks0<FM, FN, RA, RB, I + 1>();
+}
+template <int FM, int FN, int I>
+__device__ __forceinline__ void pin_ks1() {
+    __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
+    if constexpr (I & 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    if constexpr (I + 1 < FM) pin_ks1<FM, FN, I + 1>();
+}
+
+// WM x WN waves share a BM x BN tile: 2x2 (256 threads) for tiles up to 128x128, 2x4 (512 threads) for 256x256.
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM, TN = BN / WN;                 // wave tile
+    constexpr int FM = TM / 16, FN = TN / 16;                 // 16x16 fragments per wave
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;        // stage s: A tile at s*STAGE_BYTES, B tile right after it
     constexpr int NSTAGE = NS;                            // default: 3 stages up to 64x128 (72 KB, 2 workgroups/CU), 2 for 128x128
 
+    TL_DECL;
+    TL(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     // XCD-aware tile mapping: the dispatcher places workgroup b on XCD b % 8 (each XCD has a private 4 MB L2), so give
     // every XCD one contiguous run of tiles, n fastest: the tiles that share an A row-panel run on the same L2 back to
     // back, and the weight panel stays L2-resident per XCD.  Bijective for any tile count (speed only, never correctness).
@@ -192,25 +247,79 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 
     uint4 ra[4], rb[4];
     auto gload = [&](int kt) {
-        if (AKM) gload_km<BM>(p.A, p.lda, m0, kt * BK, p.M, p.K, ra, tid);
-        else     gload_rm<BM>(p.A, p.lda, m0, kt * BK, p.M, p.K, ra, tid);
-        if (BKM) gload_km<BN>(p.B, p.ldb, n0, kt * BK, p.N, p.K, rb, tid);
-        else     gload_rm<BN>(p.B, p.ldb, n0, kt * BK, p.N, p.K, rb, tid);
+        if (AKM) gload_km<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, p.K, ra, tid);
+        else     gload_rm<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, p.K, ra, tid);
+        if (BKM) gload_km<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, p.K, rb, tid);
+        else     gload_rm<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, p.K, rb, tid);
     };
     auto lstore = [&](int s) {
         char* at = smem + s * STAGE_BYTES;
         char* bt = at + A_BYTES;
-        if (AKM) lstore_km<BM>(at, ra, tid); else lstore_rm<BM>(at, ra, tid);
-        if (BKM) lstore_km<BN>(bt, rb, tid); else lstore_rm<BN>(bt, rb, tid);
+        if (AKM) lstore_km<BM, NT>(at, ra, tid); else lstore_rm<BM, NT>(at, ra, tid);
+        if (BKM) lstore_km<BN, NT>(bt, rb, tid); else lstore_rm<BN, NT>(bt, rb, tid);
     };
 
     auto glds = [&](int kt, int s) {                        // asynchronous: completion is awaited with vmcnt(0)
         char* at = smem + s * STAGE_BYTES;
         char* bt = at + A_BYTES;
-        if (AKM) glds_km<BM>(p.A, p.lda, m0, kt * BK, p.M, at, tid); else glds_rm<BM>(p.A, p.lda, m0, kt * BK, p.M, at, tid);
-        if (BKM) glds_km<BN>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid); else glds_rm<BN>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid);
+        if (AKM) glds_km<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, at, tid); else glds_rm<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, at, tid);
+        if (BKM) glds_km<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid); else glds_rm<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid);
     };
     const int lrow = lane & 15, lg = lane >> 4;
+    auto glds_piece = [&](int kt, int s, int pc) {
+        char* at = smem + s * STAGE_BYTES;
+        char* bt = at + A_BYTES;
+        constexpr int PA = BM * 8 / NT;
+        if (pc < PA) {
+            if (AKM) glds_km_piece<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, at, tid, pc); else glds_rm_piece<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, at, tid, pc);
+        } else {
+            if (BKM) glds_km_piece<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid, pc - PA);
+            else     glds_rm_piece<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid, pc - PA);
+        }
+    };
+    auto ldA = [&](const char* at, int i, int ks) -> bf16x8_t {
+        const int r0 = wm * TM + i * 16;
+        if (AKM) return frag_km<BM>(at, r0, ks, lane);
+        return *reinterpret_cast<const bf16x8_t*>(at + lds_off(r0 + lrow, ks * 4 + lg));
+    };
+    auto ldB = [&](const char* bt, int j, int ks) -> bf16x8_t {
+        const int r0 = wn * TN + j * 16;
+        if (BKM) return frag_km<BN>(bt, r0, ks, lane);
+        return *reinterpret_cast<const bf16x8_t*>(bt + lds_off(r0 + lrow, ks * 4 + lg));
+    };
+    // k-step of the 8-wave 256x256 kernel (64 MFMAs, 24 fragment reads, 8 LDS-DMA pieces per wave), finely interleaved: all
+    // waves of the workgroup run in lockstep behind the barrier, so whatever a wave issues in a bunch (the 8 DMA pieces cost
+    // ~100+ issue cycles each, the fragment reads have ~100 cycles of latency) leaves the matrix pipe of its SIMD idle.
+    // Order: ks=0 fragments; then per fragment row 4 MFMAs followed by the ks=1 fragment reads whose registers that row
+    // frees and, every second row, one DMA piece of the NEXT k-tile; then the ks=1 MFMAs with the other 4 pieces.
+    auto kstep_big = [&](int stage, int kt_pf, int s_pf) {
+        static_assert(FM * 8 / 8 >= 1, "");
+        const char* at = smem + stage * STAGE_BYTES;
+        const char* bt = at + A_BYTES;
+        bf16x8_t fa0[FM], fb0[FN], fa1[FM], fb1[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa0[i] = ldA(at, i, 0);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb0[j] = ldB(bt, j, 0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+            fa1[i] = ldA(at, i, 1);
+            if (i < FN) fb1[i] = ldB(bt, i, 1);
+            if (i & 1) glds_piece(kt_pf, s_pf, i >> 1);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+            if (i & 1) glds_piece(kt_pf, s_pf, FM / 2 + (i >> 1));
+        }
+        constexpr int RA = AKM ? 2 : 1, RB = BKM ? 2 : 1;
+        __builtin_amdgcn_sched_group_barrier(0x100, FM * RA + FN * RB, 0);
+        pin_ks0<FM, FN, RA, RB, 0>();
+        pin_ks1<FM, FN, 0>();
+    };
     auto compute = [&](int stage) {
         const char* at = smem + stage * STAGE_BYTES;
         const char* bt = at + A_BYTES;
@@ -219,13 +328,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
             bf16x8_t fa[FM], fb[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int r0 = wm * (BM / 2) + i * 16;
+                const int r0 = wm * TM + i * 16;
                 if (AKM) fa[i] = frag_km<BM>(at, r0, ks, lane);
                 else     fa[i] = *reinterpret_cast<const bf16x8_t*>(at + lds_off(r0 + lrow, ks * 4 + lg));
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int r0 = wn * (BN / 2) + j * 16;
+                const int r0 = wn * TN + j * 16;
                 if (BKM) fb[j] = frag_km<BN>(bt, r0, ks, lane);
                 else     fb[j] = *reinterpret_cast<const bf16x8_t*>(bt + lds_off(r0 + lrow, ks * 4 + lg));
             }
@@ -242,17 +351,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     // s_waitcnt vmcnt(LPT) at the top of an iteration only waits for the OLDER group, so a whole iteration of MFMAs covers
     // the memory latency.  One raw s_barrier per k-step (it both publishes tile i and retires the reads of tile i-1, whose
     // stage is the one refilled next).  A partial last k-tile (K % 64 != 0) goes through registers with zero fill.
-    constexpr int LPT = BM / 32 + BN / 32;                 // glds instructions per tile per wave
+    constexpr int LPT = (BM + BN) * 8 / NT;                // glds instructions per tile per wave
     const bool has_tail = (kt1 == nk_total) && (p.K % BK != 0) && (kt1 > kt0);
     const int nmain = (kt1 - kt0) - (has_tail ? 1 : 0);
 #pragma unroll
     for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
         if (s0 < nmain) glds(kt0 + s0, s0);
     int stage = 0, fill = NSTAGE - 1;                      // stage of tile i, stage that tile i+NSTAGE-1 goes to
+    TL(1);
+    if constexpr (WM * WN == 8) {
+        // 8-wave kernel: two stages, branch-free steps.  Every step prefetches; the last one re-requests the final k-tile into
+        // the stage that was just retired (harmless, L2-resident) instead of branching around the loads, which keeps the
+        // whole step one scheduling region.
+        static_assert(NSTAGE == 2 && LPT == FM, "kstep_big spreads FM DMA pieces over 2*FM fragment rows");
+        for (int i = 0; i < nmain; ++i) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#ifdef GEMM_TIMELINE
+            if (i == 0) TL(2);
+#endif
+            kstep_big(stage, min(kt0 + i + 1, kt0 + nmain - 1), stage ^ 1);
+            stage ^= 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus prefetch must land before LDS is reused / the wave ends
+        if (has_tail) __syncthreads();
+    } else
     for (int i = 0; i < nmain; ++i) {
         if (NSTAGE == 3 && i + 1 < nmain) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
         else                               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef GEMM_TIMELINE
+        if (i == 0) TL(2);
+#endif
         if (i + NSTAGE - 1 < nmain) glds(kt0 + i + NSTAGE - 1, fill);
         compute(stage);
         stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
@@ -265,6 +395,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         compute(stage);
     }
 
+    TL(3);
     // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4 -----------
     // Two phases.  (1) ALL auxiliary operands of the wave's tile (residual / C-for-accumulate, or the gate, and the bias) are
     // requested up front; (2) after a single wait every fragment is finished and stored back to back.  A per-fragment
@@ -273,14 +404,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     // cost per launch before this change).
     const float dscale = drop_scale(p.drop_thr);
     const bool aux_f32 = (p.resid != nullptr) || p.accum;             // block-uniform
+    // bf16 output: two neighbouring fragments j, j+1 of a row block are packed and exchanged between the lane rows with
+    // v_permlane16_swap (rows 1/3 of fragment j <-> rows 0/2 of fragment j+1), after which a lane owns 8 consecutive columns:
+    // one 16-byte store per lane, 64 contiguous bytes per matrix row per instruction, half as many store instructions as
+    // 8-byte stores (the epilogue is store-ISSUE bound: ~50 cycles per wave-store whatever its width).  Every lane takes part
+    // in the swap; only the store is predicated.
+    auto store_pair_bf16 = [&](int m, int j, const float (&v)[4], const float (&w)[4]) {
+        const uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
+        const uint32_t q0 = pack_bf16x2(w[0], w[1]), q1 = pack_bf16x2(w[2], w[3]);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(p0, q0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(p1, q1, false, false);
+        const int n = n0 + wn * TN + (j + (lg & 1)) * 16 + (lg >> 1) * 8;
+        if (m < p.M && n < p.N)
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(Cbase) + (size_t)m * p.ldc + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+    };
     if (!p.bias && !p.relu && !p.gate && !p.drop_thr && !aux_f32) {
         // plain epilogue (QKV / cross-K/V / lm_head projections, every dgrad without gate, every weight gradient): straight-line
         // scale + pack + store; keeps ~100 option-testing instructions per fragment off the tail of ~70 % of the launches
-        const int nb = n0 + wn * (BN / 2) + lg * 4;
+        const int nb = n0 + wn * TN + lg * 4;
         if (p.out_f32) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int m = m0 + wm * (BM / 2) + i * 16 + lrow;
+                const int m = m0 + wm * TM + i * 16 + lrow;
                 if (m >= p.M) continue;
                 float* crow = reinterpret_cast<float*>(Cbase) + (size_t)m * p.ldc + nb;
 #pragma unroll
@@ -292,19 +437,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         } else {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int m = m0 + wm * (BM / 2) + i * 16 + lrow;
-                if (m >= p.M) continue;
-                bf16_t* crow = reinterpret_cast<bf16_t*>(Cbase) + (size_t)m * p.ldc + nb;
+                const int m = m0 + wm * TM + i * 16 + lrow;
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    if (nb + j * 16 < p.N) {
-                        uint2 o;
-                        o.x = pack_bf16x2(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha);
-                        o.y = pack_bf16x2(acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
-                        *reinterpret_cast<uint2*>(crow + j * 16) = o;
-                    }
+                for (int j = 0; j < FN; j += 2) {
+                    float v[4], w[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = acc[i][j][r] * p.alpha; w[r] = acc[i][j + 1][r] * p.alpha; }
+                    store_pair_bf16(m, j, v, w);
+                }
             }
         }
+        TL(4);
+#ifdef GEMM_TIMELINE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        TL(5);
+        TL_FLUSH();
         return;
     }
     // Fused epilogues.  The option set is block-uniform; the combinations the engine issues are compiled as straight-line
@@ -316,51 +464,48 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         constexpr bool kGen = decltype(c_generic)::value;      // generic instance: a compiled-in option is still tested at run time
         const bool do_bias = kBias && (!kGen || bias), do_relu = kRelu && (!kGen || relu), do_drop = kDrop && (!kGen || drop);
         const bool do_aux = kAux && (!kGen || aux_f32);
-        float4 aux[FM][FN];
         float4 bs[FN];
         if constexpr (kBias) {
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
+                const int n = n0 + wn * TN + j * 16 + lg * 4;
                 bs[j] = (do_bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        if constexpr (kAux || kGate) {
+        constexpr int IC = (FM * FN > 16) ? (16 / FN) : FM;     // fragment rows per pass: at most 16 auxiliary float4 in flight
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int m = m0 + wm * (BM / 2) + i * 16 + lrow;
+        for (int ib = 0; ib < FM; ib += IC) {
+            float4 aux[IC][FN];
+            if constexpr (kAux || kGate) {
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
-                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (m < p.M && n < p.N && (do_aux || kGate)) {
-                        if constexpr (kAux) {
-                            if (p.resid) t = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
-                            if (p.accum) {
-                                float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Cbase) + (size_t)m * p.ldc + n);
-                                t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+                for (int ii = 0; ii < IC; ++ii) {
+                    const int m = m0 + wm * TM + (ib + ii) * 16 + lrow;
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const int n = n0 + wn * TN + j * 16 + lg * 4;
+                        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (m < p.M && n < p.N && (do_aux || kGate)) {
+                            if constexpr (kAux) {
+                                if (p.resid) t = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
+                                if (p.accum) {
+                                    float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Cbase) + (size_t)m * p.ldc + n);
+                                    t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+                                }
+                            } else {
+                                uint2 g2 = *reinterpret_cast<const uint2*>(p.gate + (size_t)m * p.ldg + n);
+                                t.x = __uint_as_float(g2.x); t.y = __uint_as_float(g2.y);
                             }
-                        } else {
-                            uint2 g2 = *reinterpret_cast<const uint2*>(p.gate + (size_t)m * p.ldg + n);
-                            t.x = __uint_as_float(g2.x); t.y = __uint_as_float(g2.y);
                         }
+                        aux[ii][j] = t;
                     }
-                    aux[i][j] = t;
                 }
             }
-        }
-        // one explicit vmcnt(0) that EVERY path passes: the loads above sit in divergent branches, and a conservative re-wait
-        // before each fragment would land between the stores (vmcnt counts stores too on CDNA)
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 16 + lrow;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
-                if (n >= p.N) continue;
-                float v[4];
+            // one explicit vmcnt(0) that EVERY path passes: the loads above sit in divergent branches, and a conservative
+            // re-wait before each fragment would land between the stores (vmcnt counts stores too on CDNA)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            auto finish = [&](int ii, int j, int m, float (&v)[4]) {     // everything between the accumulator and the store
+                const int i = ib + ii;
+                const int n = n0 + wn * TN + j * 16 + lg * 4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
                 if constexpr (kBias) { v[0] += bs[j].x; v[1] += bs[j].y; v[2] += bs[j].z; v[3] += bs[j].w; }
@@ -371,7 +516,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                     }
                 }
                 if constexpr (kGate) {
-                    uint32_t gw[2] = {__float_as_uint(aux[i][j].x), __float_as_uint(aux[i][j].y)};
+                    uint32_t gw[2] = {__float_as_uint(aux[ii][j].x), __float_as_uint(aux[ii][j].y)};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         bf16_t h = (bf16_t)((gw[r >> 1] >> ((r & 1) * 16)) & 0xffffu);
@@ -385,16 +530,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                         for (int r = 0; r < 4; ++r) v[r] = drop_keep(p.drop_seed, idx + r, p.drop_thr) ? v[r] * dscale : 0.f;
                     }
                 }
-                if constexpr (kAux) { v[0] += aux[i][j].x; v[1] += aux[i][j].y; v[2] += aux[i][j].z; v[3] += aux[i][j].w; }
+                if constexpr (kAux) { v[0] += aux[ii][j].x; v[1] += aux[ii][j].y; v[2] += aux[ii][j].z; v[3] += aux[ii][j].w; }
+            };
+#pragma unroll
+            for (int ii = 0; ii < IC; ++ii) {
+                const int m = m0 + wm * TM + (ib + ii) * 16 + lrow;
                 if constexpr (kF32) {
-                    float* c = reinterpret_cast<float*>(Cbase) + (size_t)m * p.ldc + n;
-                    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (m >= p.M) continue;
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const int n = n0 + wn * TN + j * 16 + lg * 4;
+                        if (n >= p.N) continue;
+                        float v[4];
+                        finish(ii, j, m, v);
+                        float* c = reinterpret_cast<float*>(Cbase) + (size_t)m * p.ldc + n;
+                        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
                 } else {
-                    bf16_t* c = reinterpret_cast<bf16_t*>(Cbase) + (size_t)m * p.ldc + n;
-                    uint2 o;
-                    o.x = pack_bf16x2(v[0], v[1]);
-                    o.y = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(c) = o;
+#pragma unroll
+                    for (int j = 0; j < FN; j += 2) {
+                        float v[4], w[4];
+                        finish(ii, j, m, v);
+                        finish(ii, j + 1, m, w);
+                        store_pair_bf16(m, j, v, w);
+                    }
                 }
             }
         }
@@ -414,6 +573,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     } else {
         if (f32) run(T{}, T{}, F{}, T{}, T{}, T{}, T{}); else run(T{}, T{}, F{}, T{}, T{}, F{}, T{});
     }
+    TL(4);
+#ifdef GEMM_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    TL(5);
+    TL_FLUSH();
 }
 
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n,
@@ -428,16 +593,16 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
     *reinterpret_cast<float4*>(out + i) = s;
 }
 
-template <int BM, int BN, bool AKM, bool BKM, int NS>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
 int launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * (BM + BN) * BK * 2;
     static bool attr_set = false;                           // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
     if (!attr_set) {
-        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AKM, BKM, NS>),
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WM, WN, AKM, BKM, NS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, AKM, BKM, NS>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, NS>), grid, dim3(WM * WN * 64), lds, st, a);
     LAUNCH_CHECK();
     return VLT5_OK;
 }
@@ -445,12 +610,14 @@ int launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
 template <int BM, int BN>
 int launch_tile(const GemmArgs& a, int akm, int bkm, int splits, int batch, hipStream_t st) {
     dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM), splits > 1 ? splits : 1, batch > 1 ? batch : 1);
+    // ring depth: 3 stages up to 64x128 (72 KB, 2 workgroups/CU); 2 for 128x128 (a 3-stage ring = 96 KB = 1 workgroup/CU
+    // measured 13 % slower end to end: occupancy matters more) and for 256x256 (2 x 64 KB, one 8-wave workgroup per CU)
     constexpr int NS = (BM + BN <= 192) ? 3 : 2;
-    // (a 3-stage ring for 128x128 = 96 KB = 1 workgroup/CU measured 13 % slower end to end: occupancy matters more)
-    if (!akm && !bkm) return launch_one<BM, BN, false, false, NS>(a, grid, st);
-    if (!akm && bkm) return launch_one<BM, BN, false, true, NS>(a, grid, st);
-    if (akm && bkm) return launch_one<BM, BN, true, true, NS>(a, grid, st);
-    return launch_one<BM, BN, true, false, NS>(a, grid, st);
+    constexpr int WM = 2, WN = (BM == 256 && BN == 256) ? 4 : 2;
+    if (!akm && !bkm) return launch_one<BM, BN, WM, WN, false, false, NS>(a, grid, st);
+    if (!akm && bkm) return launch_one<BM, BN, WM, WN, false, true, NS>(a, grid, st);
+    if (akm && bkm) return launch_one<BM, BN, WM, WN, true, true, NS>(a, grid, st);
+    return launch_one<BM, BN, WM, WN, true, false, NS>(a, grid, st);
 }
 
 }  // namespace
@@ -463,6 +630,7 @@ extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
     if ((a_contig & 7) || (b_contig & 7) || (d->N & 7) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 3)) return VLT5_ERR_ALIGN;
     if (d->resid && (d->ldr & 3)) return VLT5_ERR_ALIGN;
     if (d->gate && (d->ldg & 3)) return VLT5_ERR_ALIGN;
+    if (!d->out_f32 && (d->ldc & 7)) return VLT5_ERR_ALIGN;           // bf16 rows are written as 16-byte vectors
     if (d->accum && !d->out_f32) return VLT5_ERR_ARG;
     if (d->gate && (d->resid || d->accum)) return VLT5_ERR_ARG;      // the epilogue holds ONE auxiliary operand per fragment
     if (d->split_k > 1 && (!d->out_f32 || !d->workspace || d->ldc != d->N || d->bias || d->relu || d->gate || d->drop_p > 0.f || d->resid))
@@ -486,11 +654,16 @@ extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
         // output is only 210 tiles of 128 x 128 for 256 CUs
         const int sk = (d->split_k > 1 ? d->split_k : 1) * batch;
         auto tiles = [&](int tm, int tn) { return (long)((d->M + tm - 1) / tm) * ((d->N + tn - 1) / tn) * sk; };
-        if (tiles(128, 128) >= 768) { bm = 128; bn = 128; }            // >= 3 workgroups per CU of the big tile
+        // 256 x 256 (8 waves, one workgroup per CU): half the LDS-fill traffic per flop of 128 x 128 -- wins once its tiles
+        // fill most of the 256 CUs (wide-N forward / dgrad GEMMs with row-major A); the k-major A variant does not pay
+        // (also for a small output with a very long reduction cut into slices by vlt5_gemm_auto_split: the input gradients
+        // of lm_head and of the stacked cross-attention K/V projection)
+        if (!d->a_kmajor && (tiles(256, 256) >= 200 || (d->K >= 8192 && d->split_k > 1 && tiles(256, 256) >= 128))) { bm = 256; bn = 256; }
+        else if (tiles(128, 128) >= 768) { bm = 128; bn = 128; }       // >= 3 workgroups per CU of the big tile
         else if (tiles(64, 128) >= 256) { bm = 64; bn = 128; }         // 3-stage ring, 2 workgroups per CU
         else { bm = 64; bn = 64; }                                     // small-M (decoder) problems: most workgroups
     }
-    if (!((bm == 128 || bm == 64) && (bn == 128 || bn == 64))) return VLT5_ERR_ARG;
+    if (!(((bm == 128 || bm == 64) && (bn == 128 || bn == 64)) || (bm == 256 && bn == 256))) return VLT5_ERR_ARG;
 
     int splits = d->split_k > 1 ? d->split_k : 1;
     const int nk = (d->K + BK - 1) / BK;
@@ -503,7 +676,8 @@ extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
         a.accum = 0;
     }
     int rc;
-    if (bm == 128 && bn == 128) rc = launch_tile<128, 128>(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
+    if (bm == 256) rc = launch_tile<256, 256>(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
+    else if (bm == 128 && bn == 128) rc = launch_tile<128, 128>(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
     else if (bm == 128 && bn == 64) rc = launch_tile<128, 64>(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
     else if (bm == 64 && bn == 128) rc = launch_tile<64, 128>(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
     else rc = launch_tile<64, 64>(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
@@ -518,15 +692,26 @@ extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
     return VLT5_OK;
 }
 
-// split-K factor for a GEMM whose output has few tiles but a long reduction: aim at ~2 workgroups per CU, keep >= 4
-// k-steps (of 64) per slice, and stay inside the caller's slab scratch.  Only valid for plain f32 outputs.
+// split-K factor for a GEMM whose output has few tiles but a long reduction: aim at ~2 workgroups per CU (one for the
+// 256 x 256 kernel), keep >= 4 (8) k-steps of 64 per slice, and stay inside the caller's slab scratch.  Only valid for
+// plain f32 outputs.
 extern "C" int vlt5_gemm_auto_split(int M, int N, int Kred, long long slab_bytes) {
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const int ksteps = (Kred + 63) / 64;
-    if (Kred < 1024 || tiles >= 128) return 1;
-    int sk = (int)((512 + tiles / 2) / tiles);
-    if (sk > 8) sk = 8;
-    if (sk > ksteps / 4) sk = ksteps / 4;
+    int sk;
+    if (Kred >= 8192 && tiles256 <= 64) {
+        // very long reduction into few 256 x 256 tiles (input gradients of lm_head and of the stacked cross-attention K/V
+        // projection): ~224 workgroups of the 8-wave kernel, >= 8 k-steps each
+        sk = (int)((224 + tiles256 / 2) / tiles256);
+        if (sk > 32) sk = 32;
+        if (sk > ksteps / 8) sk = ksteps / 8;
+    } else {
+        if (Kred < 1024 || tiles >= 128) return 1;
+        sk = (int)((512 + tiles / 2) / tiles);
+        if (sk > 8) sk = 8;
+        if (sk > ksteps / 4) sk = ksteps / 4;
+    }
     while (sk > 1 && (long long)sk * M * N * 4 > slab_bytes) --sk;
     return sk < 1 ? 1 : sk;
 }
@@ -549,6 +734,12 @@ __global__ void tr_probe_kernel(const uint16_t* in, uint16_t* out, const int* ad
     for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (uint16_t)v[j];
 }
 }  // namespace
+#ifdef GEMM_TIMELINE
+extern "C" int vlt5dbg_set_timeline(void* buf) {
+    HIP_RET(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &buf, sizeof(buf)));
+    return VLT5_OK;
+}
+#endif
 extern "C" int vlt5dbg_tr_read(const void* in, void* out, const int* addr_elems, int n_in, void* stream) {
     hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)in, (uint16_t*)out, addr_elems, n_in);
     LAUNCH_CHECK();
