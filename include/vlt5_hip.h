@@ -222,6 +222,9 @@ typedef struct {
     const float* gout;             /* [1] upstream gradient of the reduced loss or NULL (=1); used when d_loss_tok == NULL */
     const float* d_loss_tok;       /* [B*T] upstream gradient of the per-token loss (generic VLT5.forward path) or NULL */
     void** events; int n_events;   /* optional hipEvent_t recorded when a gradient bucket is complete (backward) */
+    void** wait_events; int n_wait_events;   /* optional hipEvent_t per parameter bucket (same numbering): the forward phases
+                                      make the stream wait for bucket b's event before the first kernel that reads that
+                                      bucket's weights -- lets an optimizer update on another stream overlap the forward */
 } vlt5_step;
 
 /* parameter layout */

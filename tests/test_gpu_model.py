@@ -249,13 +249,15 @@ def test_training_loop_drop_in_with_torch_optimizer_and_fused_optimizer(dev):
         R.clip_grad_norm(list(oracle.used.values()), 5.0)
         oopt.step()
         ref_losses.append(float(o["loss"]))
-    for kind in ("torch", "fused"):
+    finals = {}
+    for kind in ("torch", "fused", "fused-overlap"):
         model = make_model(ocfg, params, dev)
         model.train()
         if kind == "torch":
             opt = torch.optim.AdamW(reference_param_groups(model, 0.01), lr=1e-3, eps=1e-6)
         else:
-            opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-3, eps=1e-6, max_grad_norm=5.0)
+            opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-3, eps=1e-6, max_grad_norm=5.0,
+                             overlap=(kind == "fused-overlap"))
         got = []
         for it in range(4):
             res = model.train_step(batch, 0, 0.5, 0.3)
@@ -270,8 +272,17 @@ def test_training_loop_drop_in_with_torch_optimizer_and_fused_optimizer(dev):
         for a, b in zip(got, ref_losses):
             assert abs(a - b) < 5e-2, (kind, got, ref_losses)
         assert got[-1] < got[0], "loss decreases on a repeated batch"
+        if kind != "torch":
+            model.sync_optimizer()
         w = dict(model.named_parameters())["decoder.block.1.layer.2.DenseReluDense.wo.weight"]
         assert rel_max_err(w, oracle.P["decoder.block.1.layer.2.DenseReluDense.wo.weight"]) < 5e-2
+        finals[kind] = (got, {k: v.clone() for k, v in model.state_dict().items()})
+    # the update on a second stream (ordered per bucket against the next forward) computes exactly what the in-stream one does
+    # (dropout is off in this config; the embedding-gradient atomics are the only run-to-run noise)
+    for a, b in zip(finals["fused"][0], finals["fused-overlap"][0]):
+        assert abs(a - b) < 1e-4, (finals["fused"][0], finals["fused-overlap"][0])
+    for k, v in finals["fused"][1].items():
+        assert torch.allclose(v, finals["fused-overlap"][1][k], rtol=1e-4, atol=1e-5), k
 
 
 def test_gradient_accumulation_path(dev):

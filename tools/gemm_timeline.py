@@ -34,39 +34,50 @@ run()
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3
-t = buf.cpu().numpy().astype(np.uint64).reshape(ntiles, 8)
-hw = t[:, 6]
-xcc = (hw & np.uint64(0xF)).astype(int)
-hwid = (hw >> np.uint64(32)).astype(np.int64)
-cu = ((hwid >> 8) & 0xF).astype(int)
-se = ((hwid >> 13) & 0x7).astype(int)
-t = t[:, :6].astype(np.int64)
-# the counter is per XCD (not synchronised across XCDs): offsets are taken against the first workgroup of the same XCD
-base = np.zeros(ntiles, dtype=np.int64)
-for x in range(16):
-    sel = xcc == x
-    if sel.any():
-        base[sel] = t[sel, 0].min()
-span = (t[:, 5] - base).max()
-nk = K // 64
-tick_us = float(os.environ.get("TICKS_PER_US", "100"))      # s_memtime ticks at the 100 MHz reference clock on gfx950
-print(f"M={M} N={N} K={K} akm={akm} bkm={bkm} tile={tm}x{tn}: {ntiles} workgroups, event time {us:.1f} us, tick span {span} "
-      f"= {span / tick_us:.1f} us at {tick_us:.0f} ticks/us")
+def analyse(t, label):
+    rt0, rt1 = t[:, 7].astype(np.int64), t[:, 6].astype(np.int64)      # 100 MHz device-wide clock: start / end of each workgroup
+    t = t[:, :6].astype(np.int64)
+    nk = K // 64
+    life = t[:, 5] - t[:, 0]
+    tick_us = float(np.median(life / np.maximum(rt1 - rt0, 1))) * 100.0   # shader ticks per microsecond
+    print(f"{label}: shader clock ~ {tick_us:.0f} ticks/us")
+
+    def stat(name, v, per=tick_us):
+        v = v / per
+        print(f"  {name:36s} mean {v.mean():7.2f}  p10 {np.percentile(v, 10):7.2f}  p50 {np.percentile(v, 50):7.2f}  p90 {np.percentile(v, 90):7.2f}  max {v.max():7.2f} us")
+
+    stat("start offset (first workgroup = 0)", rt0 - rt0.min(), 100.0)
+    stat("end offset", rt1 - rt0.min(), 100.0)
+    stat("setup + prologue issue (t1-t0)", t[:, 1] - t[:, 0])
+    stat("first k-tile landed (t2-t1)", t[:, 2] - t[:, 1])
+    stat(f"main loop (t3-t2), {nk} k-steps", t[:, 3] - t[:, 2])
+    stat("  per k-step", (t[:, 3] - t[:, 2]) / max(nk, 1))
+    stat("epilogue issue (t4-t3)", t[:, 4] - t[:, 3])
+    stat("store drain (t5-t4)", t[:, 5] - t[:, 4])
+    stat("workgroup life (t5-t0)", life)
+    return rt0.min(), rt1.max()
 
 
-def stat(name, v):
-    v = v / tick_us
-    print(f"  {name:34s} mean {v.mean():7.2f}  p10 {np.percentile(v, 10):7.2f}  p50 {np.percentile(v, 50):7.2f}  p90 {np.percentile(v, 90):7.2f}  max {v.max():7.2f} us")
-
-
-stat("start offset (t0 - first t0)", t[:, 0] - base)
-stat("setup + prologue issue (t1-t0)", t[:, 1] - t[:, 0])
-stat("first k-tile landed (t2-t1)", t[:, 2] - t[:, 1])
-stat(f"main loop (t3-t2), {nk} k-steps", t[:, 3] - t[:, 2])
-stat("  per k-step", (t[:, 3] - t[:, 2]) / max(nk, 1))
-stat("epilogue issue (t4-t3)", t[:, 4] - t[:, 3])
-stat("store drain (t5-t4)", t[:, 5] - t[:, 4])
-stat("workgroup life (t5-t0)", t[:, 5] - t[:, 0])
-stat("end offset (t5 - first t0 of xcd)", t[:, 5] - base)
-uniq = len(set(zip(xcc.tolist(), se.tolist(), cu.tolist())))
-print(f"  distinct (xcc, se, cu) = {uniq}; workgroups per xcc = {np.bincount(xcc, minlength=8).tolist()}")
+buf2 = torch.zeros_like(buf)
+# two dependent launches back to back (the second one reads nothing from the first, but stream order serialises them)
+torch.cuda.synchronize()
+assert lib.vlt5dbg_set_timeline(C.c_void_p(buf.data_ptr())) == 0
+run()
+assert lib.vlt5dbg_set_timeline(C.c_void_p(buf2.data_ptr())) == 0     # hipMemcpyToSymbol: synchronises with the first launch
+run()
+torch.cuda.synchronize()
+# same pair captured in a graph is not possible (the symbol copy), so measure the launch-to-launch gap with one buffer:
+g = torch.cuda.CUDAGraph()
+st = torch.cuda.Stream()
+with torch.cuda.stream(st):
+    with torch.cuda.graph(g, stream=st):
+        for _ in range(4):
+            run()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+g.replay(); torch.cuda.synchronize()
+e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+print(f"M={M} N={N} K={K} akm={akm} bkm={bkm} tile={tm}x{tn} f32={int(f32)}: {ntiles} workgroups; graph replay of 4 launches: "
+      f"{e0.elapsed_time(e1) * 250:.1f} us per launch")
+t = buf2.cpu().numpy().astype(np.uint64).reshape(ntiles, 8)
+s0, s1 = analyse(t, "single launch")
+print(f"  kernel span (first start -> last end, device clock): {(s1 - s0) / 100.0:.2f} us")

@@ -47,7 +47,8 @@ class Step(C.Structure):
     _fields_ = [("B", c_i), ("L", c_i), ("V", c_i), ("T", c_i), ("training", c_i), ("seed", c_u32),
                 ("params", vp), ("params_bf16", vp), ("grads", vp), ("workspace", vp), ("workspace_bytes", c_ll),
                 ("vis_feats", vp), ("boxes", vp), ("input_ids", vp), ("labels", vp), ("scores", vp),
-                ("enc_lut", vp), ("dec_lut", vp), ("gout", vp), ("d_loss_tok", vp), ("events", C.POINTER(vp)), ("n_events", c_i)]
+                ("enc_lut", vp), ("dec_lut", vp), ("gout", vp), ("d_loss_tok", vp), ("events", C.POINTER(vp)), ("n_events", c_i),
+                ("wait_events", C.POINTER(vp)), ("n_wait_events", c_i)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/vlt5_hip.h

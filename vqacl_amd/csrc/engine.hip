@@ -304,6 +304,12 @@ struct Ctx {
         }
         return vlt5_gemm_bf16(&g, st);
     }
+    // forward side of an overlapped optimizer: wait until parameter bucket b has been updated (no-op without events)
+    int wait_bucket(int b) const {
+        if (s.wait_events && b >= 0 && b < s.n_wait_events && s.wait_events[b])
+            HIP_RET(hipStreamWaitEvent(st, (hipEvent_t)s.wait_events[b], 0));
+        return VLT5_OK;
+    }
     int record(int k) const {
         if (s.events && k >= 0 && k < s.n_events && s.events[k]) HIP_RET(hipEventRecord((hipEvent_t)s.events[k], st));
         return VLT5_OK;
@@ -334,6 +340,8 @@ int encoder_fwd(const Ctx& k) {
     const Plan& p = k.p; const Layout& L = k.lay; const vlt5_config& c = k.c; const vlt5_step& s = k.s;
     const int d = k.d, inner = k.inner, ff = k.ff, M = p.M, S = p.S, Sx = p.Sx, B = s.B;
     float* x0 = k.w<float>(p.x[0]);
+    const int nb = c.num_decoder_layers + c.num_layers + 2;      // buckets: decoder top..0, cross k/v, encoder top..0, norms+embeddings
+    RC(k.wait_bucket(nb - 1));
     RC(vlt5_build_mask(s.input_ids, k.w<float>(p.mask), B, s.L, S, c.pad_id, k.st));
     RC(vlt5_relbias_build(k.P + L.enc_rel, s.enc_lut, k.w<float>(p.enc_bias), k.H, s.L, s.L, c.rel_buckets, k.st));
     RC(vlt5_embed_fwd(s.input_ids, k.P + L.shared, x0, (long long)S * d, d, B, s.L, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, 0, k.st));
@@ -345,6 +353,7 @@ int encoder_fwd(const Ctx& k) {
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& E = L.enc[l];
         const uint32_t sb = SITE_ENC_BASE + l * 8;
+        RC(k.wait_bucket(c.num_decoder_layers + c.num_layers - l));
         float* xa = k.w<float>(p.x[2 * l]);
         float* xf = k.w<float>(p.x[2 * l + 1]);
         float* xo = k.w<float>(p.x[2 * l + 2]);
@@ -370,6 +379,8 @@ int decoder_fwd(const Ctx& k) {
     const int d = k.d, inner = k.inner, ff = k.ff, Md = p.Md, Mx = p.Mx, Sx = p.Sx, B = s.B, T = s.T, Ld = c.num_decoder_layers;
     const int kvw = Ld * 2 * inner;
     long long* ids = k.w<long long>(p.dec_ids);
+    RC(k.wait_bucket(Ld + c.num_layers + 1));                 // (a decoder-only call: norms + embeddings first)
+    RC(k.wait_bucket(Ld));                                    // stacked cross-attention k/v
     RC(vlt5_shift_right(s.labels, ids, B, T, c.dec_start_id, c.pad_id, k.st));
     RC(vlt5_build_mask(s.input_ids, k.w<float>(p.mask_ext), B, s.L, Sx, c.pad_id, k.st));
     RC(vlt5_relbias_build(k.P + L.dec_rel, s.dec_lut, k.w<float>(p.dec_bias), k.H, T, T, c.rel_buckets, k.st));
@@ -378,6 +389,7 @@ int decoder_fwd(const Ctx& k) {
     for (int l = 0; l < Ld; ++l) {
         const auto& D = L.dec[l];
         const uint32_t sb = SITE_DEC_BASE + l * 8;
+        RC(k.wait_bucket(Ld - 1 - l));
         float* y0 = k.w<float>(p.y[3 * l]);
         float* y1 = k.w<float>(p.y[3 * l + 1]);
         float* y2 = k.w<float>(p.y[3 * l + 2]);

@@ -29,9 +29,9 @@
 #ifdef GEMM_TIMELINE
 __device__ unsigned long long* g_timeline = nullptr;
 #define TL_DECL unsigned long long tlv[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define TL(i) do { if (threadIdx.x == 0) tlv[i] = __builtin_readcyclecounter(); } while (0)
+#define TL(i) do { if (threadIdx.x == 0) { tlv[i] = __builtin_readcyclecounter(); if (i == 0) tlv[7] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define TL_FLUSH() do { if (threadIdx.x == 0 && g_timeline) { \
-        tlv[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 20); \
+        tlv[6] = __builtin_amdgcn_s_memrealtime();   /* 100 MHz, common to the whole device: [7] = start, [6] = end */ \
         unsigned long long* o = g_timeline + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8; \
         for (int q = 0; q < 8; ++q) o[q] = tlv[q]; } } while (0)
 #else

@@ -148,6 +148,7 @@ class VLT5(nn.Module):
         self.base_seed = 0x5EED
         self.dp = None                       # set by parallel.DataParallelVLT5
         self.external_bf16_sync = False      # True once a fused optimizer keeps the bf16 shadow fresh itself
+        self._opt_events = None              # per-bucket events of an overlapped optimizer update (FusedAdamW(overlap=True))
         self._bf16_version = -1
         self._build(self.cfg, None)
         self.proto = PrototypeHead(self.cfg.n_ques, self.cfg.n_cate, self.cfg.d_model, self._device)
@@ -372,7 +373,24 @@ class VLT5(nn.Module):
         s.vis_feats, s.boxes, s.input_ids = ptr(st["feats"]), ptr(st["boxes"]), ptr(st["input_ids"])
         s.labels, s.scores = ptr(st["labels"]), ptr(st.get("scores"))
         s.enc_lut, s.dec_lut = ptr(st["enc_lut"]), ptr(st["dec_lut"])
+        if self._opt_events is not None:
+            # an optimizer is (possibly still) updating the parameters on its own stream: the engine waits bucket by bucket
+            arr = (L.vp * len(self._opt_events))(*[L.vp(e.cuda_event) for e in self._opt_events])
+            st["_wait_arr"] = arr                                   # keep the array alive as long as the step state
+            s.wait_events, s.n_wait_events = arr, len(self._opt_events)
         return s
+
+    def sync_optimizer(self):
+        """Make the current stream wait for an overlapped optimizer update (FusedAdamW(overlap=True)) -- call before
+        touching parameters with anything but train_step/test_step (state_dict() does it itself)."""
+        if self._opt_events is not None:
+            cur = torch.cuda.current_stream()
+            for e in self._opt_events:
+                cur.wait_event(e)
+
+    def state_dict(self, *a, **k):
+        self.sync_optimizer()
+        return super().state_dict(*a, **k)
 
     # ------------------------------------------------------------------ forward ----------------------
     def forward(self, input_ids=None, vis_inputs=None, labels=None, decoder_input_ids=None, cate_labels=None,
