@@ -28,6 +28,11 @@ def main():
         print(f"== {k}")
         for c in sorted(row):
             print(f"   {c:40s} {row[c]:16.1f}")
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in row and "GRBM_GUI_ACTIVE" in row:
+            # GRBM_GUI_ACTIVE is reported once per XCD (8 on MI355X) and summed here; 1024 SIMDs on the chip
+            cyc = row["GRBM_GUI_ACTIVE"] / 8.0
+            print(f"   {'-> cycles per launch':40s} {cyc:16.1f}")
+            print(f"   {'-> MfmaUtil % (MFMA busy / (cycles*1024))':40s} {100.0 * row['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024):16.2f}")
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd (.db) kernel trace: per-kernel calls / total / average / share, like `--stats`.
-usage: python tools/rocpd_stats.py results.db [--steps N] > profiles/summary.txt"""
+usage: python tools/rocpd_stats.py results.db [--steps N] > profiles/summary.txt   (steps default: counted from the trace)"""
 import re
 import sqlite3
 import sys
@@ -20,8 +20,11 @@ def main():
     total = sum(r[2] for r in rows)
     span = list(cur.execute("select min(start), max(end) from rocpd_kernel_dispatch"))[0]
     print(f"# kernels: {sum(r[1] for r in rows)} dispatches, {total / 1e6:.3f} ms busy, span {(span[1] - span[0]) / 1e6:.3f} ms")
+    if steps is None:                                   # one sqnorm_kernel launch per optimizer step
+        steps = next((r[1] for r in rows if "sqnorm_kernel" in r[0] and "final" not in r[0]), None)
     if steps:
-        print(f"# per step (/{steps} incl. warm-up): {total / 1e6 / steps:.3f} ms kernel time")
+        print(f"# {steps} optimizer steps in the trace (timed + warm-up + the PCIe-inclusive side loop): "
+              f"{total / 1e6 / steps:.3f} ms kernel time per step")
     print(f"{'kernel':90s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>9s} {'min_us':>8s} {'max_us':>8s} {'%':>6s}")
     for name, n, tot, mn, mx in rows:
         short = re.sub(r"\(anonymous namespace\)::", "", name)
