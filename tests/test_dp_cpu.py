@@ -32,6 +32,7 @@ def _worker(rank, world, port, q):
                         device="cpu")
         before = model.flat_params().clone()
         dp = DataParallelVLT5(model)
+        assert model.proto.dist_enabled and model.proto.dist_group is None, "default group: the statistics must still be reduced"
         gathered = [torch.zeros_like(before) for _ in range(world)]
         dist.all_gather(gathered, model.flat_params())
         assert torch.equal(gathered[0], gathered[1]), "weights must be identical after construction"

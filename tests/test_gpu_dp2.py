@@ -1,0 +1,140 @@
+"""Two data-parallel RANKS on ONE GPU (both processes use cuda:0, collectives through gloo on CUDA tensors): the whole
+multi-rank path of `vqacl_amd.parallel` -- weight broadcast, gradient buckets released by the engine's HIP events, the comm
+stream, the prototype-statistics all-reduce, the fused optimizer after the reduction -- runs with the real kernels and is
+compared against ONE process on the concatenated batch ("N ranks x b == 1 process x N*b").  RCCL itself cannot
+place two ranks on one device; the single-rank RCCL run of the same code path is in test_gpu_model.py, and the collective
+semantics on CPU in test_dp_cpu.py.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(ocfg, params, dev):
+    from vqacl_amd import VLT5VQA, VLT5Config
+    cfg = VLT5Config(d_model=ocfg.d_model, d_kv=ocfg.d_kv, num_heads=ocfg.num_heads, d_ff=ocfg.d_ff, num_layers=ocfg.num_layers,
+                     num_decoder_layers=ocfg.num_decoder_layers, vocab_size=ocfg.vocab_size, feat_dim=ocfg.feat_dim,
+                     dropout_rate=0.0, n_ques=ocfg.n_ques, n_cate=ocfg.n_cate)
+    m = VLT5VQA(cfg, device=dev)
+    m.load_state_dict({k: v.detach() for k, v in params.items()}, strict=False)
+    return m
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        from oracle import ref_cpu as R
+        from vqacl_amd import FusedAdamW, reference_param_groups
+        from vqacl_amd.parallel import DataParallelVLT5
+        ocfg = R.tiny_cfg()
+        params = R.init_params(ocfg, seed=77)
+        full = R.synthetic_batch(ocfg, B=8, L=12, V=36, T=4, seed=5)
+        b = full["input_ids"].shape[0] // world
+        mine = {k: (v[rank * b:(rank + 1) * b] if torch.is_tensor(v) else v) for k, v in full.items()}
+
+        # every rank starts from DIFFERENT weights: the wrapper must install rank 0's
+        wrong = {k: (v + 0.01 * rank) for k, v in params.items()}
+        model = _model(ocfg, wrong, dev)
+        model.train()
+        dp = DataParallelVLT5(model, bucket_mb=0.05)          # tiny buckets: several collectives interleaved with backward
+        opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-3, eps=1e-6, max_grad_norm=5.0)
+        losses, grads0 = [], None
+        for it in range(3):
+            res = dp.train_step(mine, 0, 0.5, 0.3)
+            res["loss"].backward()
+            if it == 0:
+                torch.cuda.synchronize()
+                grads0 = model.flat_grads().clone()
+            opt.step()
+            for p in model.parameters():
+                p.grad = None
+            losses.append(float(res["loss"]))
+        torch.cuda.synchronize()
+        flat = model.flat_params().clone()
+        protoQ = model.Q_prototype.clone()
+
+        # all ranks hold the same weights and prototypes after three steps
+        other = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(other, flat)
+        assert all(torch.equal(o, other[0]) for o in other), "ranks diverged"
+        pq = [torch.zeros_like(protoQ) for _ in range(world)]
+        dist.all_gather(pq, protoQ)
+        assert all(torch.allclose(o, pq[0], atol=1e-6) for o in pq), "prototypes diverged"
+
+        if rank == 0:
+            # one process on the concatenated batch
+            ref = _model(ocfg, params, dev)
+            ref.train()
+            ropt = FusedAdamW(reference_param_groups(ref, 0.01), ref, lr=1e-3, eps=1e-6, max_grad_norm=5.0)
+            rl, rg0 = [], None
+            for it in range(3):
+                r = ref.train_step(full, 0, 0.5, 0.3)
+                r["loss"].backward()
+                if it == 0:
+                    torch.cuda.synchronize()
+                    rg0 = ref.flat_grads().clone()
+                ropt.step()
+                for p in ref.parameters():
+                    p.grad = None
+                rl.append(float(r["loss"]))
+            torch.cuda.synchronize()
+
+            def cosine(a, c):
+                return float(torch.dot(a.flatten(), c.flatten()) / (a.norm() * c.norm()).clamp(min=1e-30))
+            assert cosine(grads0, rg0) > 0.9995, cosine(grads0, rg0)                  # mean of rank gradients == full-batch gradient
+            assert abs(float(grads0.norm() / rg0.norm()) - 1.0) < 1e-2
+            assert cosine(flat, ref.flat_params()) > 0.999999
+            assert float((flat - ref.flat_params()).abs().max()) < 5e-3               # lr 1e-3 x 3 steps bounds any difference
+            assert torch.allclose(protoQ, ref.Q_prototype, atol=2e-2), float((protoQ - ref.Q_prototype).abs().max())
+            # the rank-local loss is the mean over b, the reference's over N*b: rank 0's differs, the mean over ranks matches
+        lt = torch.tensor(losses, device=dev)
+        dist.all_reduce(lt)
+        if rank == 0:
+            for a, c in zip((lt / world).tolist(), rl):
+                assert abs(a - c) < 2e-2, (lt.tolist(), rl)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_equal_one_process_on_the_concatenated_batch():
+    assert torch.cuda.is_available()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=420) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

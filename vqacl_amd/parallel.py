@@ -23,6 +23,7 @@ class DataParallelVLT5:
         self.average = average
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         model.dp = self
+        model.proto.dist_enabled = True
         model.proto.dist_group = process_group
         # bucket b covers flat elements [start_b, end_b)
         ends = {}

@@ -22,7 +22,8 @@ class PrototypeHead:
         self.V_prototype_num = torch.zeros(n_cate, **z)
         self.seen_tasks = set()            # keys of the reference's Q_task_cur_proto
         self.Q_task_mem_proto = {}         # task -> [CQ,d] memory tensor (reference name)
-        self.dist_group = None             # set by DataParallelVLT5: statistics are summed over ranks
+        self.dist_enabled = False          # set by DataParallelVLT5: statistics are summed over ranks ...
+        self.dist_group = None             # ... of this process group (None = the default group)
 
     def reset(self):
         self.seen_tasks.clear()
@@ -32,7 +33,7 @@ class PrototypeHead:
     def update(self, poolQ, poolV, ques_labels, cate_labels, task: int, alpha: float, beta: float):
         curQ, numQ = ops.proto_class_mean(poolQ, ques_labels)
         curV, numV = ops.proto_class_mean(poolV, cate_labels)
-        if self.dist_group is not None:
+        if self.dist_enabled:
             curQ, numQ = self._allreduce_stats(curQ, numQ)
             curV, numV = self._allreduce_stats(curV, numV)
         first = task not in self.seen_tasks
