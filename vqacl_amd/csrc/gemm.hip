@@ -187,18 +187,18 @@ __device__ __forceinline__ void glds_km_piece(const bf16_t* __restrict__ base, i
 }
 
 // scheduling pattern of the interleaved k-step of the 8-wave kernel (see kstep_big): instruction groups in issue order
-template <int FM, int FN, int RA, int RB, int I>
+template <int FM, int FN, int RA, int RB, bool EARLY, int I>
 __device__ __forceinline__ void pin_ks0() {                 // ks = 0 MFMAs of fragment row I, then the ks = 1 fragments it frees room for
     __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, RA + (I < FN ? RB : 0), 0);
-    if constexpr (I & 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-    if constexpr (I + 1 < FM) pin_ks0<FM, FN, RA, RB, I + 1>();
+    if constexpr (EARLY || (I & 1)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    if constexpr (I + 1 < FM) pin_ks0<FM, FN, RA, RB, EARLY, I + 1>();
 }
-template <int FM, int FN, int I>
+template <int FM, int FN, bool EARLY, int I>
 __device__ __forceinline__ void pin_ks1() {
     __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
-    if constexpr (I & 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-    if constexpr (I + 1 < FM) pin_ks1<FM, FN, I + 1>();
+    if constexpr (!EARLY && (I & 1)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    if constexpr (I + 1 < FM) pin_ks1<FM, FN, EARLY, I + 1>();
 }
 
 // WM x WN waves share a BM x BN tile: 2x2 (256 threads) for tiles up to 128x128, 2x4 (512 threads) for 256x256.
@@ -290,10 +290,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     // k-step of the 8-wave 256x256 kernel (64 MFMAs, 24 fragment reads, 8 LDS-DMA pieces per wave), finely interleaved: all
     // waves of the workgroup run in lockstep behind the barrier, so whatever a wave issues in a bunch (the 8 DMA pieces cost
     // ~100+ issue cycles each, the fragment reads have ~100 cycles of latency) leaves the matrix pipe of its SIMD idle.
-    // Order: ks=0 fragments; then per fragment row 4 MFMAs followed by the ks=1 fragment reads whose registers that row
-    // frees and, every second row, one DMA piece of the NEXT k-tile; then the ks=1 MFMAs with the other 4 pieces.
+    // Order: ks=0 fragments; then per fragment row FN MFMAs followed by the ks=1 fragment reads whose registers that row
+    // frees and a DMA piece of the NEXT k-tile; then the ks=1 MFMAs.
+    // Row-major operands: all FM pieces go into the first half, so the ks = 1 MFMAs cover their latency before the next step's
+    // vmcnt(0) (-6 % per launch); with a k-major operand (two transpose reads per fragment) spreading them over both halves
+    // measured better.
+    constexpr bool EARLY = !AKM && !BKM;
     auto kstep_big = [&](int stage, int kt_pf, int s_pf) {
-        static_assert(FM * 8 / 8 >= 1, "");
         const char* at = smem + stage * STAGE_BYTES;
         const char* bt = at + A_BYTES;
         bf16x8_t fa0[FM], fb0[FN], fa1[FM], fb1[FN];
@@ -307,18 +310,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
             for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
             fa1[i] = ldA(at, i, 1);
             if (i < FN) fb1[i] = ldB(bt, i, 1);
-            if (i & 1) glds_piece(kt_pf, s_pf, i >> 1);
+            if (EARLY) glds_piece(kt_pf, s_pf, i);             // all FM pieces in the first half: the ks = 1 MFMAs cover their latency
+            else if (i & 1) glds_piece(kt_pf, s_pf, i >> 1);
         }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
-            if (i & 1) glds_piece(kt_pf, s_pf, FM / 2 + (i >> 1));
+            if (!EARLY && (i & 1)) glds_piece(kt_pf, s_pf, FM / 2 + (i >> 1));
         }
         constexpr int RA = AKM ? 2 : 1, RB = BKM ? 2 : 1;
         __builtin_amdgcn_sched_group_barrier(0x100, FM * RA + FN * RB, 0);
-        pin_ks0<FM, FN, RA, RB, 0>();
-        pin_ks1<FM, FN, 0>();
+        pin_ks0<FM, FN, RA, RB, EARLY, 0>();
+        pin_ks1<FM, FN, EARLY, 0>();
     };
     auto compute = [&](int stage) {
         const char* at = smem + stage * STAGE_BYTES;
