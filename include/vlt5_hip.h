@@ -104,7 +104,7 @@ int vlt5_attn_bwd(const vlt5_attn_desc* d, void* stream);
  * The integer bucket table lut[Lq*Lk] is computed on the host (vqacl_amd/buckets.py, bit-exact
  * with the library); the kernel gathers table[lut[i,j], h] into bias[h,i,j]. */
 int vlt5_relbias_build(const float* table, const int* lut, float* bias, int H, int Lq, int Lk, int nbuckets, void* stream);
-/* dtable[bucket,h] (+)= sum over nmat matrices and positions of dS[mat,h,i,j];  scratch f32 [16*H*Lq*Lk] */
+/* dtable[bucket,h] (+)= sum over nmat matrices and positions of dS[mat,h,i,j];  scratch f32 [64*H*Lq*Lk] */
 int vlt5_relbias_bwd(const float* dS, const int* lut, float* dtable, float* scratch, int nmat, int H, int Lq, int Lk,
                      int nbuckets, int accum, void* stream);
 
@@ -137,6 +137,11 @@ int vlt5_vis_embed_bwd(const float* dout, long long sb, long long st, const floa
                        void* dG_bf16, float* partial, float* dshared, int B, int V, int d, int vocab,
                        float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* stream);
 int vlt5_vis_embed_bwd_blocks(int rows);
+/* reduced = column sums of the partial rows (vlt5_colsum over all 10*d columns) -> the six visual-embedding parameter
+ * gradients: feat LN weight [d], pos LN weight [d], pos bias [d], pos weight [d,5], img_order_embedding [n_images,d]
+ * (row 0 only, others zero), feat bias [d]. */
+int vlt5_vis_grad_scatter(const float* reduced, float* g_lnf, float* g_lnp, float* g_bp, float* g_wp, float* g_img,
+                          float* g_bf, int d, int n_images, void* stream);
 /* out[c] (+)= sum_blk partial[blk*row_stride + c], c < width  (fixed summation order) */
 int vlt5_colsum(const float* partial, float* out, int nblk, int width, int row_stride, int accum, void* stream);
 

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "vlt5_vis_embed_fwd": (c_i, [vp] * 9 + [c_ll, c_ll, vp, vp, c_i, c_i, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),
     "vlt5_vis_embed_bwd": (c_i, [vp, c_ll, c_ll] + [vp] * 11 + [c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp]),
     "vlt5_vis_embed_bwd_blocks": (c_i, [c_i]),
+    "vlt5_vis_grad_scatter": (c_i, [vp, vp, vp, vp, vp, vp, vp, c_i, c_i, vp]),
     "vlt5_colsum": (c_i, [vp, vp, c_i, c_i, c_i, c_i, vp]),
     "vlt5_ce_fwd": (c_i, [vp, vp, vp, vp, c_i, c_i, vp]),
     "vlt5_loss_reduce": (c_i, [vp, vp, vp, vp, vp, c_i, c_i, vp]),

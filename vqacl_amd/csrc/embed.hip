@@ -214,16 +214,31 @@ __global__ void vis_bwd_obj_kernel(const float* __restrict__ dout, long long sb,
     const int i = blockIdx.y;
     if (c >= d) return;
     const float dsc = drop_scale(thr);
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) {
+    auto term = [&](int b) {
         float g = dout[b * sb + i * st + c];
         if (thr) {
             uint32_t idx = (uint32_t)(((size_t)b * drop_rows + drop_row0 + i) * d + c);
             g = drop_keep(seed, idx, thr) ? g * dsc : 0.f;
         }
-        s += g;
-    }
+        return g;
+    };
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four loads in flight; fixed order
+    int b = 0;
+    for (; b + 3 < B; b += 4) { s0 += term(b); s1 += term(b + 1); s2 += term(b + 2); s3 += term(b + 3); }
+    for (; b < B; ++b) s0 += term(b);
+    const float s = (s0 + s1) + (s2 + s3);
     dshared[(size_t)(vocab - 1 - i) * d + c] += s;
+}
+
+// reduced column sums [10*d] (layout of one vis_bwd_cols partial row) -> the six parameter gradients; rows >= 1 of the
+// img_order_embedding gradient are zero (only row 0 is ever looked up, src/modeling_t5_our.py:121-124)
+__global__ void vis_grad_scatter_kernel(const float* __restrict__ red, float* __restrict__ g_lnf, float* __restrict__ g_lnp,
+                                        float* __restrict__ g_bp, float* __restrict__ g_wp, float* __restrict__ g_img,
+                                        float* __restrict__ g_bf, int d, int n_images) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d) { g_lnf[i] = red[i]; g_lnp[i] = red[d + i]; g_bp[i] = red[2 * d + i]; g_bf[i] = red[9 * d + i]; }
+    if (i < 5 * d) g_wp[i] = red[3 * d + i];
+    if (i < n_images * d) g_img[i] = i < d ? red[8 * d + i] : 0.f;
 }
 
 // ---------------- relative position bias ----------------------------------------------------------
@@ -243,17 +258,25 @@ __global__ void relbias_sum_mats_kernel(const float* __restrict__ dS, float* __r
     for (int m = m0; m < m1; ++m) s += dS[(size_t)m * n + i];
     R[(size_t)blockIdx.y * n + i] = s;
 }
-// one wave per (bucket, head): lanes stride over the positions, fixed-order wave reduction
-__global__ void relbias_scatter_kernel(const float* __restrict__ R, const int* __restrict__ lut, float* __restrict__ dtable,
-                                       int H, int npos, int nbuckets, int ngroups, int accum) {
+// one workgroup per (bucket, head): lanes stride over the positions, the four waves over the partial matrices; fixed order
+__global__ __launch_bounds__(256) void relbias_scatter_kernel(const float* __restrict__ R, const int* __restrict__ lut,
+                                                              float* __restrict__ dtable, int H, int npos, int nbuckets, int ngroups,
+                                                              int accum) {
+    __shared__ float part[4];
     const int i = blockIdx.x;                 // bucket * H + h
     const int bucket = i / H, h = i % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float s = 0.f;
-    for (int pos = threadIdx.x; pos < npos; pos += 64)
+    for (int pos = lane; pos < npos; pos += 64)
         if (lut[pos] == bucket)
-            for (int g = 0; g < ngroups; ++g) s += R[((size_t)g * H + h) * npos + pos];
+            for (int g = wave; g < ngroups; g += 4) s += R[((size_t)g * H + h) * npos + pos];
     s = wave_sum(s);
-    if (threadIdx.x == 0) dtable[i] = accum ? dtable[i] + s : s;
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (part[0] + part[1]) + (part[2] + part[3]);
+        dtable[i] = accum ? dtable[i] + t : t;
+    }
 }
 
 }  // namespace
@@ -303,9 +326,10 @@ extern "C" int vlt5_vis_embed_fwd(const float* G, const float* boxes, const floa
     LAUNCH_CHECK();
     return VLT5_OK;
 }
+// row splits of the column-wise pass: ~16 rows per thread (the per-row chain of loads is latency-bound), at most 256
 extern "C" int vlt5_vis_embed_bwd_blocks(int rows) {
-    int s = (rows + 63) / 64;
-    return s < 1 ? 1 : (s > 64 ? 64 : s);
+    int s = (rows + 15) / 16;
+    return s < 1 ? 1 : (s > 256 ? 256 : s);
 }
 extern "C" int vlt5_vis_embed_bwd(const float* dout, long long sb, long long st, const float* G, const float* boxes,
                                   const float* Wp, const float* bp, const float* lnf_w, const float* lnp_w, const float* rstd_f,
@@ -331,6 +355,16 @@ extern "C" int vlt5_vis_embed_bwd(const float* dout, long long sb, long long st,
     return VLT5_OK;
 }
 
+extern "C" int vlt5_vis_grad_scatter(const float* reduced, float* g_lnf, float* g_lnp, float* g_bp, float* g_wp, float* g_img,
+                                     float* g_bf, int d, int n_images, void* stream) {
+    if (!reduced || !g_lnf || !g_lnp || !g_bp || !g_wp || !g_img || !g_bf || d <= 0 || n_images <= 0) return VLT5_ERR_ARG;
+    const int n = (n_images > 5 ? n_images : 5) * d;
+    hipLaunchKernelGGL(vis_grad_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, reduced, g_lnf, g_lnp, g_bp, g_wp, g_img,
+                       g_bf, d, n_images);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+
 extern "C" int vlt5_relbias_build(const float* table, const int* lut, float* bias, int H, int Lq, int Lk, int nbuckets,
                                   void* stream) {
     if (!table || !lut || !bias || H <= 0 || Lq <= 0 || Lk <= 0 || nbuckets <= 0) return VLT5_ERR_ARG;
@@ -343,11 +377,11 @@ extern "C" int vlt5_relbias_bwd(const float* dS, const int* lut, float* dtable, 
                                 int nbuckets, int accum, void* stream) {
     if (!dS || !lut || !dtable || !scratch || nmat <= 0) return VLT5_ERR_ARG;
     int n = H * Lq * Lk;
-    const int ngroups = nmat < 16 ? nmat : 16;                 // scratch holds ngroups partial matrices
+    const int ngroups = nmat < 64 ? nmat : 64;                 // scratch holds ngroups partial matrices
     const int per_group = (nmat + ngroups - 1) / ngroups;
     hipLaunchKernelGGL(relbias_sum_mats_kernel, dim3((n + 255) / 256, ngroups), dim3(256), 0, ST, dS, scratch, nmat, n, per_group);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(relbias_scatter_kernel, dim3(H * nbuckets), dim3(64), 0, ST, scratch, lut, dtable, H, Lq * Lk,
+    hipLaunchKernelGGL(relbias_scatter_kernel, dim3(H * nbuckets), dim3(256), 0, ST, scratch, lut, dtable, H, Lq * Lk,
                        nbuckets, (nmat + per_group - 1) / per_group, accum);
     LAUNCH_CHECK();
     return VLT5_OK;

@@ -189,8 +189,8 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     p.slab_bytes = 8 * wmax * 4;
     p.slab = take(p.slab_bytes);
     p.ln_partial = take((size_t)64 * 320 * d * 4);          // 64 norm slots x <= 320 workgroup partials
-    p.vis_partial = take(((size_t)64 * 10 * d + 2 * (size_t)B * V) * 4);
-    size_t rs = 16 * H * (size_t)(L > T ? L : T) * (L > T ? L : T) * 4;
+    p.vis_partial = take(((size_t)256 * 10 * d + 2 * (size_t)B * V) * 4);   // <= 256 row splits (vlt5_vis_embed_bwd_blocks)
+    size_t rs = 64 * H * (size_t)(L > T ? L : T) * (L > T ? L : T) * 4;
     p.rel_scratch = take(rs);
     p.vis_dG = take((size_t)B * V * d * 2);
     p.small = take(10 * d * 4);
@@ -557,14 +557,9 @@ int encoder_bwd(const Ctx& k) {
                           k.P + L.vis_lnf, k.P + L.vis_lnp, k.w<float>(p.vis_rf), k.w<float>(p.vis_rp), k.w<void>(p.vis_dG), vpart,
                           k.Gr + L.shared, B, s.V, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, s.L, k.st));
     const int nsp = vlt5_vis_embed_bwd_blocks(B * s.V);
-    RC(vlt5_colsum(vpart, k.Gr + L.vis_lnf, nsp, d, 10 * d, 0, k.st));
-    RC(vlt5_colsum(vpart + d, k.Gr + L.vis_lnp, nsp, d, 10 * d, 0, k.st));
-    RC(vlt5_colsum(vpart + 2 * d, k.Gr + L.vis_bp, nsp, d, 10 * d, 0, k.st));
-    RC(vlt5_colsum(vpart + 3 * d, k.Gr + L.vis_wp, nsp, 5 * d, 10 * d, 0, k.st));
-    // img_order_embedding has n_images rows; only row 0 is ever looked up (src/modeling_t5_our.py:121-124)
-    HIP_RET(hipMemsetAsync(k.Gr + L.vis_img, 0, (size_t)c.n_images * d * 4, k.st));
-    RC(vlt5_colsum(vpart + 8 * d, k.Gr + L.vis_img, nsp, d, 10 * d, 0, k.st));
-    RC(vlt5_colsum(vpart + 9 * d, k.Gr + L.vis_bf, nsp, d, 10 * d, 0, k.st));
+    RC(vlt5_colsum(vpart, k.w<float>(p.small), nsp, 10 * d, 10 * d, 0, k.st));
+    RC(vlt5_vis_grad_scatter(k.w<float>(p.small), k.Gr + L.vis_lnf, k.Gr + L.vis_lnp, k.Gr + L.vis_bp, k.Gr + L.vis_wp,
+                             k.Gr + L.vis_img, k.Gr + L.vis_bf, d, c.n_images, k.st));
     RC(k.lin_wgrad(k.w<bf16_t>(p.vis_dG), d, k.w<bf16_t>(p.feats_bf16), c.feat_dim, k.Gr + L.vis_wf, B * s.V, d, c.feat_dim));
     RC(k.ln_flush());
     for (int b = Ld + 1 + (Le > 1 ? Le - Le / 2 : 0); b <= Ld + 1 + Le; ++b) RC(k.record(b));     // lower half + embeddings/norms

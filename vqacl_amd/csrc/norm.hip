@@ -144,6 +144,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         dwp[(size_t)blockIdx.x * d + c] = red[c] + red[d + c] + red[2 * d + c] + red[3 * d + c];
 }
 
+// sum of rows grp, grp+4, grp+8, ... of one column: four independent accumulators so four loads are always in flight (a single
+// dependent chain of ~80 loads is latency-bound); fixed order
+__device__ __forceinline__ float strided_rows_sum(const float* __restrict__ col, size_t row_stride, int grp, int nblk) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = grp;
+    for (; b + 12 < nblk; b += 16) {
+        s0 += col[(size_t)b * row_stride];
+        s1 += col[(size_t)(b + 4) * row_stride];
+        s2 += col[(size_t)(b + 8) * row_stride];
+        s3 += col[(size_t)(b + 12) * row_stride];
+    }
+    for (; b < nblk; b += 4) s0 += col[(size_t)b * row_stride];
+    return (s0 + s1) + (s2 + s3);
+}
+
 // out[c] (+)= sum_blk partial[blk*row_stride + c]: 64 columns per block, 4 row groups reduced through LDS (fixed order)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int width,
                                                      int row_stride, int accum) {
@@ -151,8 +166,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    if (c < width)
-        for (int b = grp; b < nblk; b += 4) s += partial[(size_t)b * row_stride + c];
+    if (c < width) s = strided_rows_sum(partial + c, row_stride, grp, nblk);
     sh[grp][lane] = s;
     __syncthreads();
     if (grp == 0 && c < width) {
@@ -170,8 +184,7 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(const float* __restri
     const int c = blockIdx.x * 64 + lane;
     const float* pj = partial + (size_t)j * slot_rows * width;
     float s = 0.f;
-    if (c < width)
-        for (int b = grp; b < t.nblk[j]; b += 4) s += pj[(size_t)b * width + c];
+    if (c < width) s = strided_rows_sum(pj + c, width, grp, t.nblk[j]);
     sh[grp][lane] = s;
     __syncthreads();
     if (grp == 0 && c < width) out_base[t.out_off[j] + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);

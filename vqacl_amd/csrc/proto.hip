@@ -6,21 +6,49 @@
 
 namespace {
 
-__global__ void pool_kernel(const float* __restrict__ hidden, long long sb, int B, int S, int d, int split, float* __restrict__ poolQ,
-                            float* __restrict__ poolV) {
-    const int b = blockIdx.x;
+// one block of 8 waves per sample: wave w sums tokens w, w+8, ... (independent 16-byte loads, d/256 in flight per lane and
+// token), the eight partial sums meet in LDS.  d % 4 == 0, d <= 2048.
+__global__ __launch_bounds__(512) void pool_kernel(const float* __restrict__ hidden, long long sb, int B, int S, int d, int split,
+                                                   float* __restrict__ poolQ, float* __restrict__ poolV) {
+    extern __shared__ __attribute__((aligned(16))) float psum[];   // [2][8][d]
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nq = min(split, S), nv = S - nq;
-    for (int c = threadIdx.x; c < d; c += blockDim.x) {
-        const float* h = hidden + (size_t)b * sb + c;
+    const float* h = hidden + (size_t)b * sb;
+    float4 aq[8], av[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { aq[j] = make_float4(0.f, 0.f, 0.f, 0.f); av[j] = aq[j]; }
+    for (int s = wave; s < S; s += 8) {
+        const bool isq = s < nq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = lane * 4 + j * 256;
+            if (c < d) {
+                const float4 v = *reinterpret_cast<const float4*>(h + (size_t)s * d + c);
+                if (isq) { aq[j].x += v.x; aq[j].y += v.y; aq[j].z += v.z; aq[j].w += v.w; }
+                else     { av[j].x += v.x; av[j].y += v.y; av[j].z += v.z; av[j].w += v.w; }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane * 4 + j * 256;
+        if (c < d) {
+            *reinterpret_cast<float4*>(psum + (size_t)wave * d + c) = aq[j];
+            *reinterpret_cast<float4*>(psum + (size_t)(8 + wave) * d + c) = av[j];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 512) {
         float sq = 0.f, sv = 0.f;
-        for (int s = 0; s < nq; ++s) sq += h[(size_t)s * d];
-        for (int s = nq; s < S; ++s) sv += h[(size_t)s * d];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { sq += psum[(size_t)w * d + c]; sv += psum[(size_t)(8 + w) * d + c]; }
         poolQ[(size_t)b * d + c] = sq / (float)nq;
         poolV[(size_t)b * d + c] = sv / (float)nv;          // nv == 0 -> NaN, as torch.mean of an empty slice
     }
 }
 
-// one block per class; the (few) members of the class are listed in LDS first so the column loop only visits them
+// one block per class: proto[cls] = onehot[:, cls]^T pool / max(count, 1).  The product is taken over ALL samples (weight 0
+// for non-members, exactly the matrix product of the reference), so the loads of the loop are independent and pipeline.
 __global__ __launch_bounds__(256) void class_mean_kernel(const float* __restrict__ pool, const float* __restrict__ onehot,
                                                          float* __restrict__ proto, float* __restrict__ cnt, int B, int C, int d) {
     extern __shared__ float wgt[];                 // [B] one-hot column of this class
@@ -31,13 +59,15 @@ __global__ __launch_bounds__(256) void class_mean_kernel(const float* __restrict
     for (int b = 0; b < B; ++b) n += wgt[b];
     if (threadIdx.x == 0) cnt[cls] = n;
     const float div = n <= 0.f ? 1.f : n;
-    for (int c = threadIdx.x; c < d; c += blockDim.x) {
-        float s = 0.f;
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
         for (int b = 0; b < B; ++b) {
             const float w = wgt[b];
-            if (w != 0.f) s += w * pool[(size_t)b * d + c];
+            const float4 v = *reinterpret_cast<const float4*>(pool + (size_t)b * d + c);
+            s.x += w * v.x; s.y += w * v.y; s.z += w * v.z; s.w += w * v.w;
         }
-        proto[(size_t)cls * d + c] = s / div;
+        *reinterpret_cast<float4*>(proto + (size_t)cls * d + c) = make_float4(s.x / div, s.y / div, s.z / div, s.w / div);
     }
 }
 
@@ -85,7 +115,7 @@ __global__ __launch_bounds__(256) void retrieve_kernel(const float* __restrict__
                                                        const float* __restrict__ pool, long long* __restrict__ idx,
                                                        float* __restrict__ out_f32, long long sb, bf16_t* __restrict__ out_bf16,
                                                        long long sb16, int B, int C, int d) {
-    extern __shared__ float lds[];                         // [d] tanh(x) then [C] similarities
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [d] tanh(x) then [C] similarities
     float* tx = lds;
     float* sim = lds + d;
     __shared__ float part[4];
@@ -98,12 +128,26 @@ __global__ __launch_bounds__(256) void retrieve_kernel(const float* __restrict__
     if (lane == 0) part[wave] = s;
     __syncthreads();
     const float nb = fmaxf(sqrtf((part[0] + part[1]) + (part[2] + part[3])), 1e-12f);
-    for (int cls = wave; cls < C; cls += 4) {
-        const float* a = An + (size_t)cls * d;
-        float dot = 0.f;
-        for (int c = lane; c < d; c += 64) dot += a[c] * tx[c];
-        dot = wave_sum(dot);
-        if (lane == 0) sim[cls] = dot / nb;
+    // wave w scores classes w, w+4, ...: four classes per round so 4 x (d/256) independent 16-byte loads are in flight per lane
+    for (int cls0 = wave; cls0 < C; cls0 += 16) {
+        float dot[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 t = *reinterpret_cast<const float4*>(tx + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cls = cls0 + 4 * u;
+                if (cls < C) {
+                    const float4 a = *reinterpret_cast<const float4*>(An + (size_t)cls * d + c);
+                    dot[u] += (a.x * t.x + a.y * t.y) + (a.z * t.z + a.w * t.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cls = cls0 + 4 * u;
+            const float r = wave_sum(dot[u]);
+            if (lane == 0 && cls < C) sim[cls] = r / nb;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -147,13 +191,20 @@ __global__ __launch_bounds__(256) void memory_loss_kernel(const float* __restric
 extern "C" int vlt5_proto_pool(const float* hidden, long long sb, int B, int S, int d, int split, float* poolQ, float* poolV,
                                void* stream) {
     if (!hidden || !poolQ || !poolV || B <= 0 || S <= 0 || d <= 0 || split <= 0) return VLT5_ERR_ARG;
-    hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(256), 0, ST, hidden, sb, B, S, d, split, poolQ, poolV);
+    if ((d & 3) || d > 2048 || (sb & 3)) return VLT5_ERR_ALIGN;
+    static bool attr_set = false;                           // 16*d floats of dynamic LDS: above 64 KB for d > 1024
+    if (!attr_set) {
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 4));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(512), 16 * (size_t)d * sizeof(float), ST, hidden, sb, B, S, d, split, poolQ, poolV);
     LAUNCH_CHECK();
     return VLT5_OK;
 }
 extern "C" int vlt5_proto_class_mean(const float* pool, const float* onehot, float* proto, float* cnt, int B, int C, int d,
                                      void* stream) {
     if (!pool || !onehot || !proto || !cnt || B <= 0 || C <= 0) return VLT5_ERR_ARG;
+    if (d & 3) return VLT5_ERR_ALIGN;
     hipLaunchKernelGGL(class_mean_kernel, dim3(C), dim3(256), B * sizeof(float), ST, pool, onehot, proto, cnt, B, C, d);
     LAUNCH_CHECK();
     return VLT5_OK;
@@ -173,6 +224,7 @@ extern "C" int vlt5_proto_update(const float* curQ, const float* curV, const flo
 extern "C" int vlt5_proto_retrieve(const float* protos, const float* pool, long long* idx, float* out_f32, long long sb,
                                    void* out_bf16, long long sb_bf16, float* scratch, int B, int C, int d, void* stream) {
     if (!protos || !pool || !idx || !scratch || B <= 0 || C <= 0) return VLT5_ERR_ARG;
+    if (d & 3) return VLT5_ERR_ALIGN;
     hipLaunchKernelGGL(proto_normalize_kernel, dim3(C), dim3(256), 0, ST, protos, scratch, C, d);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(retrieve_kernel, dim3(B), dim3(256), (d + C) * sizeof(float), ST, protos, scratch, pool, idx, out_f32, sb,

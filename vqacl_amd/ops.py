@@ -142,7 +142,7 @@ def relbias_build(table, lut, H, Lq, Lk):
 def relbias_bwd(dS, lut, nbuckets):
     nmat, H, Lq, Lk = dS.shape
     dtable = torch.empty(nbuckets, H, device=dS.device, dtype=torch.float32)
-    scratch = torch.empty(16 * H * Lq * Lk, device=dS.device, dtype=torch.float32)
+    scratch = torch.empty(64 * H * Lq * Lk, device=dS.device, dtype=torch.float32)
     check(lib().vlt5_relbias_bwd(ptr(dS), ptr(lut), ptr(dtable), ptr(scratch), nmat, H, Lq, Lk, nbuckets, 0, stream_ptr()),
           "vlt5_relbias_bwd")
     return dtable
