@@ -138,7 +138,8 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from oracle.ref_cpu import synthetic_batch, Cfg          # only the synthetic-input recipe and (rank 0) the cpu_baseline leg
     from vqacl_amd import VLT5VQA, VLT5Config, FusedAdamW, reference_param_groups
@@ -194,7 +195,8 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "VL-T5-base VQA v2 train step (fwd+bwd+clip+AdamW), 36x2048 regions, 20 question tokens, "
                                   "5 answer tokens, dropout 0.1", "batch_per_gpu": B, "global_batch": B * world,
-                      "parallelism": f"dp{world}"},
+                      "parallelism": f"dp{world}",
+                      "grad_allreduce": (str(handle.grad_dtype).replace("torch.", "") if distributed else "none")},
            "samples_per_sec_per_gpu": round(value / world, 2), "final_loss": round(final_loss, 4),
            "step_tflops_per_gpu": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms, 2),
            "step_frac_of_mfma_peak": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}

@@ -182,6 +182,8 @@ int vlt5_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, 
                     float beta2, float eps, float weight_decay, int step, const float* total_sq, float max_norm,
                     int hf_mode, void* stream);
 int vlt5_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);
+/* dst = scale * float(src_bf16): the way back from a bf16 gradient all-reduce (vqacl_amd/parallel.py) */
+int vlt5_cast_f32(const void* src_bf16, float* dst, long long n, float scale, void* stream);
 int vlt5_scale_add(float* dst, const float* src, float a, float b, long long n, void* stream); /* dst = a*dst + b*src */
 
 /* dst_bf16 = dropout(src) (inverted, element index r*cols+c) cast to bf16; the bf16 operand of the backward GEMMs */

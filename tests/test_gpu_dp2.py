@@ -35,7 +35,7 @@ def _model(ocfg, params, dev):
     return m
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, grad_dtype):
     try:
         sys.path.insert(0, ROOT)
         import torch.distributed as dist
@@ -56,7 +56,8 @@ def _worker(rank, world, port, q):
         wrong = {k: (v + 0.01 * rank) for k, v in params.items()}
         model = _model(ocfg, wrong, dev)
         model.train()
-        dp = DataParallelVLT5(model, bucket_mb=0.05)          # tiny buckets: several collectives interleaved with backward
+        dp = DataParallelVLT5(model, bucket_mb=0.05,          # tiny buckets: several collectives interleaved with backward
+                              grad_dtype=getattr(torch, grad_dtype))
         opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-3, eps=1e-6, max_grad_norm=5.0)
         losses, grads0 = [], None
         for it in range(3):
@@ -121,12 +122,13 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_on_one_gpu_equal_one_process_on_the_concatenated_batch():
+@pytest.mark.parametrize("grad_dtype", ["float32", "bfloat16"])
+def test_two_ranks_on_one_gpu_equal_one_process_on_the_concatenated_batch(grad_dtype):
     assert torch.cuda.is_available()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, grad_dtype)) for r in range(2)]
     for p in procs:
         p.start()
     try:

@@ -358,12 +358,22 @@ def test_data_parallel_overlap_path_on_one_gpu_and_rank_equivalence(dev):
     try:
         model = make_model(ocfg, params, dev)
         model.train()
-        dp = DataParallelVLT5(model, bucket_mb=0.05)           # tiny buckets: several collectives interleaved with backward
+        dp = DataParallelVLT5(model, bucket_mb=0.05, grad_dtype=torch.float32)   # tiny buckets: several collectives interleaved with backward
         dp.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
         torch.cuda.synchronize()
         # equal up to the summation order of the embedding scatter-add (float atomics)
         assert torch.allclose(model.flat_grads(), g_plain, rtol=1e-4, atol=1e-6)
         assert cos(model.flat_grads(), g_plain) > 0.999999
+        # default on the GPU: buckets travel as bf16 (cast -> all-reduce -> cast back): one bf16 rounding per element
+        model2 = make_model(ocfg, params, dev)
+        model2.train()
+        dp2 = DataParallelVLT5(model2, bucket_mb=0.05)
+        assert dp2.grad_dtype is torch.bfloat16
+        dp2.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
+        torch.cuda.synchronize()
+        g2 = model2.flat_grads()
+        assert cos(g2, g_plain) > 0.99999
+        assert torch.allclose(g2, g_plain, rtol=1.0 / 128, atol=1e-6)
     finally:
         dist.destroy_process_group()
 

@@ -15,8 +15,8 @@ PASSES=(
 )
 i=0
 for p in "${PASSES[@]}"; do
-  for t in 128 256; do
-    rocprofv3 --pmc $p --kernel-trace -d $OUT/p${i}_$t -o r -- python3 tools/gemm_one.py "$@" $t $t 6 > $OUT/log_${i}_$t.txt 2>&1
+  for t in ${TILES:-128 256}; do
+    rocprofv3 --pmc $p --kernel-trace -d $OUT/p${i}_$t -o r -- python3 tools/gemm_one.py "$@" ${t%x*} ${t#*x} 6 > $OUT/log_${i}_$t.txt 2>&1
   done
   i=$((i+1))
 done

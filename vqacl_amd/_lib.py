@@ -86,6 +86,7 @@ PROTOTYPES = {
     "vlt5_sqnorm_blocks": (c_i, [c_ll]),
     "vlt5_adamw_step": (c_i, [vp, vp, vp, vp, vp, c_ll, c_f, c_f, c_f, c_f, c_f, c_i, vp, c_f, c_i, vp]),
     "vlt5_cast_bf16": (c_i, [vp, vp, c_ll, vp]),
+    "vlt5_cast_f32": (c_i, [vp, vp, c_ll, c_f, vp]),
     "vlt5_scale_add": (c_i, [vp, vp, c_f, c_f, c_ll, vp]),
     "vlt5_drop_cast": (c_i, [vp, vp, c_ll, c_i, c_f, c_u32, vp]),
     "vlt5_layout_count": (c_i, [C.POINTER(Config)]),

@@ -106,6 +106,24 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
     }
 }
 
+// dst = scale * float(src): the way back from a bf16 gradient all-reduce (scale = 1/world averages)
+__global__ __launch_bounds__(256) void uncast_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long long n, float scale) {
+    const long long stride = (long long)gridDim.x * blockDim.x * 8;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 7 < n) {
+            const uint4 a = *reinterpret_cast<const uint4*>(src + i);
+            const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { o[2 * k] = __uint_as_float(w[k] << 16) * scale; o[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u) * scale; }
+            *reinterpret_cast<float4*>(dst + i) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(dst + i + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        } else {
+            for (long long k = i; k < n; ++k) dst[k] = bf16_to_f32(src[k]) * scale;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void scale_add_kernel(float* __restrict__ dst, const float* __restrict__ src, float a, float b,
                                                         long long n) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -167,6 +185,13 @@ extern "C" int vlt5_cast_bf16(const float* src, void* dst_bf16, long long n, voi
     if (!src || !dst_bf16 || n <= 0) return VLT5_ERR_ARG;
     if ((((uintptr_t)src) | ((uintptr_t)dst_bf16)) & 15) return VLT5_ERR_ALIGN;
     hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n, 8)), dim3(256), 0, ST, src, (bf16_t*)dst_bf16, n);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_cast_f32(const void* src_bf16, float* dst, long long n, float scale, void* stream) {
+    if (!src_bf16 || !dst || n <= 0) return VLT5_ERR_ARG;
+    if ((((uintptr_t)src_bf16) | ((uintptr_t)dst)) & 15) return VLT5_ERR_ALIGN;
+    hipLaunchKernelGGL(uncast_kernel, dim3(grid_for(n, 8)), dim3(256), 0, ST, (const bf16_t*)src_bf16, dst, n, scale);
     LAUNCH_CHECK();
     return VLT5_OK;
 }

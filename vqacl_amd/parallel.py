@@ -8,6 +8,12 @@ the comm stream waits on the event and all-reduces that slice while the compute 
 layer (overlap with backward).  xGMI is point-to-point, so few, large collectives are preferred: consecutive
 layer buckets are merged up to `bucket_mb`.
 
+`grad_dtype=torch.bfloat16` (default on the GPU) halves the bytes on the links: each merged bucket is cast to a bf16 staging
+buffer, all-reduced in bf16 and cast back (scaled by 1/world) into the fp32 gradient buffer on the comm stream, so clipping,
+the optimizer and `.grad` see fp32 as before.  At 8 GPUs the fp32 reduction of 0.9 GB is ~5 ms of ring time per step against
+~6.5 ms of backward to hide it in; bf16 needs half.  (The rounding -- one bf16 rounding per rank contribution -- is of the same
+size as the bf16 GEMM noise already in the gradients.)
+
 Also all-reduces the prototype sufficient statistics (class sums and counts) so that every rank holds the
 prototypes a single process would compute on the concatenated batch.
 """
@@ -16,8 +22,14 @@ import torch.distributed as dist
 
 
 class DataParallelVLT5:
-    def __init__(self, model, process_group=None, bucket_mb=128, average=True):
+    def __init__(self, model, process_group=None, bucket_mb=128, average=True, grad_dtype=None):
         self.module = model
+        if grad_dtype is None:
+            grad_dtype = torch.bfloat16 if model._flat.is_cuda else torch.float32
+        if grad_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("grad_dtype must be torch.float32 or torch.bfloat16")
+        self.grad_dtype = grad_dtype
+        self._g16 = None
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.average = average
@@ -55,6 +67,16 @@ class DataParallelVLT5:
 
     def _allreduce_slice(self, flat, a, b):
         t = flat[a:b]
+        if self.grad_dtype is torch.bfloat16 and flat.is_cuda:
+            from ._lib import check, lib, ptr, stream_ptr
+            if self._g16 is None or self._g16.numel() < flat.numel():
+                self._g16 = torch.empty(flat.numel(), device=flat.device, dtype=torch.bfloat16)
+            h = self._g16[a:b]
+            check(lib().vlt5_cast_bf16(ptr(t), ptr(h), b - a, stream_ptr()), "vlt5_cast_bf16")
+            dist.all_reduce(h, group=self.group)
+            check(lib().vlt5_cast_f32(ptr(h), ptr(t), b - a, 1.0 / self.world if self.average else 1.0, stream_ptr()),
+                  "vlt5_cast_f32")
+            return
         dist.all_reduce(t, group=self.group)
         if self.average:
             t.div_(self.world)
