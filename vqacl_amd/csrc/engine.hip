@@ -549,7 +549,10 @@ int encoder_bwd(const Ctx& k) {
     }
     RC(vlt5_relbias_bwd(k.w<float>(p.dS_enc), s.enc_lut, k.Gr + L.enc_rel, k.w<float>(p.rel_scratch), Le * B, k.H, s.L, s.L,
                         c.rel_buckets, 0, k.st));
-    RC(enc_wgrads(k, 0, Le > 1 ? Le / 2 : Le));          // lower half of the stack (the upper half was flushed mid-way)
+    // (a third flush group of Le/4 layers was measured: batches of 3 layers fill the chip too poorly, +4 % step time)
+    const int low_end = Le > 1 ? Le / 2 : Le;
+    RC(enc_wgrads(k, 0, low_end));                        // lower half of the stack (the upper half was flushed mid-way)
+    for (int b = Ld + 1 + (Le - low_end); b <= Ld + Le; ++b) RC(k.record(b));
     // inputs: text rows -> shared (scatter-add), visual rows -> visual embedding parameters
     RC(vlt5_embed_bwd(s.input_ids, dx, (long long)S * d, d, k.Gr + L.shared, B, s.L, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, 0, k.st));
     float* vpart = k.w<float>(p.vis_partial);
@@ -562,7 +565,7 @@ int encoder_bwd(const Ctx& k) {
                              k.Gr + L.vis_img, k.Gr + L.vis_bf, d, c.n_images, k.st));
     RC(k.lin_wgrad(k.w<bf16_t>(p.vis_dG), d, k.w<bf16_t>(p.feats_bf16), c.feat_dim, k.Gr + L.vis_wf, B * s.V, d, c.feat_dim));
     RC(k.ln_flush());
-    for (int b = Ld + 1 + (Le > 1 ? Le - Le / 2 : 0); b <= Ld + 1 + Le; ++b) RC(k.record(b));     // lower half + embeddings/norms
+    RC(k.record(Ld + 1 + Le));                            // embeddings + norms + visual embedding
     return VLT5_OK;
 }
 

@@ -495,7 +495,12 @@ class VLT5(nn.Module):
             self.dp.reduce_ready(self, events, upto=self.cfg.num_decoder_layers + 1)
         check(lib().vlt5_encoder_bwd(C.byref(c), C.byref(cs), stream), "vlt5_encoder_bwd")
         if events is not None:
-            self.dp.reduce_ready(self, events, upto=self._nbuckets)
+            # collectives are cut where the engine releases gradients (upper half / lower half of the encoder, then
+            # embeddings + norms), so a merged bucket never waits for a later group than its own
+            Ld, Le = self.cfg.num_decoder_layers, self.cfg.num_layers
+            cuts = [Ld + 1 + (Le - Le // 2)] if Le > 1 else []
+            for upto in cuts + [Ld + 1 + Le, self._nbuckets]:
+                self.dp.reduce_ready(self, events, upto=upto)
             self.dp.finish()
         elif self.dp is not None:
             self.dp.reduce_flat(target)
