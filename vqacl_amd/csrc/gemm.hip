@@ -207,6 +207,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;                 // wave tile
     constexpr int FM = TM / 16, FN = TN / 16;                 // 16x16 fragments per wave
+    constexpr int LPT = (BM + BN) * 8 / NT;                   // LDS-DMA wave-instructions ("pieces") per k-tile per wave
+    // k-major operands on the 4-wave tiles up to 64x128: the transpose reads are 8-byte-per-lane LDS reads, which need many
+    // reads in flight per wave to approach the LDS rate -- fetch the fragments of BOTH 32-wide halves up front (and spread
+    // the DMA pieces between the MFMAs).  Measured -20..-40 % on dgrad / wgrad shapes; the same scheme costs 5-10 % on
+    // row-major short-K shapes and too many registers at 128x128, so it is applied only here.
+    constexpr bool KM_STEP = (AKM || BKM) && (WM * WN == 4) && (BM + BN <= 192);
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;        // stage s: A tile at s*STAGE_BYTES, B tile right after it
@@ -287,6 +293,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         if (BKM) return frag_km<BN>(bt, r0, ks, lane);
         return *reinterpret_cast<const bf16x8_t*>(bt + lds_off(r0 + lrow, ks * 4 + lg));
     };
+    auto kstep_km = [&](int stage, int kt_pf, int s_pf) {
+        const char* at = smem + stage * STAGE_BYTES;
+        const char* bt = at + A_BYTES;
+        bf16x8_t fa[2][FM], fb[2][FN];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[ks][i] = ldA(at, i, ks);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[ks][j] = ldB(bt, j, ks);
+        }
+        constexpr int NMF = 2 * FM * FN;                    // MFMAs of the k-step
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {
+#pragma unroll
+            for (int pc = 0; pc < LPT; ++pc)
+                if (pc * NMF / LPT == q) glds_piece(kt_pf, s_pf, pc);      // piece pc goes in front of MFMA number pc*NMF/LPT
+            const int ks = q / (FM * FN), i = (q / FN) % FM, j = q % FN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+        }
+    };
     // k-step of the 8-wave 256x256 kernel (64 MFMAs, 24 fragment reads, 8 LDS-DMA pieces per wave), finely interleaved: all
     // waves of the workgroup run in lockstep behind the barrier, so whatever a wave issues in a bunch (the 8 DMA pieces cost
     // ~100+ issue cycles each, the fragment reads have ~100 cycles of latency) leaves the matrix pipe of its SIMD idle.
@@ -355,15 +382,36 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     // s_waitcnt vmcnt(LPT) at the top of an iteration only waits for the OLDER group, so a whole iteration of MFMAs covers
     // the memory latency.  One raw s_barrier per k-step (it both publishes tile i and retires the reads of tile i-1, whose
     // stage is the one refilled next).  A partial last k-tile (K % 64 != 0) goes through registers with zero fill.
-    constexpr int LPT = (BM + BN) * 8 / NT;                // glds instructions per tile per wave
     const bool has_tail = (kt1 == nk_total) && (p.K % BK != 0) && (kt1 > kt0);
     const int nmain = (kt1 - kt0) - (has_tail ? 1 : 0);
+    if constexpr (KM_STEP) {
+        if (nmain > 0) {
 #pragma unroll
-    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
-        if (s0 < nmain) glds(kt0 + s0, s0);
+            for (int s0 = 0; s0 < NSTAGE - 1; ++s0) glds(min(kt0 + s0, kt0 + nmain - 1), s0);   // always NSTAGE-1 k-tiles in flight
+        }
+    } else {
+#pragma unroll
+        for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+            if (s0 < nmain) glds(kt0 + s0, s0);
+    }
     int stage = 0, fill = NSTAGE - 1;                      // stage of tile i, stage that tile i+NSTAGE-1 goes to
     TL(1);
-    if constexpr (WM * WN == 8) {
+    if constexpr (KM_STEP) {
+        // branch-free steps (see the 8-wave loop below): the last NSTAGE-1 steps re-request the final k-tile, so the counted
+        // vmcnt is a constant and the whole step is one scheduling region
+        for (int i = 0; i < nmain; ++i) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * (NSTAGE - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();
+#ifdef GEMM_TIMELINE
+            if (i == 0) TL(2);
+#endif
+            kstep_km(stage, min(kt0 + i + NSTAGE - 1, kt0 + nmain - 1), fill);
+            stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
+            fill = (fill + 1 == NSTAGE) ? 0 : fill + 1;
+        }
+        if (nmain > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus prefetches land before LDS is reused / the wave ends
+        if (has_tail) __syncthreads();
+    } else if constexpr (WM * WN == 8) {
         // 8-wave kernel: two stages, branch-free steps.  Every step prefetches; the last one re-requests the final k-tile into
         // the stage that was just retired (harmless, L2-resident) instead of branching around the loads, which keeps the
         // whole step one scheduling region.
@@ -663,6 +711,8 @@ extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
         // (also for a small output with a very long reduction cut into slices by vlt5_gemm_auto_split: the input gradients
         // of lm_head and of the stacked cross-attention K/V projection)
         if (!d->a_kmajor && (tiles(256, 256) >= 200 || (d->K >= 8192 && d->split_k > 1 && tiles(256, 256) >= 128))) { bm = 256; bn = 256; }
+        // (with k-major operands the 64-wide tiles run the deeper fragment pipeline, KM_STEP, and win below this threshold;
+        // above it -- the layer-batched weight gradients -- 128 x 128 is still 25 % faster)
         else if (tiles(128, 128) >= 768) { bm = 128; bn = 128; }       // >= 3 workgroups per CU of the big tile
         else if (tiles(64, 128) >= 256) { bm = 64; bn = 128; }         // 3-stage ring, 2 workgroups per CU
         else { bm = 64; bn = 64; }                                     // small-M (decoder) problems: most workgroups
