@@ -186,19 +186,31 @@ __device__ __forceinline__ void glds_km_piece(const bf16_t* __restrict__ base, i
     __builtin_amdgcn_global_load_lds(base + (size_t)(k0 + k) * ld + gr, (lds_ptr_t)(tile + (i * NT + wave_base) * 16), 16, 0, 0);
 }
 
-// scheduling pattern of the interleaved k-step of the 8-wave kernel (see kstep_big): instruction groups in issue order
-template <int FM, int FN, int RA, int RB, bool EARLY, int I>
+// DMA pieces of the interleaved k-step (kstep_big): piece p of LPT is issued after the MFMAs of half-step row
+// piece_row(p) in [0, 2*FM) -- spread evenly over both halves, or (EARLY) over the first half only.
+template <int FM, int LPT, bool EARLY>
+__host__ __device__ constexpr int piece_row(int p) { return EARLY ? p * FM / LPT : p * 2 * FM / LPT; }
+template <int FM, int LPT, bool EARLY>
+__host__ __device__ constexpr int pieces_in_row(int r) {
+    int n = 0;
+    for (int p = 0; p < LPT; ++p) n += (piece_row<FM, LPT, EARLY>(p) == r) ? 1 : 0;
+    return n;
+}
+// scheduling pattern of the interleaved k-step (see kstep_big): instruction groups in issue order
+template <int FM, int FN, int LPT, int RA, int RB, bool EARLY, int I>
 __device__ __forceinline__ void pin_ks0() {                 // ks = 0 MFMAs of fragment row I, then the ks = 1 fragments it frees room for
     __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, RA + (I < FN ? RB : 0), 0);
-    if constexpr (EARLY || (I & 1)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-    if constexpr (I + 1 < FM) pin_ks0<FM, FN, RA, RB, EARLY, I + 1>();
+    constexpr int NP = pieces_in_row<FM, LPT, EARLY>(I);
+    if constexpr (NP > 0) __builtin_amdgcn_sched_group_barrier(0x010, NP, 0);
+    if constexpr (I + 1 < FM) pin_ks0<FM, FN, LPT, RA, RB, EARLY, I + 1>();
 }
-template <int FM, int FN, bool EARLY, int I>
+template <int FM, int FN, int LPT, bool EARLY, int I>
 __device__ __forceinline__ void pin_ks1() {
     __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
-    if constexpr (!EARLY && (I & 1)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-    if constexpr (I + 1 < FM) pin_ks1<FM, FN, EARLY, I + 1>();
+    constexpr int NP = pieces_in_row<FM, LPT, EARLY>(FM + I);
+    if constexpr (NP > 0) __builtin_amdgcn_sched_group_barrier(0x010, NP, 0);
+    if constexpr (I + 1 < FM) pin_ks1<FM, FN, LPT, EARLY, I + 1>();
 }
 
 // WM x WN waves share a BM x BN tile: 2x2 (256 threads) for tiles up to 128x128, 2x4 (512 threads) for 256x256.
@@ -213,6 +225,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     // the DMA pieces between the MFMAs).  Measured -20..-40 % on dgrad / wgrad shapes; the same scheme costs 5-10 % on
     // row-major short-K shapes and too many registers at 128x128, so it is applied only here.
     constexpr bool KM_STEP = (AKM || BKM) && (WM * WN == 4) && (BM + BN <= 192);
+    // the 8-wave 256x256 kernel runs the hand-interleaved k-step (kstep_big).  (Tried for 4-wave 128x128 with both operands
+    // k-major, the layer-batched weight gradients: 385 -> 650 us, the fragment double buffer pushes it into AGPR spills.)
+    constexpr bool BIG_STEP = (WM * WN == 8);
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;        // stage s: A tile at s*STAGE_BYTES, B tile right after it
@@ -337,19 +352,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
             for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
             fa1[i] = ldA(at, i, 1);
             if (i < FN) fb1[i] = ldB(bt, i, 1);
-            if (EARLY) glds_piece(kt_pf, s_pf, i);             // all FM pieces in the first half: the ks = 1 MFMAs cover their latency
-            else if (i & 1) glds_piece(kt_pf, s_pf, i >> 1);
+#pragma unroll
+            for (int pc = 0; pc < LPT; ++pc)
+                if (piece_row<FM, LPT, EARLY>(pc) == i) glds_piece(kt_pf, s_pf, pc);
         }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
-            if (!EARLY && (i & 1)) glds_piece(kt_pf, s_pf, FM / 2 + (i >> 1));
+#pragma unroll
+            for (int pc = 0; pc < LPT; ++pc)
+                if (piece_row<FM, LPT, EARLY>(pc) == FM + i) glds_piece(kt_pf, s_pf, pc);
         }
         constexpr int RA = AKM ? 2 : 1, RB = BKM ? 2 : 1;
         __builtin_amdgcn_sched_group_barrier(0x100, FM * RA + FN * RB, 0);
-        pin_ks0<FM, FN, RA, RB, EARLY, 0>();
-        pin_ks1<FM, FN, EARLY, 0>();
+        pin_ks0<FM, FN, LPT, RA, RB, EARLY, 0>();
+        pin_ks1<FM, FN, LPT, EARLY, 0>();
     };
     auto compute = [&](int stage) {
         const char* at = smem + stage * STAGE_BYTES;
@@ -411,11 +429,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         }
         if (nmain > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus prefetches land before LDS is reused / the wave ends
         if (has_tail) __syncthreads();
-    } else if constexpr (WM * WN == 8) {
+    } else if constexpr (BIG_STEP) {
         // 8-wave kernel: two stages, branch-free steps.  Every step prefetches; the last one re-requests the final k-tile into
         // the stage that was just retired (harmless, L2-resident) instead of branching around the loads, which keeps the
         // whole step one scheduling region.
-        static_assert(NSTAGE == 2 && LPT == FM, "kstep_big spreads FM DMA pieces over 2*FM fragment rows");
+        static_assert(NSTAGE == 2, "two stages: the step waits for the single k-tile in flight");
         for (int i = 0; i < nmain; ++i) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -707,7 +725,8 @@ extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
         const int sk = (d->split_k > 1 ? d->split_k : 1) * batch;
         auto tiles = [&](int tm, int tn) { return (long)((d->M + tm - 1) / tm) * ((d->N + tn - 1) / tn) * sk; };
         // 256 x 256 (8 waves, one workgroup per CU): half the LDS-fill traffic per flop of 128 x 128 -- wins once its tiles
-        // fill most of the 256 CUs (wide-N forward / dgrad GEMMs with row-major A); the k-major A variant does not pay
+        // fill most of the 256 CUs (wide-N forward / dgrad GEMMs with row-major A); the k-major A variant does not pay (the
+        // layer-batched FFN weight gradients: 455 us against 385-410 us with 128 x 128)
         // (also for a small output with a very long reduction cut into slices by vlt5_gemm_auto_split: the input gradients
         // of lm_head and of the stacked cross-attention K/V projection)
         if (!d->a_kmajor && (tiles(256, 256) >= 200 || (d->K >= 8192 && d->split_k > 1 && tiles(256, 256) >= 128))) { bm = 256; bn = 256; }
