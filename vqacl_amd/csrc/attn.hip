@@ -82,14 +82,17 @@ __device__ __forceinline__ bf16x8_t pack_slots(const float (&lo)[4], const float
 }
 
 // scores of this wave's 16 query rows against all 64 key slots, + bias/masks; s[jb][r] in the swapped layout
+template <bool DK64>
 __device__ __forceinline__ void scores_16x64(const AttnArgs& p, const bf16_t* Qs, const bf16_t* Ks, int b, int h, int i0,
                                              int lane, float (&s)[4][4]) {
     const int lr = lane & 15, g = lane >> 4;
     f32x4_t acc[4];
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) acc[jb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const int nks = p.dk > 32 ? 2 : 1;
-    for (int ks = 0; ks < nks; ++ks) {
+    const int nks = DK64 ? 2 : (p.dk > 32 ? 2 : 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        if (ks >= nks) break;
         bf16x8_t fq = lds_frag(Qs, i0 + lr, ks * 4 + g);
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) {
@@ -126,6 +129,9 @@ __device__ __forceinline__ float quad_lane_max(float v) {
     return v;
 }
 
+// DK64: d_kv == 64 (every T5 size): the head-dimension loops have constant trip counts and unroll, so all the LDS reads of
+// a phase are in flight together (the transpose reads are 8-byte-per-lane reads: latency-bound unless many are queued)
+template <bool DK64>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
 
     float s[4][4];
-    scores_16x64(p, Qs, Ks, b, h, i0, lane, s);
+    scores_16x64<DK64>(p, Qs, Ks, b, h, i0, lane, s);
     float m = -INFINITY;
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
@@ -171,8 +177,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             s[jb][r] = v;
         }
     bf16x8_t pf[2] = {pack_slots(s[0], s[1]), pack_slots(s[2], s[3])};
-    const int ndb = (p.dk + 15) / 16;
-    for (int db = 0; db < ndb; ++db) {
+    const int ndb = DK64 ? 4 : (p.dk + 15) / 16;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        if (db >= ndb) break;
         f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -191,6 +199,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     }
 }
 
+template <bool DK64>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
@@ -216,18 +225,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pd[jb][r] = 0.f; ds[jb][r] = 0.f; }
-    const int ndb = (p.dk + 15) / 16;
-    const int nks = p.dk > 32 ? 2 : 1;
+    const int ndb = DK64 ? 4 : (p.dk + 15) / 16;
+    const int nks = DK64 ? 2 : (p.dk > 32 ? 2 : 1);
 
     if (active) {
         float s[4][4];
-        scores_16x64(p, Qs, Ks, b, h, i0, lane, s);
+        scores_16x64<DK64>(p, Qs, Ks, b, h, i0, lane, s);
         const float lse = (i < p.Tq) ? p.lse[((size_t)b * p.H + h) * p.Tq + i] : 0.f;
         // dPd[i][j] = sum_d dO[i][d] V[j][d]  (same swapped layout as the scores)
         f32x4_t dacc[4];
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) dacc[jb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < nks; ++ks) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks >= nks) break;
             bf16x8_t fo = lds_frag(dOs, i0 + lr, ks * 4 + g);
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) {
@@ -266,7 +277,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
             }
         // dQ[i][d] = sum_j dS[i][j] K[j][d]   (K^T gathered from the natural K tile with transpose reads)
         bf16x8_t dsf[2] = {pack_slots(ds[0], ds[1]), pack_slots(ds[2], ds[3])};
-        for (int db = 0; db < ndb; ++db) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            if (db >= ndb) break;
             f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -301,9 +314,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
     if (j0 >= p.Tk) return;
     const int j = j0 + lr;
     const int nis = p.Tq > 32 ? 2 : 1;
-    for (int db = 0; db < ndb; ++db) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        if (db >= ndb) break;
         f32x4_t av = (f32x4_t){0.f, 0.f, 0.f, 0.f}, ak = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < nis; ++ks) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks >= nis) break;
             bf16x8_t fp = frag_tr_std(Ps, j0, ks, lane);          // Pd^T[j][i]
             bf16x8_t fs = frag_tr_std(dSs, j0, ks, lane);         // dS^T[j][i]
             bf16x8_t fo = frag_tr_std(dOs, db * 16, ks, lane);    // dO^T[d][i]
@@ -357,7 +374,8 @@ extern "C" int vlt5_attn_fwd(const vlt5_attn_desc* d, void* stream) {
     AttnArgs a;
     int rc = fill_args(d, a, false);
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(a.B * a.H), dim3(256), 3 * TILE_BYTES, (hipStream_t)stream, a);
+    if (a.dk == 64) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(a.B * a.H), dim3(256), 3 * TILE_BYTES, (hipStream_t)stream, a);
+    else            hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(a.B * a.H), dim3(256), 3 * TILE_BYTES, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return VLT5_OK;
 }
@@ -366,7 +384,8 @@ extern "C" int vlt5_attn_bwd(const vlt5_attn_desc* d, void* stream) {
     AttnArgs a;
     int rc = fill_args(d, a, true);
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.B * a.H), dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
+    if (a.dk == 64) hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(a.B * a.H), dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
+    else            hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(a.B * a.H), dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return VLT5_OK;
 }
