@@ -151,6 +151,8 @@ int vlt5_ce_fwd(const float* logits, const long long* labels, float* loss_tok, f
 /* loss = mean_b( score_b * sum_t CE_bt m_bt / max(sum_t m_bt,1) );  row_w[b,t] = d loss / d CE_bt */
 int vlt5_loss_reduce(const float* loss_tok, const long long* labels, const float* scores, float* loss, float* row_w,
                      int B, int T, void* stream);
+/* out[r] = index of the first maximum of row r of x [rows, cols] (greedy decoding over the vocabulary) */
+int vlt5_argmax_rows(const float* x, int rows, int cols, long long* out, void* stream);
 /* dlogits[r,:] = (softmax(logits[r]) - onehot(label_r)) * row_w[r] * (*gout or 1), bf16, 0 for ignored rows */
 int vlt5_ce_bwd(const float* logits, const long long* labels, const float* lse, const float* row_w, const float* gout,
                 void* dlogits_bf16, int R, int V, void* stream);
@@ -251,6 +253,14 @@ long long vlt5_workspace_offset(const vlt5_config* c, int B, int L, int V, int T
 
 int vlt5_encoder_fwd(const vlt5_config* c, const vlt5_step* s, void* stream);
 int vlt5_decoder_fwd(const vlt5_config* c, const vlt5_step* s, void* stream);
+/* One greedy-decoding step with a key/value cache (replaces HF generate -> VLT5.forward(decoder_input_ids[:, -1:],
+ * past_key_values), src/modeling_t5_our.py:544-566,624-629,715-772; vqa_model.py:112-116).  s->T is the cache capacity
+ * (<= 64), s->training must be 0, s->dec_lut the causal bucket table for [T, T].  tokens i64 [B]: decoder input at position t;
+ * kv_cache bf16 [num_decoder_layers][B][T][2*H*d_kv] (caller-owned, k then v per position); logits f32 [B, vocab] out;
+ * next_ids i64 [B] (optional) = argmax of the logits.  At t == 0 the cross-attention keys/values are projected from the
+ * encoder output of the same step state (vlt5_encoder_fwd + prototype rows must have been written to the workspace). */
+int vlt5_decoder_step(const vlt5_config* c, const vlt5_step* s, const long long* tokens, int t, void* kv_cache, float* logits,
+                      long long* next_ids, void* stream);
 int vlt5_decoder_bwd(const vlt5_config* c, const vlt5_step* s, void* stream);
 int vlt5_encoder_bwd(const vlt5_config* c, const vlt5_step* s, void* stream);
 

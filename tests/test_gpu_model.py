@@ -329,6 +329,73 @@ def test_state_dict_roundtrip_and_greedy_decode(dev):
     agree = float((cur[:, :tok.shape[1]] == tok.cpu()).float().mean())
     print("greedy agreement with oracle:", agree)
     assert agree >= 0.75
+    # the key/value-cached incremental decoder (default) against re-decoding the growing prefix with the training kernels
+    model.eval()
+    fb = (batch["vis_feats"], batch["boxes"])
+    for mlen in (2, 6, 12):
+        a = model.greedy_generate(batch["input_ids"], fb, max_length=mlen)
+        b = model.greedy_generate(batch["input_ids"], fb, max_length=mlen, use_cache=False)
+        n = min(a.shape[1], b.shape[1])
+        same = float((a[:, :n] == b[:, :n]).float().mean())
+        print("cached vs recomputed greedy decode:", mlen, a.shape, b.shape, same)
+        assert a.shape[1] <= mlen and same >= 0.9, (a, b)
+
+
+def test_incremental_decoder_step_matches_full_decoder_logits(dev):
+    """vlt5_decoder_step (one token, key/value cache) reproduces the logits the full decoder computes for the same prefix:
+    position t of a teacher-forced forward == step t of the incremental decoder fed the same inputs."""
+    import ctypes as C
+    from oracle import ref_cpu as R
+    from vqacl_amd import _lib as L
+    from vqacl_amd._lib import check, lib, ptr, stream_ptr
+    from vqacl_amd import ops
+    ocfg = R.tiny_cfg()
+    params = R.init_params(ocfg, seed=43)
+    model = make_model(ocfg, params, dev)
+    batch = R.synthetic_batch(ocfg, B=5, L=9, V=36, T=6, seed=14)
+    model.train()
+    model.train_step(batch, 0, 0.5, 0.3)          # populate the prototypes
+    model.eval()
+    labels = batch["target_ids"].clone()
+    labels[labels < 0] = 0                        # a dense prefix (pads become token 0) so every position is comparable
+    B, T = labels.shape
+    with torch.no_grad():
+        full = model(input_ids=batch["input_ids"], vis_inputs=(batch["vis_feats"], batch["boxes"]), labels=labels,
+                     proto_update=False)
+        ref_logits = full["logits"].clone()                                  # [B, T, vocab]; decoder inputs = shift_right(labels)
+        dec_in = torch.cat([torch.zeros(B, 1, dtype=torch.long), labels[:, :-1].cpu()], dim=1).to(dev)
+        # same state through the incremental path
+        feats, boxes = batch["vis_feats"].to(dev), batch["boxes"].to(dev)
+        ids = batch["input_ids"].to(dev).contiguous()
+        Lt, V = ids.shape[1], feats.shape[1]
+        dims = (B, Lt, V, T)
+        model._workspace(*dims)
+        st = dict(dims=dims, training=False, seed=0, feats=feats.float().contiguous(), boxes=boxes.float().contiguous(),
+                  input_ids=ids, labels=torch.zeros(B, T, dtype=torch.long, device=dev), enc_lut=model._lut(Lt, Lt, True),
+                  dec_lut=model._lut(T, T, False))
+        c = model.cfg.c_struct()
+        cs = model._make_step(st)
+        check(lib().vlt5_encoder_fwd(C.byref(c), C.byref(cs), stream_ptr()))
+        S, Sx, d = Lt + V, Lt + V + 2, model.cfg.d_model
+        enc_f32 = model._ws_view(c, dims, L.WS_ENC_OUT, torch.float32, (B, Sx, d))
+        enc_b16 = model._ws_view(c, dims, L.WS_ENC_EXT, torch.bfloat16, (B, Sx, d))
+        pq, pv = ops.proto_pool(enc_f32, S, model.L)
+        model.proto.retrieve(pq, pv, enc_f32, enc_b16, S)
+        inner = model.cfg.num_heads * model.cfg.d_kv
+        cache = torch.zeros(model.cfg.num_decoder_layers, B, T, 2 * inner, device=dev, dtype=BF)
+        logits = torch.empty(B, model.cfg.vocab_size, device=dev)
+        nxt = torch.empty(B, dtype=torch.long, device=dev)
+        for t in range(T):
+            tok = dec_in[:, t].contiguous()
+            check(lib().vlt5_decoder_step(C.byref(c), C.byref(cs), ptr(tok), t, ptr(cache), ptr(logits), ptr(nxt), stream_ptr()))
+            err = rel_max_err(logits, ref_logits[:, t])
+            assert err < 3e-2, (t, err)
+            assert torch.equal(nxt, logits.argmax(dim=-1)), "argmax kernel == torch.argmax (first maximum)"
+    # argument checks: training state, position beyond the cache
+    st["training"] = True
+    cs2 = model._make_step(st)
+    assert lib().vlt5_decoder_step(C.byref(c), C.byref(cs2), ptr(tok), 0, ptr(cache), ptr(logits), ptr(nxt), stream_ptr()) == 1001
+    assert lib().vlt5_decoder_step(C.byref(c), C.byref(cs), ptr(tok), T, ptr(cache), ptr(logits), ptr(nxt), stream_ptr()) == 1001
 
 
 def test_data_parallel_overlap_path_on_one_gpu_and_rank_equivalence(dev):

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "vlt5_colsum": (c_i, [vp, vp, c_i, c_i, c_i, c_i, vp]),
     "vlt5_ce_fwd": (c_i, [vp, vp, vp, vp, c_i, c_i, vp]),
     "vlt5_loss_reduce": (c_i, [vp, vp, vp, vp, vp, c_i, c_i, vp]),
+    "vlt5_argmax_rows": (c_i, [vp, c_i, c_i, vp, vp]),
     "vlt5_ce_bwd": (c_i, [vp, vp, vp, vp, vp, vp, c_i, c_i, vp]),
     "vlt5_proto_pool": (c_i, [vp, c_ll, c_i, c_i, c_i, c_i, vp, vp, vp]),
     "vlt5_proto_class_mean": (c_i, [vp, vp, vp, vp, c_i, c_i, c_i, vp]),
@@ -98,6 +99,7 @@ PROTOTYPES = {
     "vlt5_workspace_offset": (c_ll, [C.POINTER(Config), c_i, c_i, c_i, c_i, c_i]),
     "vlt5_encoder_fwd": (c_i, [C.POINTER(Config), C.POINTER(Step), vp]),
     "vlt5_decoder_fwd": (c_i, [C.POINTER(Config), C.POINTER(Step), vp]),
+    "vlt5_decoder_step": (c_i, [C.POINTER(Config), C.POINTER(Step), vp, c_i, vp, vp, vp, vp]),
     "vlt5_decoder_bwd": (c_i, [C.POINTER(Config), C.POINTER(Step), vp]),
     "vlt5_encoder_bwd": (c_i, [C.POINTER(Config), C.POINTER(Step), vp]),
 }

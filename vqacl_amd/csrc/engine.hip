@@ -422,6 +422,66 @@ int decoder_fwd(const Ctx& k) {
     return VLT5_OK;
 }
 
+// One greedy-decoding step with a key/value cache (reference: HF generate -> VLT5.forward(decoder_input_ids[:, -1:],
+// past_key_values), src/modeling_t5_our.py:544-566,624-629; vqa_model.py:112-116).  Row b of `tokens` is the decoder input at
+// position t; the self-attention keys/values of positions 0..t live in `cache` ([Ld][B][Tcap][2*inner] bf16, Tcap = s.T), the
+// cross-attention keys/values of the 58 encoder rows are computed at t == 0 (the encoder output incl. the two retrieved
+// prototype rows must be in the workspace: vlt5_encoder_fwd + prototype retrieval of the same step state).  Eval mode only.
+int decoder_step(const Ctx& k, const long long* tokens, int t, bf16_t* cache, float* logits, long long* next_ids) {
+    const Plan& p = k.p; const Layout& L = k.lay; const vlt5_config& c = k.c; const vlt5_step& s = k.s;
+    const int d = k.d, inner = k.inner, ff = k.ff, Mx = p.Mx, Sx = p.Sx, B = s.B, Tcap = s.T, Ld = c.num_decoder_layers;
+    const int kvw = Ld * 2 * inner, Tk = t + 1;
+    if (t == 0) {
+        RC(k.wait_bucket(Ld + c.num_layers + 1));
+        RC(k.wait_bucket(Ld));
+        RC(vlt5_build_mask(s.input_ids, k.w<float>(p.mask_ext), B, s.L, Sx, c.pad_id, k.st));
+        RC(k.lin_fwd(k.w<bf16_t>(p.enc_ext), k.Pb + L.cross_kv, k.w<void>(p.kv_all), Mx, kvw, d, 0));
+        for (int l = 0; l < Ld; ++l) RC(k.wait_bucket(Ld - 1 - l));
+    }
+    // relative-position bias of query position t against keys 0..t: row t of the causal bucket table, [H][1][Tk]
+    float* bias_t = k.w<float>(p.dec_bias);
+    RC(vlt5_relbias_build(k.P + L.dec_rel, s.dec_lut + (size_t)t * Tcap, bias_t, k.H, 1, Tk, c.rel_buckets, k.st));
+    RC(vlt5_embed_fwd(tokens, k.P + L.shared, k.w<float>(p.y[0]), d, d, B, 1, d, c.vocab, 0.f, 0, 1, 0, k.st));
+    const size_t cache_layer = (size_t)B * Tcap * 2 * inner;
+    for (int l = 0; l < Ld; ++l) {
+        const auto& D = L.dec[l];
+        float* y0 = k.w<float>(p.y[3 * l]);
+        float* y1 = k.w<float>(p.y[3 * l + 1]);
+        float* y2 = k.w<float>(p.y[3 * l + 2]);
+        float* y3 = k.w<float>(p.y[3 * l + 3]);
+        bf16_t* q = k.w<bf16_t>(p.dqkv_s[l]);                          // [B, inner]
+        bf16_t* kc = cache + (size_t)l * cache_layer;                    // [B][Tcap][2*inner]: k | v
+        bf16_t* kv = k.w<bf16_t>(p.kv_all) + (size_t)l * 2 * inner;
+        RC(vlt5_layernorm_fwd(y0, k.P + D.ln_s, k.w<void>(p.yn_a[l]), nullptr, nullptr, B, d, c.eps, 0.f, 0, 0, 0, k.st));
+        // q of the new token; its k,v go straight into cache slot t (row stride = one sample's cache)
+        RC(k.lin_fwd(k.w<bf16_t>(p.yn_a[l]), k.Pb + D.sqkv, q, B, inner, d, 0));
+        {
+            vlt5_gemm_desc g;
+            memset(&g, 0, sizeof g);
+            g.A = k.w<bf16_t>(p.yn_a[l]); g.B = k.Pb + D.sqkv + (size_t)inner * d; g.C = kc + (size_t)t * 2 * inner;
+            g.M = B; g.N = 2 * inner; g.K = d; g.lda = d; g.ldb = d; g.ldc = Tcap * 2 * inner; g.alpha = 1.f;
+            RC(vlt5_gemm_bf16(&g, k.st));
+        }
+        RC(attn_call(k, false, q, inner, inner, kc, kc + inner, (long long)Tcap * 2 * inner, 2 * inner, k.w<bf16_t>(p.ctx_s[l]),
+                     nullptr, bias_t, 1, Tk, nullptr, 0.f, 0, 1, Tk, 0));
+        RC(k.lin_fwd(k.w<bf16_t>(p.ctx_s[l]), k.Pb + D.so, y1, B, d, inner, 1, 1.f, nullptr, 0, 0.f, 0, y0));
+        RC(vlt5_layernorm_fwd(y1, k.P + D.ln_c, k.w<void>(p.yn_c[l]), nullptr, nullptr, B, d, c.eps, 0.f, 0, 0, 0, k.st));
+        RC(k.lin_fwd(k.w<bf16_t>(p.yn_c[l]), k.Pb + D.cq, k.w<void>(p.qc[l]), B, inner, d, 0));
+        RC(attn_call(k, false, k.w<bf16_t>(p.qc[l]), inner, inner, kv, kv + inner, (long long)Sx * kvw, kvw,
+                     k.w<bf16_t>(p.ctx_c[l]), nullptr, nullptr, 0, 0, k.w<float>(p.mask_ext), -1e9f, 0, 1, Sx, 0));
+        RC(k.lin_fwd(k.w<bf16_t>(p.ctx_c[l]), k.Pb + D.co, y2, B, d, inner, 1, 1.f, nullptr, 0, 0.f, 0, y1));
+        RC(vlt5_layernorm_fwd(y2, k.P + D.ln_f, k.w<void>(p.yn_f[l]), nullptr, nullptr, B, d, c.eps, 0.f, 0, 0, 0, k.st));
+        RC(k.lin_fwd(k.w<bf16_t>(p.yn_f[l]), k.Pb + D.wi, k.w<void>(p.hd[l]), B, ff, d, 0, 1.f, nullptr, 1, 0.f, 0));
+        RC(k.lin_fwd(k.w<bf16_t>(p.hd[l]), k.Pb + D.wo, y3, B, d, ff, 1, 1.f, nullptr, 0, 0.f, 0, y2));
+    }
+    RC(vlt5_layernorm_fwd(k.w<float>(p.y[3 * Ld]), k.P + L.dec_final_ln, k.w<void>(p.dec_out), nullptr, nullptr, B, d, c.eps, 0.f, 0,
+                          0, 0, k.st));
+    const float alpha = 1.0f / sqrtf((float)d);           // tied embeddings: rescale before the vocabulary projection
+    RC(k.lin_fwd(k.w<bf16_t>(p.dec_out), k.Pb + L.shared, logits, B, c.vocab, d, 1, alpha));
+    if (next_ids) RC(vlt5_argmax_rows(logits, B, c.vocab, next_ids, k.st));
+    return VLT5_OK;
+}
+
 // backward (data path only) of one  x_out = x_in + drop(W_o . drop(relu(W_i . LN(x_in))))  sublayer; dx is updated in place.
 // `dyd` holds bf16(dropout_out(dx)) on entry (emitted by the producer of dx); `dh` receives the hidden gradient; both are
 // kept for the batched weight-gradient GEMMs at the end of the phase.  `next_dst` receives the operand of the next sublayer.
@@ -635,6 +695,16 @@ extern "C" long long vlt5_workspace_offset(const vlt5_config* c, int B, int L, i
         if (rc) return rc;                                                      \
         return fn(k);                                                           \
     }
+extern "C" int vlt5_decoder_step(const vlt5_config* c, const vlt5_step* s, const long long* tokens, int t, void* kv_cache,
+                                 float* logits, long long* next_ids, void* stream) {
+    if (!c || !s || !tokens || !kv_cache || !logits) return VLT5_ERR_ARG;
+    if (t < 0 || t >= s->T || s->training) return VLT5_ERR_ARG;
+    Ctx k(*c, *s, stream);
+    int rc = k.check(false);
+    if (rc) return rc;
+    if (!s->dec_lut || !s->input_ids) return VLT5_ERR_ARG;
+    return decoder_step(k, tokens, t, (bf16_t*)kv_cache, logits, next_ids);
+}
 ENGINE_ENTRY(encoder_fwd, false)
 ENGINE_ENTRY(decoder_fwd, false)
 ENGINE_ENTRY(decoder_bwd, true)

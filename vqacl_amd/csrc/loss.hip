@@ -94,6 +94,33 @@ __global__ void loss_reduce_kernel(const float* __restrict__ loss_tok, const lon
     }
 }
 
+// first index of the row maximum (torch.argmax semantics for ties: the lowest index), one workgroup per row
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int cols, long long* __restrict__ out) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const float* r = x + (size_t)blockIdx.x * cols;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float v = r[c];
+        if (v > best || (v == best && c < idx)) { best = v; idx = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        out[blockIdx.x] = idx == 0x7fffffff ? 0 : idx;       // an all-NaN row: index 0
+    }
+}
+
 }  // namespace
 
 extern "C" int vlt5_ce_fwd(const float* logits, const long long* labels, float* loss_tok, float* lse, int R, int V, void* stream) {
@@ -117,6 +144,13 @@ extern "C" int vlt5_loss_reduce(const float* loss_tok, const long long* labels, 
     if (!loss_tok || !labels || !scores || !loss || B <= 0 || T <= 0) return VLT5_ERR_ARG;
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), B * sizeof(float), (hipStream_t)stream, loss_tok, labels, scores,
                        loss, row_w, B, T);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+
+extern "C" int vlt5_argmax_rows(const float* x, int rows, int cols, long long* out, void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0) return VLT5_ERR_ARG;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, cols, out);
     LAUNCH_CHECK();
     return VLT5_OK;
 }

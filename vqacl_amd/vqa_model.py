@@ -45,8 +45,8 @@ class VLT5VQA(VLT5):
     @torch.no_grad()
     def test_step(self, batch, **kwargs):
         """Greedy decoding (the reference forwards no generation kwargs, so `--num_beams` is ignored: vqa_model.py:112-116).
-        The encoder and the prototype retrieval run once; each step re-decodes the growing prefix through the training
-        decoder kernels (O(T^2) decoder work, T <= 20, no KV cache yet)."""
+        The encoder and the prototype retrieval run once; every further token is ONE incremental decoder step over a
+        key/value cache (`vlt5_decoder_step`)."""
         self.eval()
         token_ids = self.greedy_generate(batch["input_ids"], (batch["vis_feats"], batch["boxes"]),
                                          max_length=kwargs.get("max_length", 20))
@@ -56,7 +56,66 @@ class VLT5VQA(VLT5):
         return result
 
     @torch.no_grad()
-    def greedy_generate(self, input_ids, vis_inputs, max_length=20, eos_token_id=1):
+    def greedy_generate(self, input_ids, vis_inputs, max_length=20, eos_token_id=1, use_cache=True):
+        """HF `generate` semantics for greedy search: starts from decoder_start_token_id, a finished row keeps emitting pad,
+        stops when every row has produced EOS or at max_length.  use_cache=False re-decodes the growing prefix through the
+        training decoder kernels (O(T^2)); kept as the cross-check of the cached path."""
+        if not use_cache:
+            return self._greedy_generate_recompute(input_ids, vis_inputs, max_length, eos_token_id)
+        import ctypes as C
+        from . import _lib as L
+        from . import ops
+        from ._lib import check, lib, ptr, stream_ptr
+        if self.training:
+            raise L.Vlt5Error("greedy_generate runs in eval mode (call .eval() or test_step)")
+        if not 2 <= max_length <= 64:
+            raise L.Vlt5Error("max_length must be in [2, 64] (the key/value cache of the attention kernel)")
+        dev = self._device
+        feats = vis_inputs[0].to(dev, torch.float32).contiguous()
+        boxes = vis_inputs[1].to(dev, torch.float32).contiguous()
+        input_ids = input_ids.to(dev).contiguous()
+        B, Lt = input_ids.shape
+        V, Tcap = feats.shape[1], int(max_length)
+        S, Sx, d = Lt + V, Lt + V + 2, self.cfg.d_model
+        dims = (B, Lt, V, Tcap)
+        self._workspace(*dims)
+        self.sync_bf16()
+        pad, start = self.cfg.pad_token_id, self.cfg.decoder_start_token_id
+        st = dict(dims=dims, training=False, seed=0, feats=feats, boxes=boxes, input_ids=input_ids,
+                  labels=torch.zeros(B, Tcap, dtype=torch.long, device=dev),
+                  enc_lut=self._lut(Lt, Lt, True), dec_lut=self._lut(Tcap, Tcap, False))
+        c = self.cfg.c_struct()
+        cs = self._make_step(st)
+        stream = stream_ptr()
+        check(lib().vlt5_encoder_fwd(C.byref(c), C.byref(cs), stream), "vlt5_encoder_fwd")
+        enc_f32 = self._ws_view(c, dims, L.WS_ENC_OUT, torch.float32, (B, Sx, d))
+        enc_b16 = self._ws_view(c, dims, L.WS_ENC_EXT, torch.bfloat16, (B, Sx, d))
+        poolQ, poolV = ops.proto_pool(enc_f32, S, self.L)
+        self.proto.retrieve(poolQ, poolV, enc_f32, enc_b16, S)        # rows S, S+1 <- retrieved prototypes (modeling_t5_our.py:608-612)
+        inner = self.cfg.num_heads * self.cfg.d_kv
+        cache = torch.empty(self.cfg.num_decoder_layers, B, Tcap, 2 * inner, device=dev, dtype=torch.bfloat16)
+        logits = torch.empty(B, self.cfg.vocab_size, device=dev, dtype=torch.float32)
+        nxt = torch.empty(B, dtype=torch.long, device=dev)
+        cur = torch.full((B,), start, dtype=torch.long, device=dev)
+        done = torch.zeros(B, dtype=torch.bool, device=dev)
+        padv = torch.full((B,), pad, dtype=torch.long, device=dev)
+        tokens = [cur]
+        for t in range(Tcap - 1):
+            check(lib().vlt5_decoder_step(C.byref(c), C.byref(cs), ptr(cur), t, ptr(cache), ptr(logits), ptr(nxt), stream),
+                  "vlt5_decoder_step")
+            cur = torch.where(done, padv, nxt)
+            tokens.append(cur)
+            done = done | (cur == eos_token_id)
+            if (t & 3) == 3 and bool(done.all()):                     # one host sync every 4 tokens
+                break
+        out = torch.stack(tokens, dim=1)
+        # trim what was decoded after every row had finished (the reference stops at that token)
+        alive = (out != eos_token_id).long().cumprod(dim=1)               # 1 until (excluding) a row's first EOS
+        length = int(alive.sum(dim=1).max()) + 1                      # longest row incl. its EOS
+        return out[:, :min(out.shape[1], max(length, 1))]
+
+    @torch.no_grad()
+    def _greedy_generate_recompute(self, input_ids, vis_inputs, max_length=20, eos_token_id=1):
         device = self._device
         B = input_ids.shape[0]
         pad, start = self.cfg.pad_token_id, self.cfg.decoder_start_token_id
