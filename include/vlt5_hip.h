@@ -44,11 +44,14 @@ typedef struct {
     float drop_p; uint32_t drop_seed;        /* inverted dropout on element index m*N+n */
     int relu, out_f32, accum;                /* accum: C += (f32 only) */
     int split_k; void* workspace;            /* split_k>1: f32 slabs [split_k][M*ldc], plain epilogue, ldc==N */
-    int tile_m, tile_n;                      /* 0 = heuristic; else 64 or 128 */
+    int tile_m, tile_n;                      /* 0 = heuristic; else 64x64, 64x128, 128x64, 128x128 or 256x256 */
     int batch;                               /* > 1: batch of equal-shaped GEMMs (grid.z); entry z uses A + z*batch_stride_a, ... */
     long long batch_stride_a, batch_stride_b, batch_stride_c;   /* element strides (may be negative); resid uses batch_stride_c */
+    int defer_reduce;                        /* split_k>1: leave the f32 slabs in `workspace` (slab s = partial sum of k-slice s) for
+                                                a consumer that sums them itself (vlt5_layernorm_bwd_slabs); C is not written */
+    int split_used;                          /* out: the number of slabs actually written (<= split_k), 1 if not split */
 } vlt5_gemm_desc;
-int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream);
+int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream);     /* writes d->split_used */
 long long vlt5_gemm_workspace_bytes(int M, int ldc, int split_k);
 /* the split-K factor the engine uses for a plain f32 output [M,N] reduced over Kred (1 = no split) */
 int vlt5_gemm_auto_split(int M, int N, int Kred, long long slab_bytes);
@@ -71,6 +74,13 @@ int vlt5_layernorm_bwd(const float* dy, const float* x, const float* w, const fl
                        int accum_dx, int accum_dw, float drop_p, uint32_t drop_seed,
                        int in_group, int in_group_stride, void* dx_bf16, float dx_drop_p, uint32_t dx_drop_seed,
                        void* stream);
+/* same, with dy handed over as `nslabs` split-K slabs of the producing GEMM (vlt5_gemm_desc.defer_reduce): row r of dy =
+ * sum_s dy[s*slab_stride + r*d ..] in slab order -- saves the separate slab reduction launch and a round trip of dy */
+int vlt5_layernorm_bwd_slabs(const float* dy, int nslabs, long long slab_stride, const float* x, const float* w,
+                             const float* rstd, float* dx, float* dw, float* dw_partial, int rows, int d,
+                             int accum_dx, int accum_dw, float drop_p, uint32_t drop_seed,
+                             int in_group, int in_group_stride, void* dx_bf16, float dx_drop_p, uint32_t dx_drop_seed,
+                             void* stream);
 /* job j < njobs (<= 64): out_base[out_off[j] + c] = sum_{b < nblk[j]} partial[(j*slot_rows + b)*width + c], c < width.
  * out_off / nblk are HOST arrays (passed by value to the kernel). */
 int vlt5_colsum_multi(const float* partial, float* out_base, const long long* out_off, const int* nblk, int njobs,

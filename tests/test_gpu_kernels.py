@@ -175,6 +175,32 @@ def test_layernorm_fwd_bwd(dev, rows, d):
     assert torch.equal(dxb, ops.drop_cast(dx3, 0.1, 4242))
     frac = float((dxb == 0).float().mean())
     assert abs(frac - 0.1) < 0.02, frac
+    # dy handed over as split-K slabs of the producing GEMM (defer_reduce): the kernel sums them in slab order
+    from vqacl_amd._lib import check, lib, ptr, stream_ptr
+    xs, ws = x.detach().to(dev), w.detach().to(dev)
+    A = rnd((rows, 256), g).to(BF).to(dev)
+    Wt = (rnd((256, d), g) * 0.2).to(BF).to(dev)                 # dy = A @ Wt, weight read k-major, reduction cut into 4 slices
+    dy_full = ops.gemm(A, Wt, rows, d, 256, b_kmajor=True, out_f32=True, tile=(64, 64))
+    from vqacl_amd._lib import GemmDesc
+    import ctypes as C
+    slabs = torch.zeros(4, rows, d, device=dev)
+    gd = GemmDesc()
+    gd.A, gd.B, gd.C = ptr(A), ptr(Wt), ptr(torch.empty(rows, d, device=dev))
+    gd.M, gd.N, gd.K, gd.lda, gd.ldb, gd.ldc, gd.b_kmajor, gd.alpha, gd.out_f32 = rows, d, 256, 256, d, d, 1, 1.0, 1
+    gd.split_k, gd.workspace, gd.defer_reduce, gd.tile_m, gd.tile_n = 4, ptr(slabs), 1, 64, 64
+    check(lib().vlt5_gemm_bf16(C.byref(gd), stream_ptr()))
+    assert gd.split_used == 4
+    close(slabs.sum(0), dy_full, 1e-5, 1e-4, "deferred slabs sum to the reduced GEMM")
+    dx_ref, dw_ref = ops.layernorm_bwd(dy_full, xs, ws, rstd)
+    dx_s = torch.empty(rows, d, device=dev)
+    dw_s = torch.empty(d, device=dev)
+    part = torch.empty(lib().vlt5_layernorm_bwd_blocks(rows), d, device=dev)
+    check(lib().vlt5_layernorm_bwd_slabs(ptr(slabs), 4, rows * d, ptr(xs), ptr(ws), ptr(rstd), ptr(dx_s), ptr(dw_s), ptr(part), rows, d,
+                                         0, 0, 0.0, 0, 0, 0, None, 0.0, 0, stream_ptr()))
+    close(dx_s, dx_ref, 1e-4, 1e-5, "ln dx from slabs")
+    close(dw_s, dw_ref, 1e-4, 1e-3, "ln dw from slabs")
+    assert lib().vlt5_layernorm_bwd_slabs(ptr(slabs), 4, 0, ptr(xs), ptr(ws), ptr(rstd), ptr(dx_s), ptr(dw_s), ptr(part), rows, d,
+                                          0, 0, 0.0, 0, 0, 0, None, 0.0, 0, stream_ptr()) == 1001
 
 
 def test_layernorm_golden(dev):

@@ -24,7 +24,7 @@ class GemmDesc(C.Structure):
                 ("gate", vp), ("ldg", c_i), ("gate_scale", c_f), ("drop_p", c_f), ("drop_seed", c_u32),
                 ("relu", c_i), ("out_f32", c_i), ("accum", c_i), ("split_k", c_i), ("workspace", vp),
                 ("tile_m", c_i), ("tile_n", c_i), ("batch", c_i), ("batch_stride_a", c_ll), ("batch_stride_b", c_ll),
-                ("batch_stride_c", c_ll)]
+                ("batch_stride_c", c_ll), ("defer_reduce", c_i), ("split_used", c_i)]
 
 
 class AttnDesc(C.Structure):
@@ -59,6 +59,7 @@ PROTOTYPES = {
     "vlt5_gemm_auto_split": (c_i, [c_i, c_i, c_i, c_ll]),
     "vlt5_layernorm_fwd": (c_i, [vp, vp, vp, vp, vp, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),
     "vlt5_layernorm_bwd": (c_i, [vp, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, c_f, c_u32, vp]),
+    "vlt5_layernorm_bwd_slabs": (c_i, [vp, c_i, c_ll, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, c_f, c_u32, vp]),
     "vlt5_colsum_multi": (c_i, [vp, vp, C.POINTER(c_ll), C.POINTER(c_i), c_i, c_i, c_i, vp]),
     "vlt5_layernorm_bwd_blocks": (c_i, [c_i]),
     "vlt5_attn_fwd": (c_i, [C.POINTER(AttnDesc), vp]),

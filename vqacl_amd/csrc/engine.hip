@@ -244,17 +244,21 @@ struct Ctx {
     }
     int pick_split(int M, int N, int Kred) const { return vlt5_gemm_auto_split(M, N, Kred, (long long)p.slab_bytes); }
     // dX[M,K] = epi(alpha * dY[M,N] W[N,K])     (W read k-major)
+    // `slabs` (optional): the consumer is a LayerNorm backward that can sum split-K slabs itself -- on return *slabs = number of
+    // slabs left in the slab scratch (1: dX was written as usual)
     int lin_dgrad(const bf16_t* dY, const bf16_t* W, void* dX, int M, int N, int K, int out_f32, float alpha = 1.f,
-                  const bf16_t* gate = nullptr, float gate_scale = 1.f) const {
+                  const bf16_t* gate = nullptr, float gate_scale = 1.f, int* slabs = nullptr) const {
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);
         g.A = dY; g.B = W; g.C = dX; g.M = M; g.N = K; g.K = N; g.lda = N; g.ldb = K; g.ldc = K; g.b_kmajor = 1;
         g.alpha = alpha; g.gate = gate; g.ldg = K; g.gate_scale = gate_scale; g.out_f32 = out_f32;
         if (out_f32 && !gate) {
             int sk = pick_split(M, K, N);
-            if (sk > 1) { g.split_k = sk; g.workspace = w<void>(p.slab); }
+            if (sk > 1) { g.split_k = sk; g.workspace = w<void>(p.slab); g.defer_reduce = slabs ? 1 : 0; }
         }
-        return vlt5_gemm_bf16(&g, st);
+        int rc = vlt5_gemm_bf16(&g, st);
+        if (slabs) *slabs = g.split_used > 1 ? g.split_used : 1;
+        return rc;
     }
     // dW[N,K] (+)= alpha * dY[M,N]^T X[M,K]     (both read k-major, reduction over the M rows)
     int lin_wgrad(const bf16_t* dY, int ldy, const bf16_t* X, int ldx, float* dW, int M, int N, int K, float alpha = 1.f,
@@ -271,14 +275,16 @@ struct Ctx {
     // `next_dst` (the per-layer operand buffer of the sublayer processed next).  The weight gradient is left as per-workgroup partials in
     // slot `ln_jobs`; ln_flush() reduces all slots of the phase with one launch.
     int ln_bwd(const float* dy, const float* x, long long w_off, const float* rstd, float* dx, int rows, int accum_dx,
-               float dp, uint32_t dseed, int in_group, int in_group_stride, bf16_t* next_dst, uint32_t next_seed) const {
+               float dp, uint32_t dseed, int in_group, int in_group_stride, bf16_t* next_dst, uint32_t next_seed,
+               int nslabs = 1, long long slab_stride = 0) const {
         if (ln_jobs >= 64) { int rc = ln_flush(); if (rc) return rc; }     // deep stacks (t5-large: 73 norms per phase)
         float* part = w<float>(p.ln_partial) + (size_t)ln_jobs * 320 * d;
         ln_out[ln_jobs] = w_off;
         ln_nblk[ln_jobs] = vlt5_layernorm_bwd_blocks(rows);
         ++ln_jobs;
-        return vlt5_layernorm_bwd(dy, x, P + w_off, rstd, dx, nullptr, part, rows, d, accum_dx, 0, dp, dseed, in_group,
-                                  in_group_stride, next_dst, next_dst ? pdrop : 0.f, next_seed, st);
+        if (nslabs > 1) dy = w<float>(p.slab);            // the producing GEMM left its split-K slabs there
+        return vlt5_layernorm_bwd_slabs(dy, nslabs, slab_stride, x, P + w_off, rstd, dx, nullptr, part, rows, d, accum_dx, 0, dp,
+                                        dseed, in_group, in_group_stride, next_dst, next_dst ? pdrop : 0.f, next_seed, st);
     }
     int ln_flush() const {
         if (ln_jobs == 0) return VLT5_OK;
@@ -492,8 +498,9 @@ int ffn_bwd(const Ctx& k, int M, float* dx, const float* x_in, const float* rstd
     float* tmp = k.w<float>(p.tmp);
     const float gs = k.pdrop > 0.f ? drop_scale(drop_thr16(k.pdrop)) : 1.f;
     RC(k.lin_dgrad(dyd, k.Pb + wo, dh, M, d, ff, 0, 1.f, h, gs));
-    RC(k.lin_dgrad(dh, k.Pb + wi, tmp, M, ff, d, 1));
-    RC(k.ln_bwd(tmp, x_in, ln, rstd, dx, M, 1, 0.f, 0, 0, 0, next_dst, next_seed));
+    int ns = 1;
+    RC(k.lin_dgrad(dh, k.Pb + wi, tmp, M, ff, d, 1, 1.f, nullptr, 1.f, &ns));
+    RC(k.ln_bwd(tmp, x_in, ln, rstd, dx, M, 1, 0.f, 0, 0, 0, next_dst, next_seed, ns, (long long)M * d));
     return VLT5_OK;
 }
 
@@ -511,9 +518,10 @@ int decoder_bwd(const Ctx& k) {
                    s.d_loss_tok ? nullptr : s.gout, dlog, Md, c.vocab, k.st));
     // lm_head (tied to shared): dShared = alpha * dlogits^T dec_out ; d dec_out = alpha * dlogits shared
     RC(k.lin_wgrad(dlog, c.vocab, k.w<bf16_t>(p.dec_out), d, k.Gr + L.shared, Md, c.vocab, d, alpha, 0));
-    RC(k.lin_dgrad(dlog, k.Pb + L.shared, tmp, Md, c.vocab, d, 1, alpha));
+    int ns_head = 1;
+    RC(k.lin_dgrad(dlog, k.Pb + L.shared, tmp, Md, c.vocab, d, 1, alpha, nullptr, 1.f, &ns_head));
     RC(k.ln_bwd(tmp, k.w<float>(p.y[3 * Ld]), L.dec_final_ln, k.w<float>(p.yr[3 * Ld]), dx, Md, 0, k.pdrop, k.seed(SITE_DEC_FINAL), 0, 0,
-                k.w<bf16_t>(p.d_dyd_f[Ld - 1]), k.seed(SITE_DEC_BASE + (Ld - 1) * 8 + D_FFN_OUT)));
+                k.w<bf16_t>(p.d_dyd_f[Ld - 1]), k.seed(SITE_DEC_BASE + (Ld - 1) * 8 + D_FFN_OUT), ns_head, (long long)Md * d));
     for (int l = Ld - 1; l >= 0; --l) {
         const auto& D = L.dec[l];
         const uint32_t sb = SITE_DEC_BASE + l * 8;
@@ -539,9 +547,11 @@ int decoder_bwd(const Ctx& k) {
                      3 * inner, nullptr, k.w<float>(p.lse_s[l]), k.w<float>(p.dec_bias), T, T, nullptr, 0.f, 1, T, T,
                      k.seed(sb + D_SPROBS), dctx, dqkv, (long long)T * 3 * inner, 3 * inner, dqkv + inner, dqkv + 2 * inner,
                      (long long)T * 3 * inner, 3 * inner, k.w<float>(p.dS_dec) + (size_t)l * B * k.H * T * T));
-        RC(k.lin_dgrad(dqkv, k.Pb + D.sqkv, tmp, Md, 3 * inner, d, 1));
+        int ns_s = 1;
+        RC(k.lin_dgrad(dqkv, k.Pb + D.sqkv, tmp, Md, 3 * inner, d, 1, 1.f, nullptr, 1.f, &ns_s));
         RC(k.ln_bwd(tmp, k.w<float>(p.y[3 * l]), D.ln_s, k.w<float>(p.yr[3 * l]), dx, Md, 1, 0.f, 0, 0, 0,
-                    l > 0 ? k.w<bf16_t>(p.d_dyd_f[l - 1]) : nullptr, l > 0 ? k.seed(SITE_DEC_BASE + (l - 1) * 8 + D_FFN_OUT) : 0u));
+                    l > 0 ? k.w<bf16_t>(p.d_dyd_f[l - 1]) : nullptr, l > 0 ? k.seed(SITE_DEC_BASE + (l - 1) * 8 + D_FFN_OUT) : 0u, ns_s,
+                    (long long)Md * d));
     }
     RC(vlt5_relbias_bwd(k.w<float>(p.dS_dec), s.dec_lut, k.Gr + L.dec_rel, k.w<float>(p.rel_scratch), Ld * B, k.H, T, T,
                         c.rel_buckets, 0, k.st));
@@ -597,9 +607,11 @@ int encoder_bwd(const Ctx& k) {
                      3 * inner, nullptr, k.w<float>(p.lse[l]), k.w<float>(p.enc_bias), s.L, s.L, k.w<float>(p.mask), -10000.f, 0, S, S,
                      k.seed(sb + E_PROBS), dctx, dqkv, (long long)S * 3 * inner, 3 * inner, dqkv + inner, dqkv + 2 * inner,
                      (long long)S * 3 * inner, 3 * inner, k.w<float>(p.dS_enc) + (size_t)l * B * k.H * s.L * s.L));
-        RC(k.lin_dgrad(dqkv, k.Pb + E.sqkv, tmp, M, 3 * inner, d, 1));
+        int ns_e = 1;
+        RC(k.lin_dgrad(dqkv, k.Pb + E.sqkv, tmp, M, 3 * inner, d, 1, 1.f, nullptr, 1.f, &ns_e));
         RC(k.ln_bwd(tmp, k.w<float>(p.x[2 * l]), E.ln_s, k.w<float>(p.xr[2 * l]), dx, M, 1, 0.f, 0, 0, 0,
-                    l > 0 ? k.w<bf16_t>(p.e_dyd_f[l - 1]) : nullptr, l > 0 ? k.seed(SITE_ENC_BASE + (l - 1) * 8 + E_FFN_OUT) : 0u));
+                    l > 0 ? k.w<bf16_t>(p.e_dyd_f[l - 1]) : nullptr, l > 0 ? k.seed(SITE_ENC_BASE + (l - 1) * 8 + E_FFN_OUT) : 0u, ns_e,
+                    (long long)M * d));
         if (Le > 1 && l == Le / 2) {
             // upper half of the stack: its weight gradients are complete early, so a data-parallel all-reduce of these
             // buckets overlaps with the backward of the lower half

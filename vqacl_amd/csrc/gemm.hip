@@ -692,7 +692,7 @@ int launch_tile(const GemmArgs& a, int akm, int bkm, int splits, int batch, hipS
 
 }  // namespace
 
-extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
+extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->B || !d->C) return VLT5_ERR_ARG;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return VLT5_ERR_ARG;
     // contiguous dimensions are read/written as 8-element (16-byte) vectors
@@ -705,6 +705,7 @@ extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
     if (d->gate && (d->resid || d->accum)) return VLT5_ERR_ARG;      // the epilogue holds ONE auxiliary operand per fragment
     if (d->split_k > 1 && (!d->out_f32 || !d->workspace || d->ldc != d->N || d->bias || d->relu || d->gate || d->drop_p > 0.f || d->resid))
         return VLT5_ERR_ARG;
+    if (d->defer_reduce && d->accum) return VLT5_ERR_ARG;            // the consumer of the slabs adds nothing else
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     GemmArgs a;
     a.A = (const bf16_t*)d->A; a.B = (const bf16_t*)d->B; a.C = d->C;
@@ -755,7 +756,8 @@ extern "C" int vlt5_gemm_bf16(const vlt5_gemm_desc* d, void* stream) {
     else if (bm == 64 && bn == 128) rc = launch_tile<64, 128>(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
     else rc = launch_tile<64, 64>(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
     if (rc) return rc;
-    if (splits > 1) {
+    d->split_used = splits > 1 ? splits : 1;
+    if (splits > 1 && !d->defer_reduce) {
         long long n = (long long)d->M * d->ldc;
         int blocks = (int)((n / 4 + 255) / 256);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace,

@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ w, const float* __restrict__ rstd,
                                                      float* __restrict__ dx, float* __restrict__ dwp, int rows, int d,
                                                      int accum_dx, uint32_t thr, uint32_t seed, int group, int gstride,
-                                                     bf16_t* __restrict__ dxb, uint32_t thr2, uint32_t seed2) {
+                                                     bf16_t* __restrict__ dxb, uint32_t thr2, uint32_t seed2, int nslabs,
+                                                     long long slab_stride) {
     extern __shared__ float red[];                       // [4][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 dwacc[LN_MAXCH];
@@ -91,6 +92,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             if (c < d) {
                 xv[k] = *reinterpret_cast<const float4*>(xr + c);
                 float4 t = *reinterpret_cast<const float4*>(gr + c);
+                for (int sl = 1; sl < nslabs; ++sl) {          // dy handed over as split-K slabs of the producing GEMM: fixed-order sum
+                    const float4 u = *reinterpret_cast<const float4*>(gr + (size_t)sl * slab_stride + c);
+                    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                }
                 if (thr) {
                     uint32_t idx = (uint32_t)row * (uint32_t)d + (uint32_t)c;
                     t.x = drop_keep(seed, idx, thr) ? t.x * dsc : 0.f;
@@ -213,7 +218,16 @@ extern "C" int vlt5_layernorm_bwd(const float* dy, const float* x, const float* 
                                   float* dw_partial, int rows, int d, int accum_dx, int accum_dw, float drop_p,
                                   uint32_t drop_seed, int in_group, int in_group_stride, void* dx_bf16, float dx_drop_p,
                                   uint32_t dx_drop_seed, void* stream) {
+    return vlt5_layernorm_bwd_slabs(dy, 1, 0, x, w, rstd, dx, dw, dw_partial, rows, d, accum_dx, accum_dw, drop_p, drop_seed, in_group,
+                                    in_group_stride, dx_bf16, dx_drop_p, dx_drop_seed, stream);
+}
+
+extern "C" int vlt5_layernorm_bwd_slabs(const float* dy, int nslabs, long long slab_stride, const float* x, const float* w,
+                                        const float* rstd, float* dx, float* dw, float* dw_partial, int rows, int d, int accum_dx,
+                                        int accum_dw, float drop_p, uint32_t drop_seed, int in_group, int in_group_stride,
+                                        void* dx_bf16, float dx_drop_p, uint32_t dx_drop_seed, void* stream) {
     if (!dy || !x || !w || !rstd || !dx || !dw_partial || rows <= 0) return VLT5_ERR_ARG;
+    if (nslabs < 1 || (nslabs > 1 && (slab_stride <= 0 || (slab_stride & 3)))) return VLT5_ERR_ARG;
     if ((d & 3) || d > 256 * LN_MAXCH_MAX) return VLT5_ERR_ALIGN;
     uint32_t thr = drop_p > 0.f ? drop_thr16(drop_p) : 0u;
     uint32_t thr2 = dx_drop_p > 0.f ? drop_thr16(dx_drop_p) : 0u;
@@ -221,11 +235,11 @@ extern "C" int vlt5_layernorm_bwd(const float* dy, const float* x, const float* 
     if (d <= 1024)
         hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(256), 4 * d * sizeof(float), (hipStream_t)stream, dy, x, w, rstd, dx,
                            dw_partial, rows, d, accum_dx, thr, drop_seed, in_group, in_group_stride, (bf16_t*)dx_bf16, thr2,
-                           dx_drop_seed);
+                           dx_drop_seed, nslabs, slab_stride);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<8>, dim3(nblk), dim3(256), 4 * d * sizeof(float), (hipStream_t)stream, dy, x, w, rstd, dx,
                            dw_partial, rows, d, accum_dx, thr, drop_seed, in_group, in_group_stride, (bf16_t*)dx_bf16, thr2,
-                           dx_drop_seed);
+                           dx_drop_seed, nslabs, slab_stride);
     LAUNCH_CHECK();
     if (dw) {
         hipLaunchKernelGGL(colsum_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)stream, dw_partial, dw, nblk, d, d,
