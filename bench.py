@@ -219,6 +219,49 @@ def main():
             step_host()
         torch.cuda.synchronize()
         out["samples_per_sec_pcie_inclusive"] = round(5 * B / (time.perf_counter() - t1), 2)
+        # f-2 feed: the same step fed from the HBM-resident bf16 feature store (vqacl_amd/feed.py): a fresh random draw of
+        # 80 images out of 4096 per step, only ids / labels / slot indices come from the host.  Also never `value`.
+        from vqacl_amd.feed import FeatureStore
+        n_img = 4096
+        store = FeatureStore(n_img, n_boxes=V, feat_dim=cfg.feat_dim, device=dev)
+        for a in range(0, n_img, 256):
+            store.put(list(range(a, a + 256)), torch.relu(torch.randn(256, V, cfg.feat_dim, device=dev)) * 1.5,
+                      torch.rand(256, V, 4, device=dev).sort(-1).values)
+        small = {k: v for k, v in host.items() if k not in ("vis_feats", "boxes")}
+        draws = [torch.randint(0, n_img, (B,)).tolist() for _ in range(8)]
+
+        def step_store(i):
+            fed = dict(small)
+            fed["feat_ref"] = store.ref(draws[i % 8])
+            res = handle.train_step(fed, 0, 0.5, 0.3)
+            res["loss"].backward()
+            opt.step()
+            for p in model.parameters():
+                p.grad = None
+        for i in range(2):
+            step_store(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(8):
+            step_store(i)
+        torch.cuda.synchronize()
+        out["samples_per_sec_store_feed"] = round(8 * B / (time.perf_counter() - t1), 2)
+        # the gather kernel against the HBM roofline: algorithmic bytes = rows read + rows written (bf16 features + f32 boxes)
+        slots = store.slots(draws[0])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        store.gather(slots)
+        e0.record()
+        for _ in range(20):
+            store.gather(slots)
+        e1.record()
+        e1.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        gbytes = 2 * B * V * (cfg.feat_dim * 2 + 16) / 1e9
+        out["feed"] = {"kernel": "feat_gather_kernel", "bound": "hbm", "bytes_per_launch": int(gbytes * 1e9), "us": round(us, 2),
+                       "achieved": round(gbytes / (us * 1e-6), 1), "peak": 8000.0, "unit": "GB/s",
+                       "frac": round(gbytes / (us * 1e-6) / 8000.0, 4), "store_images": n_img,
+                       "store_gb": round(n_img * V * (cfg.feat_dim * 2 + 16) / 1e9, 3)}
+        del store
     if rank == 0 and world == 1 and not distributed and not args.no_roofline:
         rows = time_gemms(cfg, B, L, V, T, dev)
         launches = sum(r["count"] for r in rows)

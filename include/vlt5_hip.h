@@ -24,7 +24,7 @@ extern "C" {
 #define VLT5_OK 0
 #define VLT5_ERR_ARG 1001
 #define VLT5_ERR_ALIGN 1002
-#define VLT5_ABI_VERSION 1
+#define VLT5_ABI_VERSION 2
 
 int vlt5_abi_version(void);
 
@@ -244,7 +244,24 @@ typedef struct {
     void** wait_events; int n_wait_events;   /* optional hipEvent_t per parameter bucket (same numbering): the forward phases
                                       make the stream wait for bucket b's event before the first kernel that reads that
                                       bucket's weights -- lets an optimizer update on another stream overlap the forward */
+    /* optional HBM-resident region-feature store (vlt5_feat_store_put): when feat_store != NULL the step's visual inputs are
+     * rows of the store selected by feat_slots and vis_feats / boxes are ignored (may be NULL) */
+    const void* feat_store;        /* bf16 [n_slots][V][feat_dim] */
+    const float* box_store;        /* f32  [n_slots][V][4], normalised boxes */
+    const long long* feat_slots;   /* [B] slot of each sample */
+    long long n_slots;
 } vlt5_step;
+
+/* ---- batch feed from a resident feature store (replaces the per-item HDF5 read + collate + H2D copy of
+ *      src/vqa_data_memory.py:141-189, 291-396) ----
+ * put: store[slots[i]] = bf16(feats[i]) (round to nearest even: exactly the rounding the engine applies to the f32 batch),
+ *      box_store[slots[i]] = boxes[i]; feats f32 [n,V,feat_dim], boxes f32 [n,V,4] device pointers.
+ * gather: out_feats[b] = store[slots[b]], out_boxes[b] = box_store[slots[b]]; a slot outside [0,n_slots) yields a zero row
+ *      (put: is skipped) -- the host side validates before launching. feat_dim % 8 == 0, V <= 256. */
+int vlt5_feat_store_put(const float* feats, const float* boxes, const long long* slots, int n, void* store_bf16,
+                        float* box_store, long long n_slots, int V, int feat_dim, void* stream);
+int vlt5_feat_gather(const void* store_bf16, const float* box_store, const long long* slots, long long n_slots,
+                     void* out_feats_bf16, float* out_boxes, int B, int V, int feat_dim, void* stream);
 
 /* parameter layout */
 int vlt5_layout_count(const vlt5_config* c);

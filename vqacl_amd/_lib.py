@@ -48,7 +48,8 @@ class Step(C.Structure):
                 ("params", vp), ("params_bf16", vp), ("grads", vp), ("workspace", vp), ("workspace_bytes", c_ll),
                 ("vis_feats", vp), ("boxes", vp), ("input_ids", vp), ("labels", vp), ("scores", vp),
                 ("enc_lut", vp), ("dec_lut", vp), ("gout", vp), ("d_loss_tok", vp), ("events", C.POINTER(vp)), ("n_events", c_i),
-                ("wait_events", C.POINTER(vp)), ("n_wait_events", c_i)]
+                ("wait_events", C.POINTER(vp)), ("n_wait_events", c_i),
+                ("feat_store", vp), ("box_store", vp), ("feat_slots", vp), ("n_slots", c_ll)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/vlt5_hip.h
@@ -60,6 +61,8 @@ PROTOTYPES = {
     "vlt5_layernorm_fwd": (c_i, [vp, vp, vp, vp, vp, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),
     "vlt5_layernorm_bwd": (c_i, [vp, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, c_f, c_u32, vp]),
     "vlt5_layernorm_bwd_slabs": (c_i, [vp, c_i, c_ll, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, c_f, c_u32, vp]),
+    "vlt5_feat_store_put": (c_i, [vp, vp, vp, c_i, vp, vp, c_ll, c_i, c_i, vp]),
+    "vlt5_feat_gather": (c_i, [vp, vp, vp, c_ll, vp, vp, c_i, c_i, c_i, vp]),
     "vlt5_colsum_multi": (c_i, [vp, vp, C.POINTER(c_ll), C.POINTER(c_i), c_i, c_i, c_i, vp]),
     "vlt5_layernorm_bwd_blocks": (c_i, [c_i]),
     "vlt5_attn_fwd": (c_i, [C.POINTER(AttnDesc), vp]),
@@ -126,7 +129,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.vlt5_abi_version() != 1:
+        if L.vlt5_abi_version() != 2:
             raise Vlt5Error("libvlt5_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -115,7 +115,7 @@ void build_layout(const vlt5_config& c, Layout& L, bool names) {
 struct Plan {
     int B, L, V, T, S, Sx, M, Mx, Md;
     size_t total;
-    size_t feats_bf16, visG, vis_rf, vis_rp, mask, enc_bias;
+    size_t feats_bf16, boxes_g, visG, vis_rf, vis_rp, mask, enc_bias;
     size_t x[2 * MAXL + 1], xr[2 * MAXL + 1];
     size_t xn_a[MAXL], qkv[MAXL], lse[MAXL], ctx[MAXL], xn_f[MAXL], h[MAXL];
     size_t enc_out, enc_ext, mask_ext;
@@ -141,6 +141,7 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     p.feats_bf16 = take((size_t)B * V * c.feat_dim * 2);
+    p.boxes_g = take((size_t)B * V * 4 * 4);
     p.visG = take((size_t)B * V * d * 4);
     p.vis_rf = take((size_t)B * V * 4);
     p.vis_rp = take((size_t)B * V * 4);
@@ -221,12 +222,14 @@ struct Ctx {
         d = c.d_model; inner = c.num_heads * c.d_kv; ff = c.d_ff; H = c.num_heads;
     }
     template <class T> T* w(size_t off) const { return reinterpret_cast<T*>(ws + off); }
+    const float* boxes() const { return s.feat_store ? w<float>(p.boxes_g) : s.boxes; }    // gathered from the store, or the caller's
     uint32_t seed(uint32_t site) const { return site_seed(s.seed, site); }
     int check(bool bwd) const {
         if (!s.params || !s.params_bf16 || !s.workspace) return VLT5_ERR_ARG;
         if (bwd && !s.grads) return VLT5_ERR_ARG;
         if (s.workspace_bytes < (long long)p.total) return VLT5_ERR_ARG;
         if (c.num_layers > MAXL || c.num_decoder_layers > MAXL) return VLT5_ERR_ARG;
+        if (s.feat_store && (!s.box_store || !s.feat_slots || s.n_slots <= 0)) return VLT5_ERR_ARG;
         if (p.Sx > 64 || s.T > 64 || c.d_kv > 64 || s.B < 1 || s.L < 1 || s.V < 1 || s.T < 1) return VLT5_ERR_ARG;
         if ((d & 7) || (inner & 7) || (ff & 7) || (c.vocab & 7) || (c.feat_dim & 7) || (c.d_kv & 7)) return VLT5_ERR_ALIGN;
         return VLT5_OK;
@@ -351,9 +354,13 @@ int encoder_fwd(const Ctx& k) {
     RC(vlt5_build_mask(s.input_ids, k.w<float>(p.mask), B, s.L, S, c.pad_id, k.st));
     RC(vlt5_relbias_build(k.P + L.enc_rel, s.enc_lut, k.w<float>(p.enc_bias), k.H, s.L, s.L, c.rel_buckets, k.st));
     RC(vlt5_embed_fwd(s.input_ids, k.P + L.shared, x0, (long long)S * d, d, B, s.L, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, 0, k.st));
-    RC(vlt5_cast_bf16(s.vis_feats, k.w<void>(p.feats_bf16), (long long)B * s.V * c.feat_dim, k.st));
+    if (s.feat_store)       // batch assembled from the resident store: bf16 rows as they are (the rounding the cast would apply)
+        RC(vlt5_feat_gather(s.feat_store, s.box_store, s.feat_slots, s.n_slots, k.w<void>(p.feats_bf16), k.w<float>(p.boxes_g), B, s.V,
+                            c.feat_dim, k.st));
+    else
+        RC(vlt5_cast_bf16(s.vis_feats, k.w<void>(p.feats_bf16), (long long)B * s.V * c.feat_dim, k.st));
     RC(k.lin_fwd(k.w<bf16_t>(p.feats_bf16), k.Pb + L.vis_wf, k.w<void>(p.visG), B * s.V, d, c.feat_dim, 1, 1.f, k.P + L.vis_bf));
-    RC(vlt5_vis_embed_fwd(k.w<float>(p.visG), s.boxes, k.P + L.vis_wp, k.P + L.vis_bp, k.P + L.vis_lnf, k.P + L.vis_lnp,
+    RC(vlt5_vis_embed_fwd(k.w<float>(p.visG), k.boxes(), k.P + L.vis_wp, k.P + L.vis_bp, k.P + L.vis_lnf, k.P + L.vis_lnp,
                           k.P + L.vis_img, k.P + L.shared, x0 + (size_t)s.L * d, (long long)S * d, d, k.w<float>(p.vis_rf),
                           k.w<float>(p.vis_rp), B, s.V, d, c.vocab, c.eps, k.pdrop, k.seed(SITE_ENC_EMBED), S, s.L, k.st));
     for (int l = 0; l < c.num_layers; ++l) {
@@ -628,7 +635,7 @@ int encoder_bwd(const Ctx& k) {
     // inputs: text rows -> shared (scatter-add), visual rows -> visual embedding parameters
     RC(vlt5_embed_bwd(s.input_ids, dx, (long long)S * d, d, k.Gr + L.shared, B, s.L, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, 0, k.st));
     float* vpart = k.w<float>(p.vis_partial);
-    RC(vlt5_vis_embed_bwd(dx + (size_t)s.L * d, (long long)S * d, d, k.w<float>(p.visG), s.boxes, k.P + L.vis_wp, k.P + L.vis_bp,
+    RC(vlt5_vis_embed_bwd(dx + (size_t)s.L * d, (long long)S * d, d, k.w<float>(p.visG), k.boxes(), k.P + L.vis_wp, k.P + L.vis_bp,
                           k.P + L.vis_lnf, k.P + L.vis_lnp, k.w<float>(p.vis_rf), k.w<float>(p.vis_rp), k.w<void>(p.vis_dG), vpart,
                           k.Gr + L.shared, B, s.V, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, s.L, k.st));
     const int nsp = vlt5_vis_embed_bwd_blocks(B * s.V);

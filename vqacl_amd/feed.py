@@ -1,0 +1,203 @@
+"""Batch feed for the train/test step (reference: VL-T5/src/vqa_data_memory.py:141-189 item read,
+:291-396 `collate_fn`).
+
+The reference reads `{img_id}/features [36,2048] f32`, `boxes`, `img_w/h` from HDF5 per item in 4 loader workers, collates on the
+host and copies 23.6 MB of f32 features per step over PCIe.  At >7k samples/s that copy and the per-item reads are the
+bottleneck, and the whole VQA v2 feature set is 12 GB in bf16 -- 4 % of one MI355X's HBM.  So:
+
+* `FeatureStore`: every image's features live in HBM as bf16 rows (`vlt5_feat_store_put` rounds to nearest even -- the rounding
+  the engine applies to the f32 batch before its projection GEMM, so nothing downstream changes by a bit), boxes as f32;
+* `collate(entries, store=...)`: same batch dict as the reference's `collate_fn`, except that `vis_feats`/`boxes` are replaced by
+  `feat_ref = StoreRef(store, slots)`; the engine gathers the rows itself (`vlt5_feat_gather`, one HBM-bound launch) -- only the
+  token ids, labels and B slot indices cross PCIe;
+* without a store `collate` returns exactly the reference's batch (host tensors), which `VLT5VQA.train_step` also accepts.
+
+There is no CPU path for the store: it needs the HIP library and a GPU.
+"""
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+StoreRef = namedtuple("StoreRef", ["store", "slots"])        # slots: int64 [B] on the store's device
+
+
+def normalize_boxes(boxes, img_w, img_h):
+    """(x1, y1, x2, y2) in pixels -> [0, 1], as the item read does (vqa_data_memory.py:179-187): divide by the image size, insist
+    on -1e-5 < box < 1+1e-5 (AssertionError otherwise, like `np.testing.assert_array_less`), clamp to [0, 1].  Returns f32 [V,4]."""
+    boxes = np.array(boxes, dtype=np.float32, copy=True)
+    boxes[:, (0, 2)] /= img_w
+    boxes[:, (1, 3)] /= img_h
+    if not (boxes < 1 + 1e-5).all() or not (-boxes < 0 + 1e-5).all():
+        raise AssertionError("box coordinates outside the image")
+    return torch.from_numpy(boxes).clamp_(min=0.0, max=1.0)
+
+
+def collate(entries, pad_token_id=0, n_cate=80, n_task=10, store=None):
+    """The reference's `collate_fn` (vqa_data_memory.py:291-396) over the dicts its `__getitem__` returns.
+
+    Same keys, dtypes and padding: `input_ids` padded with `pad_token_id`; `target_ids` padded and every pad position set to -100;
+    `boxes`/`vis_feats` f32 [B,V,4]/[B,V,F]; `scores` f32; `cate_labels` [B,80] and `ques_labels` [B,n_task] one-hot f32;
+    host lists `sent`, `question_ids`, `answers`, `all_answers`, `labels`; `task` = 'vqa'; `args` passed through.
+    With `store`, entries need `img_id` only and the batch carries `feat_ref` instead of `vis_feats`/`boxes`."""
+    B = len(entries)
+    first = entries[0]
+    batch = {}
+    S = max(e["input_length"] for e in entries)
+    input_ids = torch.full((B, S), pad_token_id, dtype=torch.long)
+    use_vision = "boxes" in first and store is None
+    if use_vision:
+        V, F = len(first["boxes"]), first["vis_feats"].shape[-1]
+        boxes = torch.zeros(B, V, 4, dtype=torch.float)
+        vis_feats = torch.zeros(B, V, F, dtype=torch.float)
+    if "target" in first:
+        targets = torch.zeros(B, len(first["target"]), dtype=torch.float)
+    if "target_ids" in first:
+        T = max(e["target_length"] for e in entries)
+        target_ids = torch.full((B, T), pad_token_id, dtype=torch.long)
+    sentences, question_ids, answers, all_answers, labels, scores, cate, ques = [], [], [], [], [], [], [], []
+    for i, e in enumerate(entries):
+        input_ids[i, :e["input_length"]] = e["input_ids"]
+        if use_vision:
+            boxes[i] += e["boxes"]
+            vis_feats[i] += e["vis_feats"]
+        if "target_ids" in e:
+            target_ids[i, :e["target_length"]] = e["target_ids"]
+        if "target" in e:
+            targets[i] += e["target"]
+        sentences.append(e["sent"])
+        question_ids.append(e["question_id"])
+        if "answer" in e:
+            answers.append(e["answer"])
+        if "all_answers" in e:
+            all_answers.append(e["all_answers"])
+        if "score" in e:
+            scores.append(e["score"])
+        if "label" in e:
+            labels.append(e["label"])
+        if "img_cate" in e:
+            cate.append(e["img_cate"])
+        if "ques_label" in e:
+            ques.append(e["ques_label"])
+    batch["input_ids"] = input_ids
+    if "target_ids" in first:
+        target_ids[target_ids == pad_token_id] = -100
+        batch["target_ids"] = target_ids
+    if "target" in first:
+        batch["targets"] = targets
+    if use_vision:
+        batch["boxes"] = boxes
+        batch["vis_feats"] = vis_feats
+    if store is not None:
+        batch["feat_ref"] = store.ref([e["img_id"] for e in entries])
+    batch["sent"] = sentences
+    batch["question_ids"] = question_ids
+    batch["answers"] = answers
+    batch["all_answers"] = all_answers
+    batch["scores"] = torch.FloatTensor(scores)
+    batch["labels"] = labels
+    batch["args"] = first.get("args")
+    batch["task"] = "vqa"
+    cate_idx = torch.LongTensor(cate).unsqueeze(1)
+    batch["cate_labels"] = torch.zeros(cate_idx.shape[0], n_cate).scatter_(1, cate_idx, 1)
+    ques_idx = torch.LongTensor(ques).unsqueeze(1)
+    batch["ques_labels"] = torch.zeros(cate_idx.shape[0], n_task).scatter_(1, ques_idx, 1)
+    return batch
+
+
+class FeatureStore:
+    """HBM-resident region features: `feats` bf16 [capacity, V, feat_dim], `boxes` f32 [capacity, V, 4], `index` img_id -> slot.
+
+    36 x 2048 bf16 = 147 KB per image: VQA v2 train+val (123k images) is 18 GB, the 500-5000 sample rehearsal buffer 0.07-0.7 GB."""
+
+    def __init__(self, capacity, n_boxes=36, feat_dim=2048, device="cuda:0"):
+        from . import _lib
+        if not torch.cuda.is_available():
+            raise _lib.Vlt5Error("FeatureStore keeps the features in HBM: it needs a GPU (no CPU fallback)")
+        _lib.lib()
+        if feat_dim % 8 or not 0 < n_boxes <= 256 or capacity <= 0:
+            raise _lib.Vlt5Error("FeatureStore: feat_dim must be a multiple of 8, 0 < n_boxes <= 256, capacity > 0")
+        self.capacity, self.V, self.feat_dim = int(capacity), int(n_boxes), int(feat_dim)
+        self.device = torch.device(device)
+        self.feats = torch.zeros(self.capacity, self.V, self.feat_dim, dtype=torch.bfloat16, device=self.device)
+        self.boxes = torch.zeros(self.capacity, self.V, 4, dtype=torch.float32, device=self.device)
+        self.index = {}
+
+    def __len__(self):
+        return len(self.index)
+
+    def __contains__(self, img_id):
+        return img_id in self.index
+
+    def put(self, img_ids, feats, boxes, chunk=256):
+        """Store (or overwrite) the rows of `img_ids`: feats f32 [n,V,feat_dim], boxes f32 [n,V,4] (normalised), host or device."""
+        from ._lib import Vlt5Error, check, lib, ptr, stream_ptr
+        n = len(img_ids)
+        if tuple(feats.shape) != (n, self.V, self.feat_dim) or tuple(boxes.shape) != (n, self.V, 4):
+            raise Vlt5Error(f"FeatureStore.put: expected feats [{n},{self.V},{self.feat_dim}] and boxes [{n},{self.V},4]")
+        slots = []
+        for i in img_ids:
+            s = self.index.get(i)
+            if s is None:
+                s = len(self.index)
+                if s >= self.capacity:
+                    raise Vlt5Error(f"FeatureStore is full ({self.capacity} images)")
+                self.index[i] = s
+            slots.append(s)
+        for a in range(0, n, chunk):
+            b = min(n, a + chunk)
+            f = feats[a:b].to(self.device, torch.float32, non_blocking=True).contiguous()
+            x = boxes[a:b].to(self.device, torch.float32, non_blocking=True).contiguous()
+            sl = torch.tensor(slots[a:b], dtype=torch.long, device=self.device)
+            check(lib().vlt5_feat_store_put(ptr(f), ptr(x), ptr(sl), b - a, ptr(self.feats), ptr(self.boxes), self.capacity, self.V,
+                                            self.feat_dim, stream_ptr()), "vlt5_feat_store_put")
+            f.record_stream(torch.cuda.current_stream())
+        return slots
+
+    def slots(self, img_ids):
+        """int64 [B] slot indices on the store's device (KeyError for an image that was never put)."""
+        return torch.tensor([self.index[i] for i in img_ids], dtype=torch.long).to(self.device, non_blocking=True)
+
+    def ref(self, img_ids):
+        return StoreRef(self, self.slots(img_ids))
+
+    def gather(self, slots):
+        """Standalone batch assembly (the engine does the same inside `vlt5_encoder_fwd`): bf16 [B,V,feat_dim], f32 [B,V,4]."""
+        from ._lib import Vlt5Error, check, lib, ptr, stream_ptr
+        if slots.dtype != torch.long or slots.device != self.device:
+            raise Vlt5Error("FeatureStore.gather: slots must be int64 on the store's device")
+        B = slots.numel()
+        out_f = torch.empty(B, self.V, self.feat_dim, dtype=torch.bfloat16, device=self.device)
+        out_b = torch.empty(B, self.V, 4, dtype=torch.float32, device=self.device)
+        check(lib().vlt5_feat_gather(ptr(self.feats), ptr(self.boxes), ptr(slots), self.capacity, ptr(out_f), ptr(out_b), B, self.V,
+                                     self.feat_dim, stream_ptr()), "vlt5_feat_gather")
+        return out_f, out_b
+
+
+class H5FeatureSource:
+    """The reference's on-disk format (vqa_data_memory.py:124-134,166-187): `{img_id}/features [n_boxes,2048] f32`,
+    `{img_id}/boxes [n_boxes,4]` in pixels, `{img_id}/img_w`, `{img_id}/img_h`.  Needs h5py (not in this image: the class raises
+    ImportError when constructed without it; everything else in this module works without)."""
+
+    def __init__(self, path, n_boxes=36, feat_dim=2048):
+        import h5py
+        self.f = h5py.File(path, "r")
+        self.n_boxes, self.feat_dim = n_boxes, feat_dim
+
+    def read(self, img_id):
+        feats = np.zeros(shape=(self.n_boxes, self.feat_dim), dtype=np.float32)
+        self.f[f"{img_id}/features"].read_direct(feats)
+        boxes = normalize_boxes(self.f[f"{img_id}/boxes"][()], self.f[f"{img_id}/img_w"][()], self.f[f"{img_id}/img_h"][()])
+        return torch.from_numpy(feats), boxes
+
+    def fill(self, store, img_ids, chunk=256):
+        """Load `img_ids` into a FeatureStore through a pinned staging buffer, `chunk` images per copy."""
+        stage_f = torch.empty(chunk, store.V, store.feat_dim, dtype=torch.float32).pin_memory()
+        stage_b = torch.empty(chunk, store.V, 4, dtype=torch.float32).pin_memory()
+        for a in range(0, len(img_ids), chunk):
+            ids = img_ids[a:a + chunk]
+            for j, i in enumerate(ids):
+                f, b = self.read(i)
+                stage_f[j], stage_b[j] = f, b
+            store.put(ids, stage_f[:len(ids)], stage_b[:len(ids)], chunk=chunk)
+            torch.cuda.current_stream().synchronize()        # the staging buffer is reused

@@ -372,6 +372,10 @@ class VLT5(nn.Module):
         s.workspace, s.workspace_bytes = ptr(self._ws), self._ws.numel()
         s.vis_feats, s.boxes, s.input_ids = ptr(st["feats"]), ptr(st["boxes"]), ptr(st["input_ids"])
         s.labels, s.scores = ptr(st["labels"]), ptr(st.get("scores"))
+        ref = st.get("feat_ref")
+        if ref is not None:                 # the step's visual inputs are rows of the resident feature store (vqacl_amd/feed.py)
+            s.feat_store, s.box_store = ptr(ref.store.feats), ptr(ref.store.boxes)
+            s.feat_slots, s.n_slots = ptr(ref.slots), ref.store.capacity
         s.enc_lut, s.dec_lut = ptr(st["enc_lut"]), ptr(st["dec_lut"])
         if self._opt_events is not None:
             # an optimizer is (possibly still) updating the parameters on its own stream: the engine waits bucket by bucket
@@ -379,6 +383,22 @@ class VLT5(nn.Module):
             st["_wait_arr"] = arr                                   # keep the array alive as long as the step state
             s.wait_events, s.n_wait_events = arr, len(self._opt_events)
         return s
+
+    def _visual_inputs(self, vis_inputs):
+        """(feats f32, boxes f32, V, None) for the reference's `(vis_feats, boxes)` pair, or (None, None, V, ref) for a
+        `feed.StoreRef` -- rows of the HBM-resident feature store, gathered by the engine itself."""
+        from .feed import StoreRef
+        dev = self._device
+        if isinstance(vis_inputs, StoreRef):
+            st = vis_inputs.store
+            if st.feats.device != dev or st.feat_dim != self.cfg.feat_dim:
+                raise L.Vlt5Error("feature store lives on another device or has another feature width than the model")
+            if vis_inputs.slots.device != dev or vis_inputs.slots.dtype != torch.long:
+                raise L.Vlt5Error("StoreRef.slots must be an int64 tensor on the model's device")
+            return None, None, st.V, vis_inputs
+        feats = vis_inputs[0].to(dev, torch.float32).contiguous()
+        boxes = vis_inputs[1].to(dev, torch.float32).contiguous()
+        return feats, boxes, feats.shape[1], None
 
     def sync_optimizer(self):
         """Make the current stream wait for an overlapped optimizer update (FusedAdamW(overlap=True)) -- call before
@@ -404,12 +424,11 @@ class VLT5(nn.Module):
         if labels is None:
             raise NotImplementedError("decoding without labels is the generate path (vqa_model.test_step)")
         dev = self._device
-        feats = vis_inputs[0].to(dev, torch.float32).contiguous()
-        boxes = vis_inputs[1].to(dev, torch.float32).contiguous()
+        feats, boxes, V, ref = self._visual_inputs(vis_inputs)
         input_ids = input_ids.to(dev).contiguous()
         labels = labels.to(dev).contiguous()
         B, Lt = input_ids.shape
-        V, T = feats.shape[1], labels.shape[1]
+        T = labels.shape[1]
         S, Sx, d = Lt + V, Lt + V + 2, self.cfg.d_model
         dims = (B, Lt, V, T)
         self._workspace(*dims)
@@ -417,7 +436,7 @@ class VLT5(nn.Module):
         training = self.training
         self._step_count += 1
         st = dict(dims=dims, training=training, seed=(self.base_seed + 0x9E3779B1 * self._step_count) & 0xFFFFFFFF,
-                  feats=feats, boxes=boxes, input_ids=input_ids, labels=labels,
+                  feats=feats, boxes=boxes, feat_ref=ref, input_ids=input_ids, labels=labels,
                   enc_lut=self._lut(Lt, Lt, True), dec_lut=self._lut(T, T, False))
         if scores is not None:
             st["scores"] = scores.to(dev, torch.float32).contiguous()

@@ -9,6 +9,13 @@ import torch
 from .modeling_vlt5 import VLT5
 
 
+def _vis_inputs(batch):
+    """`(vis_feats, boxes)` as collated by the reference (vqa_data_memory.py:365-396), or the batch's rows of the HBM-resident
+    feature store (`feat_ref`, vqacl_amd/feed.py) when the feed keeps the features on the GPU."""
+    ref = batch.get("feat_ref")
+    return ref if ref is not None else (batch["vis_feats"], batch["boxes"])
+
+
 class VLT5VQA(VLT5):
     def __init__(self, config, num_answers=None, label2ans=None, **kw):
         super().__init__(config, **kw)
@@ -20,7 +27,7 @@ class VLT5VQA(VLT5):
         lm_labels = batch["target_ids"].to(device)
         output = self(
             input_ids=batch["input_ids"],
-            vis_inputs=(batch["vis_feats"], batch["boxes"]),
+            vis_inputs=_vis_inputs(batch),
             labels=lm_labels,
             cate_labels=batch["cate_labels"],
             ques_labels=batch["ques_labels"],
@@ -48,7 +55,7 @@ class VLT5VQA(VLT5):
         The encoder and the prototype retrieval run once; every further token is ONE incremental decoder step over a
         key/value cache (`vlt5_decoder_step`)."""
         self.eval()
-        token_ids = self.greedy_generate(batch["input_ids"], (batch["vis_feats"], batch["boxes"]),
+        token_ids = self.greedy_generate(batch["input_ids"], _vis_inputs(batch),
                                          max_length=kwargs.get("max_length", 20))
         result = {"token_ids": token_ids}
         if self.tokenizer is not None:
@@ -71,17 +78,16 @@ class VLT5VQA(VLT5):
         if not 2 <= max_length <= 64:
             raise L.Vlt5Error("max_length must be in [2, 64] (the key/value cache of the attention kernel)")
         dev = self._device
-        feats = vis_inputs[0].to(dev, torch.float32).contiguous()
-        boxes = vis_inputs[1].to(dev, torch.float32).contiguous()
+        feats, boxes, V, ref = self._visual_inputs(vis_inputs)
         input_ids = input_ids.to(dev).contiguous()
         B, Lt = input_ids.shape
-        V, Tcap = feats.shape[1], int(max_length)
+        Tcap = int(max_length)
         S, Sx, d = Lt + V, Lt + V + 2, self.cfg.d_model
         dims = (B, Lt, V, Tcap)
         self._workspace(*dims)
         self.sync_bf16()
         pad, start = self.cfg.pad_token_id, self.cfg.decoder_start_token_id
-        st = dict(dims=dims, training=False, seed=0, feats=feats, boxes=boxes, input_ids=input_ids,
+        st = dict(dims=dims, training=False, seed=0, feats=feats, boxes=boxes, feat_ref=ref, input_ids=input_ids,
                   labels=torch.zeros(B, Tcap, dtype=torch.long, device=dev),
                   enc_lut=self._lut(Lt, Lt, True), dec_lut=self._lut(Tcap, Tcap, False))
         c = self.cfg.c_struct()
@@ -122,8 +128,7 @@ class VLT5VQA(VLT5):
         tokens = torch.full((B, 1), start, dtype=torch.long, device=device)
         done = torch.zeros(B, dtype=torch.bool, device=device)
         input_ids = input_ids.to(device)
-        vis_inputs = (vis_inputs[0].to(device), vis_inputs[1].to(device))
-        self._workspace(B, input_ids.shape[1], vis_inputs[0].shape[1], max_length)    # size the arena once for the longest prefix
+        self._workspace(B, input_ids.shape[1], self._visual_inputs(vis_inputs)[2], max_length)    # size the arena once for the longest prefix
         for step in range(max_length - 1):
             # labels whose shift-right equals the current prefix: prefix[1:] followed by one dummy position
             labels = torch.cat([tokens[:, 1:], torch.full((B, 1), pad, dtype=torch.long, device=device)], dim=1)
