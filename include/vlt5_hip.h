@@ -69,6 +69,14 @@ int vlt5_layernorm_fwd(const float* x, const float* w, void* y_bf16, float* y_f3
  *   reduces later (the engine reduces all norms of a phase with ONE vlt5_colsum_multi launch).
  * dx_bf16 (optional): also emit bf16(dropout(dx)) with (dx_drop_p, dx_drop_seed), element index r*d+c -- the operand the
  *   next sublayer's backward GEMMs read, saving a separate vlt5_drop_cast pass. */
+/* same, with the input row assembled first from the `nslabs` split-K slabs of the producing GEMM (vlt5_gemm_desc.defer_reduce):
+ * x_out[r] = resid[r] + dropout(sum_s slabs[s*slab_stride + r*d ..], resid_drop_p, resid_drop_seed) (element index r*d+c, the
+ * index the GEMM's own dropout epilogue uses), then normalised as above -- the kernel stands in for the residual/dropout
+ * epilogue and the slab reduction of that GEMM */
+int vlt5_layernorm_fwd_slabs(const float* slabs, int nslabs, long long slab_stride, const float* resid, float* x_out,
+                             float resid_drop_p, uint32_t resid_drop_seed, const float* w, void* y_bf16, float* y_f32,
+                             float* rstd, int rows, int d, float eps, float drop_p, uint32_t drop_seed, int out_group,
+                             int out_group_stride, void* stream);
 int vlt5_layernorm_bwd(const float* dy, const float* x, const float* w, const float* rstd,
                        float* dx, float* dw, float* dw_partial, int rows, int d,
                        int accum_dx, int accum_dw, float drop_p, uint32_t drop_seed,

@@ -203,6 +203,47 @@ def test_layernorm_fwd_bwd(dev, rows, d):
                                           0, 0, 0.0, 0, 0, 0, None, 0.0, 0, stream_ptr()) == 1001
 
 
+@pytest.mark.parametrize("rows,d,K,splits", [(400, 768, 3072, 8), (136, 64, 256, 3), (37, 1024, 192, 1)])
+def test_layernorm_fwd_from_deferred_slabs(dev, rows, d, K, splits):
+    """Sublayer output left as split-K slabs + LayerNorm that assembles the row (slab sum, dropout, residual) == the GEMM's own
+    residual/dropout epilogue followed by the plain LayerNorm: same dropout mask, values equal up to the f32 summation order."""
+    import ctypes as C
+    from vqacl_amd import ops
+    from vqacl_amd._lib import GemmDesc, check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(rows + d)
+    A = rnd((rows, K), g).to(BF).to(dev)
+    W = (rnd((d, K), g) * 0.05).to(BF).to(dev)
+    resid = rnd((rows, d), g).to(dev)
+    w = (1 + 0.1 * rnd((d,), g)).to(dev)
+    for dp, seed in ((0.0, 0), (0.1, 977)):
+        x_ref = ops.gemm(A, W, rows, d, K, out_f32=True, resid=resid, drop_p=dp, drop_seed=seed, tile=(64, 64))
+        yb_ref, yf_ref, rstd_ref = ops.layernorm_fwd(x_ref, w, want_f32=True, drop_p=dp, drop_seed=seed + 1)
+        slabs = torch.full((max(splits, 1), rows, d), float("nan"), device=dev)
+        gd = GemmDesc()
+        gd.A, gd.B, gd.C = ptr(A), ptr(W), ptr(slabs)
+        gd.M, gd.N, gd.K, gd.lda, gd.ldb, gd.ldc, gd.alpha, gd.out_f32 = rows, d, K, K, K, d, 1.0, 1
+        gd.split_k, gd.workspace, gd.defer_reduce, gd.tile_m, gd.tile_n = splits, ptr(slabs), 1, 64, 64
+        check(lib().vlt5_gemm_bf16(C.byref(gd), stream_ptr()))
+        assert 1 <= gd.split_used <= splits and (gd.split_used == splits or K // 64 % splits)      # (clipped to whole k-tiles)
+        x = torch.empty(rows, d, device=dev)
+        yb = torch.empty(rows, d, device=dev, dtype=BF)
+        yf = torch.empty(rows, d, device=dev)
+        rstd = torch.empty(rows, device=dev)
+        check(lib().vlt5_layernorm_fwd_slabs(ptr(slabs), gd.split_used, rows * d, ptr(resid), ptr(x), dp, seed, ptr(w), ptr(yb), ptr(yf),
+                                             ptr(rstd), rows, d, 1e-6, dp, seed + 1, 0, 0, stream_ptr()))
+        close(x, x_ref, 2e-5, 2e-5, "row assembled from slabs")
+        if dp > 0:
+            assert torch.equal(x == resid, x_ref == resid)               # identical dropout mask on the projection
+            assert torch.equal(yf == 0, yf_ref == 0)
+        close(yf, yf_ref, 1e-4, 1e-4, "normalised row")
+        close(rstd, rstd_ref, 1e-5, 1e-5, "rstd")
+        close(yb.float(), yb_ref.float(), 1e-2, 1e-2, "bf16 operand")
+    assert lib().vlt5_layernorm_fwd_slabs(ptr(slabs), 2, 0, ptr(resid), ptr(x), 0.0, 0, ptr(w), ptr(yb), None, ptr(rstd), rows, d, 1e-6,
+                                          0.0, 0, 0, 0, stream_ptr()) == 1001
+    assert lib().vlt5_layernorm_fwd_slabs(ptr(slabs), 1, 0, None, ptr(x), 0.0, 0, ptr(w), ptr(yb), None, ptr(rstd), rows, d, 1e-6,
+                                          0.0, 0, 0, 0, stream_ptr()) == 1001
+
+
 def test_layernorm_golden(dev):
     from vqacl_amd import ops
     G = load_golden("g3_hf_leaves")

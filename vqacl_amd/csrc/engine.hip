@@ -246,6 +246,31 @@ struct Ctx {
         return vlt5_gemm_bf16(&g, st);
     }
     int pick_split(int M, int N, int Kred) const { return vlt5_gemm_auto_split(M, N, Kred, (long long)p.slab_bytes); }
+    // y = resid + dropout(x W^T) for a sublayer output that only a LayerNorm consumes next: when the reduction is long and the output
+    // small (decoder FFN: 400 x 768 over K = 3072, 84 tiles for 256 CUs) the GEMM is cut into split-K slices that stay in the slab
+    // scratch, and ln_fwd_pending() assembles the row (slab sum, dropout, residual) while it normalises it.  *pending = number
+    // of slabs left for the norm (0: y was written by the GEMM's own epilogue as usual).
+    int lin_fwd_for_norm(const bf16_t* X, const bf16_t* W, float* Y, int M, int N, int K, float dp, uint32_t dseed,
+                         const float* resid, int* pending) const {
+        *pending = 0;
+        const int sk = pick_split(M, N, K);
+        if (sk <= 1) return lin_fwd(X, W, Y, M, N, K, 1, 1.f, nullptr, 0, dp, dseed, resid);
+        vlt5_gemm_desc g;
+        memset(&g, 0, sizeof g);
+        g.A = X; g.B = W; g.C = w<void>(p.slab); g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
+        g.alpha = 1.f; g.out_f32 = 1; g.split_k = sk; g.workspace = w<void>(p.slab); g.defer_reduce = 1;
+        int rc = vlt5_gemm_bf16(&g, st);
+        *pending = g.split_used;             // (1: the policy clipped the split; the un-split product lies in the slab scratch too)
+        return rc;
+    }
+    // LayerNorm forward of x, or -- pending > 0 -- of resid + dropout(sum of the pending slabs), which is also stored to x
+    int ln_fwd_pending(int pending, float* x, const float* resid, float rdp, uint32_t rseed, long long w_off, void* y_bf16, float* y_f32,
+                       float* rstd, int rows, float dp, uint32_t dseed, int og, int ogs) const {
+        if (pending > 0)
+            return vlt5_layernorm_fwd_slabs(w<float>(p.slab), pending, (long long)rows * d, resid, x, rdp, rseed, P + w_off, y_bf16, y_f32,
+                                            rstd, rows, d, c.eps, dp, dseed, og, ogs, st);
+        return vlt5_layernorm_fwd(x, P + w_off, y_bf16, y_f32, rstd, rows, d, c.eps, dp, dseed, og, ogs, st);
+    }
     // dX[M,K] = epi(alpha * dY[M,N] W[N,K])     (W read k-major)
     // `slabs` (optional): the consumer is a LayerNorm backward that can sum split-K slabs itself -- on return *slabs = number of
     // slabs left in the slab scratch (1: dX was written as usual)
@@ -363,6 +388,7 @@ int encoder_fwd(const Ctx& k) {
     RC(vlt5_vis_embed_fwd(k.w<float>(p.visG), k.boxes(), k.P + L.vis_wp, k.P + L.vis_bp, k.P + L.vis_lnf, k.P + L.vis_lnp,
                           k.P + L.vis_img, k.P + L.shared, x0 + (size_t)s.L * d, (long long)S * d, d, k.w<float>(p.vis_rf),
                           k.w<float>(p.vis_rp), B, s.V, d, c.vocab, c.eps, k.pdrop, k.seed(SITE_ENC_EMBED), S, s.L, k.st));
+    int pending = 0;                                          // split-K slabs of the previous layer's FFN output, if any
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& E = L.enc[l];
         const uint32_t sb = SITE_ENC_BASE + l * 8;
@@ -371,7 +397,8 @@ int encoder_fwd(const Ctx& k) {
         float* xf = k.w<float>(p.x[2 * l + 1]);
         float* xo = k.w<float>(p.x[2 * l + 2]);
         bf16_t* qkv = k.w<bf16_t>(p.qkv[l]);
-        RC(vlt5_layernorm_fwd(xa, k.P + E.ln_s, k.w<void>(p.xn_a[l]), nullptr, k.w<float>(p.xr[2 * l]), M, d, c.eps, 0.f, 0, 0, 0, k.st));
+        RC(k.ln_fwd_pending(pending, xa, l > 0 ? k.w<float>(p.x[2 * l - 1]) : nullptr, k.pdrop, k.seed(sb - 8 + E_FFN_OUT), E.ln_s,
+                            k.w<void>(p.xn_a[l]), nullptr, k.w<float>(p.xr[2 * l]), M, 0.f, 0, 0, 0));
         RC(k.lin_fwd(k.w<bf16_t>(p.xn_a[l]), k.Pb + E.sqkv, qkv, M, 3 * inner, d, 0));
         RC(attn_call(k, false, qkv, (long long)S * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)S * 3 * inner,
                      3 * inner, k.w<bf16_t>(p.ctx[l]), k.w<float>(p.lse[l]), k.w<float>(p.enc_bias), s.L, s.L, k.w<float>(p.mask),
@@ -379,11 +406,12 @@ int encoder_fwd(const Ctx& k) {
         RC(k.lin_fwd(k.w<bf16_t>(p.ctx[l]), k.Pb + E.so, xf, M, d, inner, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + E_ATTN_OUT), xa));
         RC(vlt5_layernorm_fwd(xf, k.P + E.ln_f, k.w<void>(p.xn_f[l]), nullptr, k.w<float>(p.xr[2 * l + 1]), M, d, c.eps, 0.f, 0, 0, 0, k.st));
         RC(k.lin_fwd(k.w<bf16_t>(p.xn_f[l]), k.Pb + E.wi, k.w<void>(p.h[l]), M, ff, d, 0, 1.f, nullptr, 1, k.pdrop, k.seed(sb + E_FFN_H)));
-        RC(k.lin_fwd(k.w<bf16_t>(p.h[l]), k.Pb + E.wo, xo, M, d, ff, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + E_FFN_OUT), xf));
+        RC(k.lin_fwd_for_norm(k.w<bf16_t>(p.h[l]), k.Pb + E.wo, xo, M, d, ff, k.pdrop, k.seed(sb + E_FFN_OUT), xf, &pending));
     }
     const int Le = c.num_layers;
-    RC(vlt5_layernorm_fwd(k.w<float>(p.x[2 * Le]), k.P + L.enc_final_ln, k.w<void>(p.enc_ext), k.w<float>(p.enc_out),
-                          k.w<float>(p.xr[2 * Le]), M, d, c.eps, k.pdrop, k.seed(SITE_ENC_FINAL), S, Sx, k.st));
+    RC(k.ln_fwd_pending(pending, k.w<float>(p.x[2 * Le]), k.w<float>(p.x[2 * Le - 1]), k.pdrop,
+                        k.seed(SITE_ENC_BASE + (Le - 1) * 8 + E_FFN_OUT), L.enc_final_ln, k.w<void>(p.enc_ext), k.w<float>(p.enc_out),
+                        k.w<float>(p.xr[2 * Le]), M, k.pdrop, k.seed(SITE_ENC_FINAL), S, Sx));
     return VLT5_OK;
 }
 
@@ -399,6 +427,7 @@ int decoder_fwd(const Ctx& k) {
     RC(vlt5_relbias_build(k.P + L.dec_rel, s.dec_lut, k.w<float>(p.dec_bias), k.H, T, T, c.rel_buckets, k.st));
     RC(k.lin_fwd(k.w<bf16_t>(p.enc_ext), k.Pb + L.cross_kv, k.w<void>(p.kv_all), Mx, kvw, d, 0));
     RC(vlt5_embed_fwd(ids, k.P + L.shared, k.w<float>(p.y[0]), (long long)T * d, d, B, T, d, c.vocab, k.pdrop, k.seed(SITE_DEC_EMBED), T, 0, k.st));
+    int pending = 0;                                          // split-K slabs of the previous layer's FFN output, if any
     for (int l = 0; l < Ld; ++l) {
         const auto& D = L.dec[l];
         const uint32_t sb = SITE_DEC_BASE + l * 8;
@@ -409,7 +438,8 @@ int decoder_fwd(const Ctx& k) {
         float* y3 = k.w<float>(p.y[3 * l + 3]);
         bf16_t* qkv = k.w<bf16_t>(p.dqkv_s[l]);
         bf16_t* kv = k.w<bf16_t>(p.kv_all) + (size_t)l * 2 * inner;
-        RC(vlt5_layernorm_fwd(y0, k.P + D.ln_s, k.w<void>(p.yn_a[l]), nullptr, k.w<float>(p.yr[3 * l]), Md, d, c.eps, 0.f, 0, 0, 0, k.st));
+        RC(k.ln_fwd_pending(pending, y0, l > 0 ? k.w<float>(p.y[3 * l - 1]) : nullptr, k.pdrop, k.seed(sb - 8 + D_FFN_OUT), D.ln_s,
+                            k.w<void>(p.yn_a[l]), nullptr, k.w<float>(p.yr[3 * l]), Md, 0.f, 0, 0, 0));
         RC(k.lin_fwd(k.w<bf16_t>(p.yn_a[l]), k.Pb + D.sqkv, qkv, Md, 3 * inner, d, 0));
         RC(attn_call(k, false, qkv, (long long)T * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)T * 3 * inner,
                      3 * inner, k.w<bf16_t>(p.ctx_s[l]), k.w<float>(p.lse_s[l]), k.w<float>(p.dec_bias), T, T, nullptr, 0.f, 1, T, T,
@@ -423,10 +453,11 @@ int decoder_fwd(const Ctx& k) {
         RC(k.lin_fwd(k.w<bf16_t>(p.ctx_c[l]), k.Pb + D.co, y2, Md, d, inner, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + D_COUT), y1));
         RC(vlt5_layernorm_fwd(y2, k.P + D.ln_f, k.w<void>(p.yn_f[l]), nullptr, k.w<float>(p.yr[3 * l + 2]), Md, d, c.eps, 0.f, 0, 0, 0, k.st));
         RC(k.lin_fwd(k.w<bf16_t>(p.yn_f[l]), k.Pb + D.wi, k.w<void>(p.hd[l]), Md, ff, d, 0, 1.f, nullptr, 1, k.pdrop, k.seed(sb + D_FFN_H)));
-        RC(k.lin_fwd(k.w<bf16_t>(p.hd[l]), k.Pb + D.wo, y3, Md, d, ff, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + D_FFN_OUT), y2));
+        RC(k.lin_fwd_for_norm(k.w<bf16_t>(p.hd[l]), k.Pb + D.wo, y3, Md, d, ff, k.pdrop, k.seed(sb + D_FFN_OUT), y2, &pending));
     }
-    RC(vlt5_layernorm_fwd(k.w<float>(p.y[3 * Ld]), k.P + L.dec_final_ln, k.w<void>(p.dec_out), nullptr, k.w<float>(p.yr[3 * Ld]), Md,
-                          d, c.eps, k.pdrop, k.seed(SITE_DEC_FINAL), 0, 0, k.st));
+    RC(k.ln_fwd_pending(pending, k.w<float>(p.y[3 * Ld]), k.w<float>(p.y[3 * Ld - 1]), k.pdrop,
+                        k.seed(SITE_DEC_BASE + (Ld - 1) * 8 + D_FFN_OUT), L.dec_final_ln, k.w<void>(p.dec_out), nullptr,
+                        k.w<float>(p.yr[3 * Ld]), Md, k.pdrop, k.seed(SITE_DEC_FINAL), 0, 0));
     const float alpha = 1.0f / sqrtf((float)d);           // tied embeddings: rescale before the vocabulary projection
     RC(k.lin_fwd(k.w<bf16_t>(p.dec_out), k.Pb + L.shared, k.w<void>(p.logits), Md, c.vocab, d, 1, alpha));
     RC(vlt5_ce_fwd(k.w<float>(p.logits), s.labels, k.w<float>(p.loss_tok), k.w<float>(p.lse_ce), Md, c.vocab, k.st));

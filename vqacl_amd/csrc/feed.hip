@@ -49,10 +49,10 @@ __global__ __launch_bounds__(256) void feat_put_kernel(const float4* __restrict_
 }
 
 int pieces_for(int chunks, int B) {
-    // enough workgroups to cover 256 CUs several times over, at least 1 KB of 16-byte chunks per lane-quad
+    // four 16-byte chunks per lane (all in flight before the first store) while that still gives >= 2 workgroups per CU
     int per = (chunks + 1023) / 1024;
     if (per < 1) per = 1;
-    while ((long long)per * B < 1024 && per * 256 < chunks) per *= 2;
+    while ((long long)per * B < 512 && per * 256 < chunks) per *= 2;
     if (per > 64) per = 64;
     return per;
 }

@@ -9,10 +9,16 @@ __device__ __forceinline__ int remap_row(int r, int group, int gstride) {
     return group > 0 ? (r / group) * gstride + (r % group) : r;
 }
 
+// SLABS: the row is not read from `x` but assembled first -- x_new = resid + dropout(sum of the `nslabs` split-K partial sums the
+// producing GEMM left at x + s*slab_stride (fixed slab order)) -- and written to `xsum` (the residual-stream snapshot backward
+// reads); i.e. the kernel also plays the residual/dropout epilogue and the slab reduction of that GEMM.
+template <bool SLABS>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      bf16_t* __restrict__ yb, float* __restrict__ yf,
                                                      float* __restrict__ rstd_out, int rows, int d, float eps,
-                                                     uint32_t thr, uint32_t seed, int group, int gstride) {
+                                                     uint32_t thr, uint32_t seed, int group, int gstride, int nslabs,
+                                                     long long slab_stride, const float* __restrict__ resid,
+                                                     float* __restrict__ xsum, uint32_t rthr, uint32_t rseed) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -24,6 +30,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         int c = lane * 4 + k * 256;
         if (c < d) {
             xv[k] = *reinterpret_cast<const float4*>(xr + c);
+            if (SLABS) {
+                for (int sl = 1; sl < nslabs; ++sl) {
+                    const float4 u = *reinterpret_cast<const float4*>(xr + (size_t)sl * slab_stride + c);
+                    xv[k].x += u.x; xv[k].y += u.y; xv[k].z += u.z; xv[k].w += u.w;
+                }
+                if (rthr) {
+                    const float rsc = drop_scale(rthr);
+                    const uint32_t idx = (uint32_t)row * (uint32_t)d + (uint32_t)c;
+                    xv[k].x = drop_keep(rseed, idx, rthr) ? xv[k].x * rsc : 0.f;
+                    xv[k].y = drop_keep(rseed, idx + 1, rthr) ? xv[k].y * rsc : 0.f;
+                    xv[k].z = drop_keep(rseed, idx + 2, rthr) ? xv[k].z * rsc : 0.f;
+                    xv[k].w = drop_keep(rseed, idx + 3, rthr) ? xv[k].w * rsc : 0.f;
+                }
+                const float4 r = *reinterpret_cast<const float4*>(resid + (size_t)row * d + c);
+                xv[k].x += r.x; xv[k].y += r.y; xv[k].z += r.z; xv[k].w += r.w;
+                *reinterpret_cast<float4*>(xsum + (size_t)row * d + c) = xv[k];
+            }
             ss += xv[k].x * xv[k].x + xv[k].y * xv[k].y + xv[k].z * xv[k].z + xv[k].w * xv[k].w;
         }
     }
@@ -208,8 +231,24 @@ extern "C" int vlt5_layernorm_fwd(const float* x, const float* w, void* y_bf16, 
     if (!x || !w || (!y_bf16 && !y_f32) || rows <= 0 || d <= 0) return VLT5_ERR_ARG;
     if ((d & 3) || d > 2048) return VLT5_ERR_ALIGN;
     uint32_t thr = drop_p > 0.f ? drop_thr16(drop_p) : 0u;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16_t*)y_bf16, y_f32,
-                       rstd, rows, d, eps, thr, drop_seed, out_group, out_group_stride);
+    hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16_t*)y_bf16, y_f32,
+                       rstd, rows, d, eps, thr, drop_seed, out_group, out_group_stride, 1, 0ll, nullptr, nullptr, 0u, 0u);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+
+extern "C" int vlt5_layernorm_fwd_slabs(const float* slabs, int nslabs, long long slab_stride, const float* resid, float* x_out,
+                                        float resid_drop_p, uint32_t resid_drop_seed, const float* w, void* y_bf16, float* y_f32,
+                                        float* rstd, int rows, int d, float eps, float drop_p, uint32_t drop_seed, int out_group,
+                                        int out_group_stride, void* stream) {
+    if (!slabs || !resid || !x_out || !w || (!y_bf16 && !y_f32) || rows <= 0 || d <= 0) return VLT5_ERR_ARG;
+    if (nslabs < 1 || (nslabs > 1 && (slab_stride <= 0 || (slab_stride & 3)))) return VLT5_ERR_ARG;
+    if ((d & 3) || d > 2048) return VLT5_ERR_ALIGN;
+    uint32_t thr = drop_p > 0.f ? drop_thr16(drop_p) : 0u;
+    uint32_t rthr = resid_drop_p > 0.f ? drop_thr16(resid_drop_p) : 0u;
+    hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, slabs, w, (bf16_t*)y_bf16, y_f32,
+                       rstd, rows, d, eps, thr, drop_seed, out_group, out_group_stride, nslabs, slab_stride, resid, x_out, rthr,
+                       resid_drop_seed);
     LAUNCH_CHECK();
     return VLT5_OK;
 }
