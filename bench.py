@@ -118,6 +118,42 @@ def cpu_baseline(seconds_budget=25.0):
                 sample=f"{len(times)} train steps of batch {Bc} (L=20,V=36,T=5, dropout on, fp32 torch-CPU oracle), best of steps 2+")
 
 
+def eager_gpu_baseline(dev, B=80, steps=5):
+    """the restatement of the reference path run as plain PyTorch-ROCm eager ops on the same GPU (what a hipified
+    reference would execute: torch ops + hipBLASLt GEMMs), fp32 like the reference and under bf16 autocast; same synthetic
+    batch, dropout on, fwd + bwd + clip + AdamW.  A reported baseline beside `cpu_baseline`, never the product path."""
+    from oracle import ref_cpu as R
+    cfg = R.Cfg(dropout=0.1)
+    params = {k: v.to(dev) for k, v in R.init_params(cfg, seed=0).items()}
+    batch = {k: v.to(dev) for k, v in R.synthetic_batch(cfg, B=B, L=20, V=36, T=5, seed=66666).items()}
+    out = {}
+    torch.set_default_device(dev)                 # the restatement builds its index tensors with default-device factories
+    try:
+        for tag, amp in (("fp32", False), ("bf16_autocast", True)):
+            model = R.OracleModel(cfg, params)
+            opt = R.HFAdamW(model.used, lr=1e-4, eps=1e-6, weight_decay=0.01)
+
+            def step():
+                model.zero_grad()
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                    o = model.train_step(batch, 0, 0.5, 0.3, training=True)
+                o["loss"].backward()
+                R.clip_grad_norm(list(model.used.values()), 5.0)
+                opt.step()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            out[tag] = round(steps * B / (time.perf_counter() - t0), 1)
+            del model, opt
+    finally:
+        torch.set_default_device("cpu")
+    return dict(unit="samples/s", kind="torch-eager restatement on the same GPU", batch=B, **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +162,7 @@ def main():
     ap.add_argument("--batch", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager-baseline", action="store_true", help="also time the torch-eager restatement on the GPU (SURVEY 8d)")
     ap.add_argument("--overlap-optimizer", action="store_true", help="run the optimizer update on a second stream (see FusedAdamW)")
     args = ap.parse_args()
 
@@ -289,6 +326,10 @@ def main():
                                               us=round(r["ms"] * 1e3, 1), tflops=round(r["gflop"] / r["ms"], 1)) for r in worst]
     if rank == 0 and world == 1 and not distributed and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+    if rank == 0 and world == 1 and not distributed and args.eager_baseline:
+        del model, opt
+        torch.cuda.empty_cache()
+        out["eager_gpu_baseline"] = eager_gpu_baseline(dev, B)
     if rank == 0:
         print(json.dumps(out))
     if distributed:

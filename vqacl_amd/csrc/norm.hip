@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      long long slab_stride, const float* __restrict__ resid,
                                                      float* __restrict__ xsum, uint32_t rthr, uint32_t rseed) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per row; 1 or 4 rows per workgroup
     if (row >= rows) return;
     const float* xr = x + (size_t)row * d;
     float ss = 0.f;
@@ -31,7 +31,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         if (c < d) {
             xv[k] = *reinterpret_cast<const float4*>(xr + c);
             if (SLABS) {
-                for (int sl = 1; sl < nslabs; ++sl) {
+                int sl = 1;
+                for (; sl + 3 < nslabs; sl += 4) {            // four slab loads in flight, summed in slab order
+                    const float* q = xr + (size_t)sl * slab_stride + c;
+                    const float4 u0 = *reinterpret_cast<const float4*>(q);
+                    const float4 u1 = *reinterpret_cast<const float4*>(q + slab_stride);
+                    const float4 u2 = *reinterpret_cast<const float4*>(q + 2 * slab_stride);
+                    const float4 u3 = *reinterpret_cast<const float4*>(q + 3 * slab_stride);
+                    xv[k].x = (((xv[k].x + u0.x) + u1.x) + u2.x) + u3.x; xv[k].y = (((xv[k].y + u0.y) + u1.y) + u2.y) + u3.y;
+                    xv[k].z = (((xv[k].z + u0.z) + u1.z) + u2.z) + u3.z; xv[k].w = (((xv[k].w + u0.w) + u1.w) + u2.w) + u3.w;
+                }
+                for (; sl < nslabs; ++sl) {
                     const float4 u = *reinterpret_cast<const float4*>(xr + (size_t)sl * slab_stride + c);
                     xv[k].x += u.x; xv[k].y += u.y; xv[k].z += u.z; xv[k].w += u.w;
                 }
@@ -102,22 +112,53 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         wreg[k] = (c < d) ? *reinterpret_cast<const float4*>(w + c) : make_float4(0, 0, 0, 0);
     }
     const float dsc2 = drop_scale(thr2);
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    // Rows are independent and a wave walks several of them: the loads of the NEXT row (x, dy, and dx when it is accumulated into)
+    // are issued before the current row's reduction, so one memory round trip per row instead of two stays exposed.
+    auto load_row = [&](int row, float4 (&xv)[LN_MAXCH], float4 (&gv)[LN_MAXCH], float4 (&qv)[LN_MAXCH]) {
         const float* xr = x + (size_t)row * d;
         const float* gr = dy + (size_t)remap_row(row, group, gstride) * d;
+        const float* dp = dx + (size_t)row * d;
+#pragma unroll
+        for (int k = 0; k < LN_MAXCH; ++k) {
+            const int c = lane * 4 + k * 256;
+            if (c < d) {
+                xv[k] = *reinterpret_cast<const float4*>(xr + c);
+                gv[k] = *reinterpret_cast<const float4*>(gr + c);
+                if (accum_dx) qv[k] = *reinterpret_cast<const float4*>(dp + c);
+            }
+        }
+    };
+    const int stride = gridDim.x * 4;
+    int row = blockIdx.x * 4 + wave;
+    float4 xv[LN_MAXCH], gv[LN_MAXCH], qv[LN_MAXCH], xn[LN_MAXCH], gn[LN_MAXCH], qn[LN_MAXCH];
+    if (row < rows) load_row(row, xv, gv, qv);
+    for (; row < rows; row += stride) {
+        const int nxt = row + stride;
+        const bool ahead = nslabs == 1 && nxt < rows;           // (with slabs a wave has one row: few-row launches)
+        if (ahead) load_row(nxt, xn, gn, qn);
         const float rs = rstd[row];
-        // single pass over HBM: this lane's slice of the row (x and the masked upstream gradient) stays in registers
-        float4 xv[LN_MAXCH], gv[LN_MAXCH];
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < LN_MAXCH; ++k) {
             int c = lane * 4 + k * 256;
             if (c < d) {
-                xv[k] = *reinterpret_cast<const float4*>(xr + c);
-                float4 t = *reinterpret_cast<const float4*>(gr + c);
-                for (int sl = 1; sl < nslabs; ++sl) {          // dy handed over as split-K slabs of the producing GEMM: fixed-order sum
-                    const float4 u = *reinterpret_cast<const float4*>(gr + (size_t)sl * slab_stride + c);
-                    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                float4 t = gv[k];
+                if (nslabs > 1) {          // dy handed over as split-K slabs of the producing GEMM: fixed-order sum, 4 loads in flight
+                    const float* gr = dy + (size_t)remap_row(row, group, gstride) * d + c;
+                    int sl = 1;
+                    for (; sl + 3 < nslabs; sl += 4) {
+                        const float* q = gr + (size_t)sl * slab_stride;
+                        const float4 u0 = *reinterpret_cast<const float4*>(q);
+                        const float4 u1 = *reinterpret_cast<const float4*>(q + slab_stride);
+                        const float4 u2 = *reinterpret_cast<const float4*>(q + 2 * slab_stride);
+                        const float4 u3 = *reinterpret_cast<const float4*>(q + 3 * slab_stride);
+                        t.x = (((t.x + u0.x) + u1.x) + u2.x) + u3.x; t.y = (((t.y + u0.y) + u1.y) + u2.y) + u3.y;
+                        t.z = (((t.z + u0.z) + u1.z) + u2.z) + u3.z; t.w = (((t.w + u0.w) + u1.w) + u2.w) + u3.w;
+                    }
+                    for (; sl < nslabs; ++sl) {
+                        const float4 u = *reinterpret_cast<const float4*>(gr + (size_t)sl * slab_stride);
+                        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                    }
                 }
                 if (thr) {
                     uint32_t idx = (uint32_t)row * (uint32_t)d + (uint32_t)c;
@@ -142,10 +183,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 o.x = rs * gv[k].x * wreg[k].x - xv[k].x * coef; o.y = rs * gv[k].y * wreg[k].y - xv[k].y * coef;
                 o.z = rs * gv[k].z * wreg[k].z - xv[k].z * coef; o.w = rs * gv[k].w * wreg[k].w - xv[k].w * coef;
                 float* dp = dx + (size_t)row * d + c;
-                if (accum_dx) {
-                    float4 q = *reinterpret_cast<const float4*>(dp);
-                    o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
-                }
+                if (accum_dx) { o.x += qv[k].x; o.y += qv[k].y; o.z += qv[k].z; o.w += qv[k].w; }
                 *reinterpret_cast<float4*>(dp) = o;
                 if (dxb) {                      // bf16(dropout(dx)) = the A operand of the next sublayer's backward GEMMs
                     float q[4] = {o.x, o.y, o.z, o.w};
@@ -160,6 +198,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     *reinterpret_cast<uint2*>(dxb + (size_t)row * d + c) = pk;
                 }
             }
+        }
+        if (ahead) {
+#pragma unroll
+            for (int k = 0; k < LN_MAXCH; ++k) { xv[k] = xn[k]; gv[k] = gn[k]; qv[k] = qn[k]; }
+        } else if (nxt < rows) {
+            load_row(nxt, xv, gv, qv);
         }
     }
 #pragma unroll
@@ -231,7 +275,8 @@ extern "C" int vlt5_layernorm_fwd(const float* x, const float* w, void* y_bf16, 
     if (!x || !w || (!y_bf16 && !y_f32) || rows <= 0 || d <= 0) return VLT5_ERR_ARG;
     if ((d & 3) || d > 2048) return VLT5_ERR_ALIGN;
     uint32_t thr = drop_p > 0.f ? drop_thr16(drop_p) : 0u;
-    hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16_t*)y_bf16, y_f32,
+    const int rpw = rows < 2048 ? 1 : 4;
+    hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3((rows + rpw - 1) / rpw), dim3(64 * rpw), 0, (hipStream_t)stream, x, w, (bf16_t*)y_bf16, y_f32,
                        rstd, rows, d, eps, thr, drop_seed, out_group, out_group_stride, 1, 0ll, nullptr, nullptr, 0u, 0u);
     LAUNCH_CHECK();
     return VLT5_OK;
@@ -246,7 +291,8 @@ extern "C" int vlt5_layernorm_fwd_slabs(const float* slabs, int nslabs, long lon
     if ((d & 3) || d > 2048) return VLT5_ERR_ALIGN;
     uint32_t thr = drop_p > 0.f ? drop_thr16(drop_p) : 0u;
     uint32_t rthr = resid_drop_p > 0.f ? drop_thr16(resid_drop_p) : 0u;
-    hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, slabs, w, (bf16_t*)y_bf16, y_f32,
+    const int rpw = rows < 2048 ? 1 : 4;          // few rows (decoder): one row per workgroup, so every CU gets work
+    hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3((rows + rpw - 1) / rpw), dim3(64 * rpw), 0, (hipStream_t)stream, slabs, w, (bf16_t*)y_bf16, y_f32,
                        rstd, rows, d, eps, thr, drop_seed, out_group, out_group_stride, nslabs, slab_stride, resid, x_out, rthr,
                        resid_drop_seed);
     LAUNCH_CHECK();
