@@ -258,6 +258,10 @@ typedef struct {
     const float* box_store;        /* f32  [n_slots][V][4], normalised boxes */
     const long long* feat_slots;   /* [B] slot of each sample */
     long long n_slots;
+    /* optional second stream for the backward phases: the batched weight-gradient GEMMs are enqueued there (after an event of the
+     * main stream) and run beside the input-gradient chain; vlt5_encoder_bwd makes the main stream wait for it before it
+     * returns, so the caller sees a single-stream contract.  side_events: >= 4 hipEvent_t owned by the caller.  NULL: one stream. */
+    void* side_stream; void** side_events; int n_side_events;
 } vlt5_step;
 
 /* ---- batch feed from a resident feature store (replaces the per-item HDF5 read + collate + H2D copy of

@@ -49,7 +49,8 @@ class Step(C.Structure):
                 ("vis_feats", vp), ("boxes", vp), ("input_ids", vp), ("labels", vp), ("scores", vp),
                 ("enc_lut", vp), ("dec_lut", vp), ("gout", vp), ("d_loss_tok", vp), ("events", C.POINTER(vp)), ("n_events", c_i),
                 ("wait_events", C.POINTER(vp)), ("n_wait_events", c_i),
-                ("feat_store", vp), ("box_store", vp), ("feat_slots", vp), ("n_slots", c_ll)]
+                ("feat_store", vp), ("box_store", vp), ("feat_slots", vp), ("n_slots", c_ll),
+                ("side_stream", vp), ("side_events", C.POINTER(vp)), ("n_side_events", c_i)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/vlt5_hip.h

@@ -124,7 +124,7 @@ struct Plan {
     size_t yn_a[MAXL], dqkv_s[MAXL], lse_s[MAXL], ctx_s[MAXL], yn_c[MAXL], qc[MAXL], lse_c[MAXL], ctx_c[MAXL], yn_f[MAXL], hd[MAXL];
     size_t dec_out, logits, lse_ce, loss_tok, row_w, loss;
     // backward scratch
-    size_t dx, tmp, dctx, dkv_all, d_enc_ext, dS_enc, dS_dec, dlogits, slab, ln_partial, vis_partial, rel_scratch, vis_dG, small;
+    size_t dx, tmp, dctx, dkv_all, d_enc_ext, dS_enc, dS_dec, dlogits, slab, ln_partial, vis_partial, rel_scratch, vis_dG, small, slab2;
     // per-layer gradient operands kept until the end of the phase: the weight-gradient GEMMs of all layers run as ONE
     // batched launch per weight kind (grid.z = layer)
     size_t e_dyd_f[MAXL], e_dh[MAXL], e_dyd_a[MAXL], e_dqkv[MAXL];
@@ -189,6 +189,7 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     if (3 * inner * d > wmax) wmax = 3 * inner * d;
     p.slab_bytes = 8 * wmax * 4;
     p.slab = take(p.slab_bytes);
+    p.slab2 = take(p.slab_bytes);                            // split-K scratch of the weight-gradient side stream
     p.ln_partial = take((size_t)64 * 320 * d * 4);          // 64 norm slots x <= 320 workgroup partials
     p.vis_partial = take(((size_t)256 * 10 * d + 2 * (size_t)B * V) * 4);   // <= 256 row splits (vlt5_vis_embed_bwd_blocks)
     size_t rs = 64 * H * (size_t)(L > T ? L : T) * (L > T ? L : T) * 4;
@@ -213,7 +214,9 @@ struct Ctx {
     mutable int ln_jobs = 0;
     mutable long long ln_out[64];
     mutable int ln_nblk[64];
+    hipStream_t side = nullptr;        // optional second stream of the backward phases (vlt5_step.side_stream)
     Ctx(const vlt5_config& c_, const vlt5_step& s_, void* stream) : c(c_), s(s_), st((hipStream_t)stream) {
+        if (s.side_stream && s.side_events && s.n_side_events >= 4) side = (hipStream_t)s.side_stream;
         build_layout(c, lay, false);
         make_plan(c, s.B, s.L, s.V, s.T, p);
         ws = (char*)s.workspace;
@@ -222,6 +225,28 @@ struct Ctx {
         d = c.d_model; inner = c.num_heads * c.d_kv; ff = c.d_ff; H = c.num_heads;
     }
     template <class T> T* w(size_t off) const { return reinterpret_cast<T*>(ws + off); }
+    // The weight-gradient GEMMs depend on the input-gradient chain but nothing in the chain depends on them, and the chain is full
+    // of latency-/HBM-bound kernels (norms, attention, few-tile GEMMs) that leave the matrix cores idle: with a side stream the
+    // batched weight gradients run beside the rest of the chain.  fork(e): the side stream continues from this point of the main
+    // stream; join(e): the main stream waits for everything enqueued on the side stream; on_side(): the same context, launching
+    // on the side stream with its own split-K scratch.  Without a side stream all three are no-ops / the identity.
+    int fork(int e) const {
+        if (!side) return VLT5_OK;
+        HIP_RET(hipEventRecord((hipEvent_t)s.side_events[e], st));
+        HIP_RET(hipStreamWaitEvent(side, (hipEvent_t)s.side_events[e], 0));
+        return VLT5_OK;
+    }
+    int join(int e) const {
+        if (!side) return VLT5_OK;
+        HIP_RET(hipEventRecord((hipEvent_t)s.side_events[e], side));
+        HIP_RET(hipStreamWaitEvent(st, (hipEvent_t)s.side_events[e], 0));
+        return VLT5_OK;
+    }
+    Ctx on_side() const {
+        Ctx k2 = *this;
+        if (side) { k2.st = side; k2.p.slab = p.slab2; }
+        return k2;
+    }
     const float* boxes() const { return s.feat_store ? w<float>(p.boxes_g) : s.boxes; }    // gathered from the store, or the caller's
     uint32_t seed(uint32_t site) const { return site_seed(s.seed, site); }
     int check(bool bwd) const {
@@ -593,20 +618,25 @@ int decoder_bwd(const Ctx& k) {
     }
     RC(vlt5_relbias_bwd(k.w<float>(p.dS_dec), s.dec_lut, k.Gr + L.dec_rel, k.w<float>(p.rel_scratch), Ld * B, k.H, T, T,
                         c.rel_buckets, 0, k.st));
-    // weight gradients of all decoder layers, one batched GEMM per weight kind
-    const int l1 = Ld > 1 ? 1 : 0;
-    RC(k.wgrad_batched(p.d_dyd_f[0], p.d_dyd_f[l1], d, p.hd[0], p.hd[l1], ff, L.dec[0].wo, L.dec[l1].wo, Ld, Md, d, ff));
-    RC(k.wgrad_batched(p.d_dh[0], p.d_dh[l1], ff, p.yn_f[0], p.yn_f[l1], d, L.dec[0].wi, L.dec[l1].wi, Ld, Md, ff, d));
-    RC(k.wgrad_batched(p.d_dyd_c[0], p.d_dyd_c[l1], d, p.ctx_c[0], p.ctx_c[l1], inner, L.dec[0].co, L.dec[l1].co, Ld, Md, d, inner));
-    RC(k.wgrad_batched(p.d_dq_c[0], p.d_dq_c[l1], inner, p.yn_c[0], p.yn_c[l1], d, L.dec[0].cq, L.dec[l1].cq, Ld, Md, inner, d));
-    RC(k.wgrad_batched(p.d_dyd_s[0], p.d_dyd_s[l1], d, p.ctx_s[0], p.ctx_s[l1], inner, L.dec[0].so, L.dec[l1].so, Ld, Md, d, inner));
-    RC(k.wgrad_batched(p.d_dqkv[0], p.d_dqkv[l1], 3 * inner, p.yn_a[0], p.yn_a[l1], d, L.dec[0].sqkv, L.dec[l1].sqkv, Ld, Md, 3 * inner, d));
+    // weight gradients of all decoder layers, one batched GEMM per weight kind, and of the stacked cross-attention K/V projection
+    // -- on the side stream (if there is one) they run beside the rest of this phase and the first half of the encoder's chain
+    RC(k.fork(0));
+    {
+        const Ctx ks = k.on_side();
+        const int l1 = Ld > 1 ? 1 : 0;
+        RC(ks.wgrad_batched(p.d_dyd_f[0], p.d_dyd_f[l1], d, p.hd[0], p.hd[l1], ff, L.dec[0].wo, L.dec[l1].wo, Ld, Md, d, ff));
+        RC(ks.wgrad_batched(p.d_dh[0], p.d_dh[l1], ff, p.yn_f[0], p.yn_f[l1], d, L.dec[0].wi, L.dec[l1].wi, Ld, Md, ff, d));
+        RC(ks.wgrad_batched(p.d_dyd_c[0], p.d_dyd_c[l1], d, p.ctx_c[0], p.ctx_c[l1], inner, L.dec[0].co, L.dec[l1].co, Ld, Md, d, inner));
+        RC(ks.wgrad_batched(p.d_dq_c[0], p.d_dq_c[l1], inner, p.yn_c[0], p.yn_c[l1], d, L.dec[0].cq, L.dec[l1].cq, Ld, Md, inner, d));
+        RC(ks.wgrad_batched(p.d_dyd_s[0], p.d_dyd_s[l1], d, p.ctx_s[0], p.ctx_s[l1], inner, L.dec[0].so, L.dec[l1].so, Ld, Md, d, inner));
+        RC(ks.wgrad_batched(p.d_dqkv[0], p.d_dqkv[l1], 3 * inner, p.yn_a[0], p.yn_a[l1], d, L.dec[0].sqkv, L.dec[l1].sqkv, Ld, Md, 3 * inner, d));
+        // cross-attention K/V projections of all layers at once
+        RC(ks.lin_wgrad(k.w<bf16_t>(p.dkv_all), kvw, k.w<bf16_t>(p.enc_ext), d, k.Gr + L.cross_kv, Mx, kvw, d));
+        for (int b = 0; b <= Ld; ++b) RC(ks.record(b));     // decoder-side gradient buckets are complete (rel-bias: before the fork)
+    }
     RC(vlt5_embed_bwd(ids, dx, (long long)T * d, d, k.Gr + L.shared, B, T, d, c.vocab, k.pdrop, k.seed(SITE_DEC_EMBED), T, 0, k.st));
-    // cross-attention K/V projections of all layers at once
-    RC(k.lin_wgrad(k.w<bf16_t>(p.dkv_all), kvw, k.w<bf16_t>(p.enc_ext), d, k.Gr + L.cross_kv, Mx, kvw, d));
     RC(k.lin_dgrad(k.w<bf16_t>(p.dkv_all), k.Pb + L.cross_kv, k.w<void>(p.d_enc_ext), Mx, kvw, d, 1));
     RC(k.ln_flush());
-    for (int b = 0; b <= Ld; ++b) RC(k.record(b));          // decoder-side gradient buckets are complete
     return VLT5_OK;
 }
 
@@ -653,16 +683,22 @@ int encoder_bwd(const Ctx& k) {
         if (Le > 1 && l == Le / 2) {
             // upper half of the stack: its weight gradients are complete early, so a data-parallel all-reduce of these
             // buckets overlaps with the backward of the lower half
-            RC(enc_wgrads(k, Le / 2, Le));
-            for (int b = Ld + 1; b <= Ld + 1 + (Le - 1 - l); ++b) RC(k.record(b));
+            RC(k.fork(1));
+            const Ctx ks = k.on_side();                   // beside the lower half's chain when there is a side stream
+            RC(enc_wgrads(ks, Le / 2, Le));
+            for (int b = Ld + 1; b <= Ld + 1 + (Le - 1 - l); ++b) RC(ks.record(b));
         }
     }
     RC(vlt5_relbias_bwd(k.w<float>(p.dS_enc), s.enc_lut, k.Gr + L.enc_rel, k.w<float>(p.rel_scratch), Le * B, k.H, s.L, s.L,
                         c.rel_buckets, 0, k.st));
     // (a third flush group of Le/4 layers was measured: batches of 3 layers fill the chip too poorly, +4 % step time)
     const int low_end = Le > 1 ? Le / 2 : Le;
-    RC(enc_wgrads(k, 0, low_end));                        // lower half of the stack (the upper half was flushed mid-way)
-    for (int b = Ld + 1 + (Le - low_end); b <= Ld + Le; ++b) RC(k.record(b));
+    RC(k.fork(2));
+    {
+        const Ctx ks = k.on_side();                       // beside the embedding / visual-embedding backward below
+        RC(enc_wgrads(ks, 0, low_end));                   // lower half of the stack (the upper half was flushed mid-way)
+        for (int b = Ld + 1 + (Le - low_end); b <= Ld + Le; ++b) RC(ks.record(b));
+    }
     // inputs: text rows -> shared (scatter-add), visual rows -> visual embedding parameters
     RC(vlt5_embed_bwd(s.input_ids, dx, (long long)S * d, d, k.Gr + L.shared, B, s.L, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, 0, k.st));
     float* vpart = k.w<float>(p.vis_partial);
@@ -675,6 +711,7 @@ int encoder_bwd(const Ctx& k) {
                              k.Gr + L.vis_img, k.Gr + L.vis_bf, d, c.n_images, k.st));
     RC(k.lin_wgrad(k.w<bf16_t>(p.vis_dG), d, k.w<bf16_t>(p.feats_bf16), c.feat_dim, k.Gr + L.vis_wf, B * s.V, d, c.feat_dim));
     RC(k.ln_flush());
+    RC(k.join(3));                                        // every gradient is complete on the caller's stream from here on
     RC(k.record(Ld + 1 + Le));                            // embeddings + norms + visual embedding
     return VLT5_OK;
 }

@@ -13,6 +13,7 @@ Memory layout (sized for 288 GB HBM, one process per GPU):
   * activations live in one workspace arena planned by the C side (`vlt5_workspace_bytes`).
 """
 import ctypes as C
+import os
 import math
 from collections import OrderedDict
 
@@ -147,6 +148,9 @@ class VLT5(nn.Module):
         self._step_count = 0
         self.base_seed = 0x5EED
         self.dp = None                       # set by parallel.DataParallelVLT5
+        self.side_stream_enabled = os.environ.get("VQACL_SIDE_STREAM", "0") == "1"    # weight gradients on a second stream (measured: no gain)
+        self._side = None
+        self._side_events = None
         self.external_bf16_sync = False      # True once a fused optimizer keeps the bf16 shadow fresh itself
         self._opt_events = None              # per-bucket events of an overlapped optimizer update (FusedAdamW(overlap=True))
         self._bf16_version = -1
@@ -508,6 +512,16 @@ class VLT5(nn.Module):
             arr = (L.vp * len(events))(*[L.vp(e.cuda_event) for e in events])
             cs.events, cs.n_events = arr, len(events)
             keep = keep + (arr,)
+        if self.side_stream_enabled:
+            # the batched weight-gradient GEMMs run on a second stream beside the input-gradient chain; vlt5_encoder_bwd joins it
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self._device)
+                self._side_events = [torch.cuda.Event() for _ in range(4)]
+                for e in self._side_events:                 # force creation of the underlying hipEvent_t
+                    e.record()
+            sarr = (L.vp * 4)(*[L.vp(e.cuda_event) for e in self._side_events])
+            cs.side_stream, cs.side_events, cs.n_side_events = L.vp(self._side.cuda_stream), sarr, 4
+            keep = keep + (sarr,)
         stream = stream_ptr()
         check(lib().vlt5_decoder_bwd(C.byref(c), C.byref(cs), stream), "vlt5_decoder_bwd")
         if events is not None:
