@@ -275,6 +275,10 @@ int vlt5_feat_store_put(const float* feats, const float* boxes, const long long*
 int vlt5_feat_gather(const void* store_bf16, const float* box_store, const long long* slots, long long n_slots,
                      void* out_feats_bf16, float* out_boxes, int B, int V, int feat_dim, void* stream);
 
+/* a lowest-priority stream for vlt5_step.side_stream (hipStreamCreateWithPriority); the caller destroys it */
+int vlt5_side_stream_create(void** stream);
+int vlt5_side_stream_destroy(void* stream);
+
 /* parameter layout */
 int vlt5_layout_count(const vlt5_config* c);
 /* name_cap >= 128.  bucket: index of the gradient bucket (0 = first complete in backward); decay: 1 if the

@@ -718,6 +718,23 @@ int encoder_bwd(const Ctx& k) {
 
 }  // namespace
 
+// A stream of the LOWEST priority for vlt5_step.side_stream: the weight-gradient GEMMs then only take the workgroup slots the
+// input-gradient chain on the caller's (normal-priority) stream leaves free, instead of starving it.
+extern "C" int vlt5_side_stream_create(void** stream) {
+    if (!stream) return VLT5_ERR_ARG;
+    int least = 0, greatest = 0;
+    HIP_RET(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t st;
+    HIP_RET(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least));
+    *stream = (void*)st;
+    return VLT5_OK;
+}
+extern "C" int vlt5_side_stream_destroy(void* stream) {
+    if (!stream) return VLT5_ERR_ARG;
+    HIP_RET(hipStreamDestroy((hipStream_t)stream));
+    return VLT5_OK;
+}
+
 extern "C" int vlt5_layout_count(const vlt5_config* c) {
     if (!c) return -1;
     Layout L;
