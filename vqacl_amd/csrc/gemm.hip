@@ -20,6 +20,7 @@
 // Fused epilogue (all optional): bias[n], ReLU, gate by the sign of a saved bf16 activation (ReLU and
 // dropout backward in one), counter-based dropout, fp32 residual add, accumulate into C, bf16 or
 // fp32 output.  Split-K (grid.z) writes fp32 slabs that vlt5_reduce_slabs sums in a fixed order.
+#include <cstdlib>
 #include "common.h"
 #include "vlt5_hip.h"
 #include <type_traits>
@@ -64,7 +65,7 @@ __device__ __forceinline__ uint32_t lds_off(int row, int kchunk) {            //
 // ---- row-major operand: tile [R rows][64 k], 16-byte chunks along k ------------------------------
 template <int R, int NT>
 __device__ __forceinline__ void gload_rm(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, int K,
-                                         uint4 (&v)[4], int tid) {
+                                         uint4 (&v)[8], int tid) {
 #pragma unroll
     for (int i = 0; i < R * 8 / NT; ++i) {
         int c = tid + i * NT;
@@ -76,7 +77,7 @@ __device__ __forceinline__ void gload_rm(const bf16_t* __restrict__ base, int ld
     }
 }
 template <int R, int NT>
-__device__ __forceinline__ void lstore_rm(char* tile, const uint4 (&v)[4], int tid) {
+__device__ __forceinline__ void lstore_rm(char* tile, const uint4 (&v)[8], int tid) {
 #pragma unroll
     for (int i = 0; i < R * 8 / NT; ++i) {
         int c = tid + i * NT;
@@ -98,7 +99,7 @@ __device__ __forceinline__ int km_swz(int k) {
 }
 template <int R, int NT>
 __device__ __forceinline__ void gload_km(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, int K,
-                                         uint4 (&v)[4], int tid) {
+                                         uint4 (&v)[8], int tid) {
     constexpr int CPR = R / 8;                                  // 16-byte chunks per k-row
 #pragma unroll
     for (int i = 0; i < R * 8 / NT; ++i) {
@@ -111,7 +112,7 @@ __device__ __forceinline__ void gload_km(const bf16_t* __restrict__ base, int ld
     }
 }
 template <int R, int NT>
-__device__ __forceinline__ void lstore_km(char* tile, const uint4 (&v)[4], int tid) {
+__device__ __forceinline__ void lstore_km(char* tile, const uint4 (&v)[8], int tid) {
     constexpr int CPR = R / 8;
 #pragma unroll
     for (int i = 0; i < R * 8 / NT; ++i) {
@@ -196,11 +197,15 @@ __host__ __device__ constexpr int pieces_in_row(int r) {
     for (int p = 0; p < LPT; ++p) n += (piece_row<FM, LPT, EARLY>(p) == r) ? 1 : 0;
     return n;
 }
+// ks = 1 B fragments fetched after the ks = 0 MFMAs of fragment row i: fragment i itself while FM >= FN (the 8-wave layout),
+// an even split of the FN fragments over the FM rows otherwise (4-wave layouts with wave tiles wider than tall)
+template <int FM, int FN>
+__host__ __device__ constexpr int bfrag_lo(int i) { return FM >= FN ? (i < FN ? i : FN) : i * FN / FM; }
 // scheduling pattern of the interleaved k-step (see kstep_big): instruction groups in issue order
 template <int FM, int FN, int LPT, int RA, int RB, bool EARLY, int I>
 __device__ __forceinline__ void pin_ks0() {                 // ks = 0 MFMAs of fragment row I, then the ks = 1 fragments it frees room for
     __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, RA + (I < FN ? RB : 0), 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, RA + (bfrag_lo<FM, FN>(I + 1) - bfrag_lo<FM, FN>(I)) * RB, 0);
     constexpr int NP = pieces_in_row<FM, LPT, EARLY>(I);
     if constexpr (NP > 0) __builtin_amdgcn_sched_group_barrier(0x010, NP, 0);
     if constexpr (I + 1 < FM) pin_ks0<FM, FN, LPT, RA, RB, EARLY, I + 1>();
@@ -215,7 +220,7 @@ __device__ __forceinline__ void pin_ks1() {
 
 // WM x WN waves share a BM x BN tile: 2x2 (256 threads) for tiles up to 128x128, 2x4 (512 threads) for 256x256.
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm_body(GemmArgs p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;                 // wave tile
     constexpr int FM = TM / 16, FN = TN / 16;                 // 16x16 fragments per wave
@@ -266,28 +271,28 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[4], rb[4];
-    auto gload = [&](int kt) {
+    uint4 ra[8], rb[8];          // tail k-tile through registers: R*8/NT <= 8 chunks per thread
+    auto gload = [&](int kt) __attribute__((always_inline)) {
         if (AKM) gload_km<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, p.K, ra, tid);
         else     gload_rm<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, p.K, ra, tid);
         if (BKM) gload_km<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, p.K, rb, tid);
         else     gload_rm<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, p.K, rb, tid);
     };
-    auto lstore = [&](int s) {
+    auto lstore = [&](int s) __attribute__((always_inline)) {
         char* at = smem + s * STAGE_BYTES;
         char* bt = at + A_BYTES;
         if (AKM) lstore_km<BM, NT>(at, ra, tid); else lstore_rm<BM, NT>(at, ra, tid);
         if (BKM) lstore_km<BN, NT>(bt, rb, tid); else lstore_rm<BN, NT>(bt, rb, tid);
     };
 
-    auto glds = [&](int kt, int s) {                        // asynchronous: completion is awaited with vmcnt(0)
+    auto glds = [&](int kt, int s) __attribute__((always_inline)) {                        // asynchronous: completion is awaited with vmcnt(0)
         char* at = smem + s * STAGE_BYTES;
         char* bt = at + A_BYTES;
         if (AKM) glds_km<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, at, tid); else glds_rm<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, at, tid);
         if (BKM) glds_km<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid); else glds_rm<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid);
     };
     const int lrow = lane & 15, lg = lane >> 4;
-    auto glds_piece = [&](int kt, int s, int pc) {
+    auto glds_piece = [&](int kt, int s, int pc) __attribute__((always_inline)) {
         char* at = smem + s * STAGE_BYTES;
         char* bt = at + A_BYTES;
         constexpr int PA = BM * 8 / NT;
@@ -298,17 +303,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
             else     glds_rm_piece<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid, pc - PA);
         }
     };
-    auto ldA = [&](const char* at, int i, int ks) -> bf16x8_t {
+    auto ldA = [&](const char* at, int i, int ks) __attribute__((always_inline)) -> bf16x8_t {
         const int r0 = wm * TM + i * 16;
         if (AKM) return frag_km<BM>(at, r0, ks, lane);
         return *reinterpret_cast<const bf16x8_t*>(at + lds_off(r0 + lrow, ks * 4 + lg));
     };
-    auto ldB = [&](const char* bt, int j, int ks) -> bf16x8_t {
+    auto ldB = [&](const char* bt, int j, int ks) __attribute__((always_inline)) -> bf16x8_t {
         const int r0 = wn * TN + j * 16;
         if (BKM) return frag_km<BN>(bt, r0, ks, lane);
         return *reinterpret_cast<const bf16x8_t*>(bt + lds_off(r0 + lrow, ks * 4 + lg));
     };
-    auto kstep_km = [&](int stage, int kt_pf, int s_pf) {
+    auto kstep_km = [&](int stage, int kt_pf, int s_pf) __attribute__((always_inline)) {
         const char* at = smem + stage * STAGE_BYTES;
         const char* bt = at + A_BYTES;
         bf16x8_t fa[2][FM], fb[2][FN];
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     // vmcnt(0) (-6 % per launch); with a k-major operand (two transpose reads per fragment) spreading them over both halves
     // measured better.
     constexpr bool EARLY = !AKM && !BKM;
-    auto kstep_big = [&](int stage, int kt_pf, int s_pf) {
+    auto kstep_big = [&](int stage, int kt_pf, int s_pf) __attribute__((always_inline)) {
         const char* at = smem + stage * STAGE_BYTES;
         const char* bt = at + A_BYTES;
         bf16x8_t fa0[FM], fb0[FN], fa1[FM], fb1[FN];
@@ -351,7 +356,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
             fa1[i] = ldA(at, i, 1);
-            if (i < FN) fb1[i] = ldB(bt, i, 1);
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                if (j >= bfrag_lo<FM, FN>(i) && j < bfrag_lo<FM, FN>(i + 1)) fb1[j] = ldB(bt, j, 1);
 #pragma unroll
             for (int pc = 0; pc < LPT; ++pc)
                 if (piece_row<FM, LPT, EARLY>(pc) == i) glds_piece(kt_pf, s_pf, pc);
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         pin_ks0<FM, FN, LPT, RA, RB, EARLY, 0>();
         pin_ks1<FM, FN, LPT, EARLY, 0>();
     };
-    auto compute = [&](int stage) {
+    auto compute = [&](int stage) __attribute__((always_inline)) {
         const char* at = smem + stage * STAGE_BYTES;
         const char* bt = at + A_BYTES;
 #pragma unroll
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     // one 16-byte store per lane, 64 contiguous bytes per matrix row per instruction, half as many store instructions as
     // 8-byte stores (the epilogue is store-ISSUE bound: ~50 cycles per wave-store whatever its width).  Every lane takes part
     // in the swap; only the store is predicated.
-    auto store_pair_bf16 = [&](int m, int j, const float (&v)[4], const float (&w)[4]) {
+    auto store_pair_bf16 = [&](int m, int j, const float (&v)[4], const float (&w)[4]) __attribute__((always_inline)) {
         const uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
         const uint32_t q0 = pack_bf16x2(w[0], w[1]), q1 = pack_bf16x2(w[2], w[3]);
         const auto s0 = __builtin_amdgcn_permlane16_swap(p0, q0, false, false);
@@ -528,7 +535,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     // Fused epilogues.  The option set is block-uniform; the combinations the engine issues are compiled as straight-line
     // specialisations (generic lambda + integral constants), everything else takes the fully generic instance.
     const bool drop = p.drop_thr != 0, gate = p.gate != nullptr, bias = p.bias != nullptr, relu = p.relu != 0, f32 = p.out_f32 != 0;
-    auto run = [&](auto c_bias, auto c_relu, auto c_gate, auto c_drop, auto c_aux, auto c_f32, auto c_generic) {
+    auto run = [&](auto c_bias, auto c_relu, auto c_gate, auto c_drop, auto c_aux, auto c_f32, auto c_generic) __attribute__((always_inline)) {
         constexpr bool kBias = decltype(c_bias)::value, kRelu = decltype(c_relu)::value, kGate = decltype(c_gate)::value;
         constexpr bool kDrop = decltype(c_drop)::value, kAux = decltype(c_aux)::value, kF32 = decltype(c_f32)::value;
         constexpr bool kGen = decltype(c_generic)::value;      // generic instance: a compiled-in option is still tested at run time
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
             // one explicit vmcnt(0) that EVERY path passes: the loads above sit in divergent branches, and a conservative
             // re-wait before each fragment would land between the stores (vmcnt counts stores too on CDNA)
             __builtin_amdgcn_s_waitcnt(0x0F70);
-            auto finish = [&](int ii, int j, int m, float (&v)[4]) {     // everything between the accumulator and the store
+            auto finish = [&](int ii, int j, int m, float (&v)[4]) __attribute__((always_inline)) {     // everything between the accumulator and the store
                 const int i = ib + ii;
                 const int n = n0 + wn * TN + j * 16 + lg * 4;
 #pragma unroll
@@ -651,6 +658,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     TL_FLUSH();
 }
 
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
+    gemm_body<BM, BN, WM, WN, AKM, BKM, NS>(p);
+}
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n,
                                     int nslabs, long long stride, int accum) {
     long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
