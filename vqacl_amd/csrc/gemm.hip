@@ -741,11 +741,15 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         // layer-batched FFN weight gradients: 455 us against 385-410 us with 128 x 128)
         // (also for a small output with a very long reduction cut into slices by vlt5_gemm_auto_split: the input gradients
         // of lm_head and of the stacked cross-attention K/V projection)
-        if (!d->a_kmajor && (tiles(256, 256) >= 200 || (d->K >= 8192 && d->split_k > 1 && tiles(256, 256) >= 128))) { bm = 256; bn = 256; }
+        if (!d->a_kmajor && (tiles(256, 256) >= 160 || (d->K >= 8192 && d->split_k > 1 && tiles(256, 256) >= 128))) { bm = 256; bn = 256; }
         // (with k-major operands the 64-wide tiles run the deeper fragment pipeline, KM_STEP, and win below this threshold;
         // above it -- the layer-batched weight gradients -- 128 x 128 is still 25 % faster)
         else if (tiles(128, 128) >= 768) { bm = 128; bn = 128; }       // >= 3 workgroups per CU of the big tile
-        else if (tiles(64, 128) >= 256) { bm = 64; bn = 128; }         // 3-stage ring, 2 workgroups per CU
+        else if (tiles(64, 128) >= 256) {                              // 3-stage ring, 2 workgroups per CU
+            // input-gradient layout (row-major dY, k-major W): the tall tile reads the transpose-read operand half as often per
+            // flop (sweep r01_f: 26.0 vs 27.5 us on 4480x768x2304, 171.6 vs 182.3 on 4640x768x18432)
+            if (!d->a_kmajor && d->b_kmajor) { bm = 128; bn = 64; } else { bm = 64; bn = 128; }
+        }
         else { bm = 64; bn = 64; }                                     // small-M (decoder) problems: most workgroups
     }
     if (!(((bm == 128 || bm == 64) && (bn == 128 || bn == 64)) || (bm == 256 && bn == 256))) return VLT5_ERR_ARG;
