@@ -201,6 +201,12 @@ int vlt5_sqnorm_blocks(long long n);
 int vlt5_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, const float* total_sq, float max_norm,
                     int hf_mode, void* stream);
+/* the same two with the gradient read as bf16 * g_scale -- the reduced bucket of a bf16 data-parallel all-reduce as it lies in
+ * the staging buffer (g_scale = 1/world): what vlt5_cast_f32 would have written to the f32 gradient buffer, without the pass */
+int vlt5_sqnorm_g16(const void* g_bf16, float g_scale, long long n, float* partial, float* total_sq, int accum_total, void* stream);
+int vlt5_adamw_step_g16(float* p, const void* g_bf16, float g_scale, float* m, float* v, void* p_bf16, long long n, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int step, const float* total_sq, float max_norm,
+                        int hf_mode, void* stream);
 int vlt5_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);
 /* dst = scale * float(src_bf16): the way back from a bf16 gradient all-reduce (vqacl_amd/parallel.py) */
 int vlt5_cast_f32(const void* src_bf16, float* dst, long long n, float scale, void* stream);

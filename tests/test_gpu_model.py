@@ -441,6 +441,31 @@ def test_data_parallel_overlap_path_on_one_gpu_and_rank_equivalence(dev):
         g2 = model2.flat_grads()
         assert cos(g2, g_plain) > 0.99999
         assert torch.allclose(g2, g_plain, rtol=1.0 / 128, atol=1e-6)
+        # with the fused optimizer the cast back is deferred: the norm / AdamW kernels read the reduced bf16 buckets themselves.
+        # Same weights, bit for bit, as casting back first; .grad keeps the local f32 gradients until flat_grads() is asked.
+        from vqacl_amd import FusedAdamW, reference_param_groups
+        outs = []
+        for defer in (True, False):
+            m3 = make_model(ocfg, params, dev)
+            m3.train()
+            dp3 = DataParallelVLT5(m3, bucket_mb=0.05)
+            opt3 = FusedAdamW(reference_param_groups(m3, 0.01), m3, lr=1e-3, eps=1e-6, max_grad_norm=0.05)   # the clip is active
+            assert dp3.defer_cast_back
+            dp3.defer_cast_back = defer
+            for it in range(2):
+                dp3.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
+                assert dp3.g16_valid == defer
+                if defer and it == 1:
+                    local = m3._flat_grad.clone()
+                    avg = m3.flat_grads().clone()              # materialises: one rank, so local == averaged up to the bf16 rounding
+                    assert not dp3.g16_valid and torch.allclose(avg, local, rtol=1.0 / 128, atol=1e-6)
+                opt3.step()
+                assert not dp3.g16_valid
+                for p in m3.parameters():
+                    p.grad = None
+            torch.cuda.synchronize()
+            outs.append((m3.flat_params().clone(), float(opt3.grad_norm())))
+        assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
     finally:
         dist.destroy_process_group()
 

@@ -94,6 +94,8 @@ PROTOTYPES = {
     "vlt5_sqnorm": (c_i, [vp, c_ll, vp, vp, c_i, vp]),
     "vlt5_sqnorm_blocks": (c_i, [c_ll]),
     "vlt5_adamw_step": (c_i, [vp, vp, vp, vp, vp, c_ll, c_f, c_f, c_f, c_f, c_f, c_i, vp, c_f, c_i, vp]),
+    "vlt5_sqnorm_g16": (c_i, [vp, c_f, c_ll, vp, vp, c_i, vp]),
+    "vlt5_adamw_step_g16": (c_i, [vp, vp, c_f, vp, vp, vp, c_ll, c_f, c_f, c_f, c_f, c_f, c_i, vp, c_f, c_i, vp]),
     "vlt5_cast_bf16": (c_i, [vp, vp, c_ll, vp]),
     "vlt5_cast_f32": (c_i, [vp, vp, c_ll, c_f, vp]),
     "vlt5_scale_add": (c_i, [vp, vp, c_f, c_f, c_ll, vp]),

@@ -15,16 +15,33 @@ __device__ __forceinline__ void nt_store4(float* p, float a, float b, float c, f
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4v*>(p));
 }
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long long n, float* __restrict__ partial) {
+// four gradients starting at element i: f32 as they are, or (G16) bf16 times `gs` -- exactly what vlt5_cast_f32 would have written
+template <bool G16>
+__device__ __forceinline__ float4 grad4(const void* __restrict__ g, long long i, float gs, bool nt) {
+    if (G16) {
+        const uint2 a = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g) + i);
+        return make_float4(__uint_as_float(a.x << 16) * gs, __uint_as_float(a.x & 0xffff0000u) * gs,
+                           __uint_as_float(a.y << 16) * gs, __uint_as_float(a.y & 0xffff0000u) * gs);
+    }
+    const float* f = reinterpret_cast<const float*>(g) + i;
+    return nt ? nt_load4(f) : *reinterpret_cast<const float4*>(f);
+}
+template <bool G16>
+__device__ __forceinline__ float grad1(const void* __restrict__ g, long long i, float gs) {
+    return G16 ? bf16_to_f32(reinterpret_cast<const bf16_t*>(g)[i]) * gs : reinterpret_cast<const float*>(g)[i];
+}
+
+template <bool G16>
+__global__ __launch_bounds__(256) void sqnorm_kernel(const void* __restrict__ g, float gs, long long n, float* __restrict__ partial) {
     __shared__ float sh[4];
     float s = 0.f;
     const long long stride = (long long)gridDim.x * blockDim.x * 4;
     for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 3 < n) {
-            float4 v = *reinterpret_cast<const float4*>(g + i);
+            float4 v = grad4<G16>(g, i, gs, false);
             s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         } else {
-            for (long long k = i; k < n; ++k) s += g[k] * g[k];
+            for (long long k = i; k < n; ++k) { const float x = grad1<G16>(g, k, gs); s += x * x; }
         }
     }
     s = wave_sum(s);
@@ -39,7 +56,8 @@ __global__ void sqnorm_final_kernel(const float* __restrict__ partial, int nblk,
     if (threadIdx.x == 0) total[0] = accum ? total[0] + s : s;
 }
 
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+template <bool G16>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const void* __restrict__ g, float gs, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ pb, long long n, float lr,
                                                     float b1, float b2, float eps, float wd, float bc1, float bc2,
                                                     const float* __restrict__ total_sq, float max_norm, int hf_mode) {
@@ -51,11 +69,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         float pv[4], gv[4], mv[4], vv[4];
         if (cnt == 4) {
             // streamed once per step: non-temporal so 3.6 GB of optimizer state do not evict the weights' bf16 shadow from L2/MALL
-            float4 a = nt_load4(p + i), b = nt_load4(g + i), c = nt_load4(m + i), e = nt_load4(v + i);
+            float4 a = nt_load4(p + i), b = grad4<G16>(g, i, gs, true), c = nt_load4(m + i), e = nt_load4(v + i);
             pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w; gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
             mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w; vv[0] = e.x; vv[1] = e.y; vv[2] = e.z; vv[3] = e.w;
         } else {
-            for (int k = 0; k < cnt; ++k) { pv[k] = p[i + k]; gv[k] = g[i + k]; mv[k] = m[i + k]; vv[k] = v[i + k]; }
+            for (int k = 0; k < cnt; ++k) { pv[k] = p[i + k]; gv[k] = grad1<G16>(g, i + k, gs); mv[k] = m[i + k]; vv[k] = v[i + k]; }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -163,7 +181,18 @@ extern "C" int vlt5_sqnorm(const float* g, long long n, float* partial, float* t
     if (!g || !partial || !total_sq || n <= 0) return VLT5_ERR_ARG;
     if (((uintptr_t)g) & 15) return VLT5_ERR_ALIGN;
     int nblk = grid_for(n, 4);
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk), dim3(256), 0, ST, g, n, partial);
+    hipLaunchKernelGGL(sqnorm_kernel<false>, dim3(nblk), dim3(256), 0, ST, (const void*)g, 1.f, n, partial);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(64), 0, ST, partial, nblk, total_sq, accum_total);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_sqnorm_g16(const void* g_bf16, float g_scale, long long n, float* partial, float* total_sq, int accum_total,
+                               void* stream) {
+    if (!g_bf16 || !partial || !total_sq || n <= 0) return VLT5_ERR_ARG;
+    if (((uintptr_t)g_bf16) & 7) return VLT5_ERR_ALIGN;
+    int nblk = grid_for(n, 4);
+    hipLaunchKernelGGL(sqnorm_kernel<true>, dim3(nblk), dim3(256), 0, ST, g_bf16, g_scale, n, partial);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(64), 0, ST, partial, nblk, total_sq, accum_total);
     LAUNCH_CHECK();
@@ -176,8 +205,20 @@ extern "C" int vlt5_adamw_step(float* p, const float* g, float* m, float* v, voi
     if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return VLT5_ERR_ALIGN;
     if (p_bf16 && (((uintptr_t)p_bf16) & 7)) return VLT5_ERR_ALIGN;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 4)), dim3(256), 0, ST, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, bc2, total_sq, max_norm, hf_mode);
+    hipLaunchKernelGGL(adamw_kernel<false>, dim3(grid_for(n, 4)), dim3(256), 0, ST, p, (const void*)g, 1.f, m, v, (bf16_t*)p_bf16, n, lr,
+                       beta1, beta2, eps, weight_decay, bc1, bc2, total_sq, max_norm, hf_mode);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+extern "C" int vlt5_adamw_step_g16(float* p, const void* g_bf16, float g_scale, float* m, float* v, void* p_bf16, long long n, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, int step, const float* total_sq,
+                                   float max_norm, int hf_mode, void* stream) {
+    if (!p || !g_bf16 || !m || !v || n <= 0 || step < 1) return VLT5_ERR_ARG;
+    if ((((uintptr_t)p) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return VLT5_ERR_ALIGN;
+    if ((((uintptr_t)g_bf16) & 7) || (p_bf16 && (((uintptr_t)p_bf16) & 7))) return VLT5_ERR_ALIGN;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel<true>, dim3(grid_for(n, 4)), dim3(256), 0, ST, p, g_bf16, g_scale, m, v, (bf16_t*)p_bf16, n, lr,
+                       beta1, beta2, eps, weight_decay, bc1, bc2, total_sq, max_norm, hf_mode);
     LAUNCH_CHECK();
     return VLT5_OK;
 }

@@ -334,6 +334,8 @@ class VLT5(nn.Module):
         return self._flat
 
     def flat_grads(self):
+        if self.dp is not None and getattr(self.dp, "g16_valid", False):
+            self.dp.materialize_grads(self)      # data parallel, deferred cast-back: the averaged gradients are still bf16
         return self._flat_grad
 
     def flat_bf16(self):
@@ -496,6 +498,8 @@ class VLT5(nn.Module):
         if direct:
             target = self._flat_grad
         else:
+            if self.dp is not None and getattr(self.dp, "g16_valid", False):
+                self.dp.materialize_grads(self)  # accumulate onto the averaged gradients of the previous backward, not the local ones
             if self._flat_grad_tmp is None:
                 self._flat_grad_tmp = torch.zeros_like(self._flat_grad)
             target = self._flat_grad_tmp

@@ -68,6 +68,10 @@ class FusedAdamW(torch.optim.Optimizer):
             else:
                 runs.append([a, b, gi])
         self._runs = runs
+        # data parallel with bf16 buckets: read the reduced gradients straight from the staging buffer (no cast-back pass)
+        dp = getattr(model, "dp", None)
+        if dp is not None and dp.grad_dtype is torch.bfloat16 and flat.is_cuda:
+            dp.defer_cast_back = True
         self.overlap = bool(overlap)
         if self.overlap:
             # the same runs cut at bucket boundaries, grouped by bucket
@@ -94,7 +98,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             raise L.Vlt5Error("closures are not supported")
         model = self.model
-        flat, grad, bf16 = model.flat_params(), model.flat_grads(), model.flat_bf16()
+        flat, grad, bf16 = model.flat_params(), model._flat_grad, model.flat_bf16()     # (flat_grads() would cast a deferred bucket back)
         anchor = model._params_by_name["shared.weight"]
         if anchor.grad is None:
             return None
@@ -103,19 +107,29 @@ class FusedAdamW(torch.optim.Optimizer):
                 if p.grad is not None:
                     model._gviews[name].copy_(p.grad)
         self._t += 1
+        dp = getattr(model, "dp", None)
+        g16 = dp._g16 if (dp is not None and dp.g16_valid and grad.data_ptr() == model._flat_grad.data_ptr()) else None
+        gs = dp.grad_scale if g16 is not None else 1.0
 
         def update(runs, st, total):
             for a, b, gi in runs:
                 g = self.param_groups[gi]
-                check(lib().vlt5_adamw_step(L.vp(flat.data_ptr() + 4 * a), L.vp(grad.data_ptr() + 4 * a),
-                                            L.vp(self._m.data_ptr() + 4 * a), L.vp(self._v.data_ptr() + 4 * a),
-                                            L.vp(bf16.data_ptr() + 2 * a), b - a, float(g["lr"]), float(g["betas"][0]),
-                                            float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._t, ptr(total),
-                                            float(self.max_grad_norm or 0.0), self.hf_mode, st), "vlt5_adamw_step")
+                tail = (L.vp(self._m.data_ptr() + 4 * a), L.vp(self._v.data_ptr() + 4 * a), L.vp(bf16.data_ptr() + 2 * a), b - a,
+                        float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._t,
+                        ptr(total), float(self.max_grad_norm or 0.0), self.hf_mode, st)
+                if g16 is None:
+                    check(lib().vlt5_adamw_step(L.vp(flat.data_ptr() + 4 * a), L.vp(grad.data_ptr() + 4 * a), *tail), "vlt5_adamw_step")
+                else:       # the reduced bf16 bucket as the all-reduce left it, times 1/world
+                    check(lib().vlt5_adamw_step_g16(L.vp(flat.data_ptr() + 4 * a), L.vp(g16.data_ptr() + 2 * a), gs, *tail),
+                          "vlt5_adamw_step_g16")
 
         def norm(st):
             if self.max_grad_norm is not None and self.max_grad_norm > 0:
-                check(lib().vlt5_sqnorm(ptr(grad), self._used_end, ptr(self._partial), ptr(self._total_sq), 0, st), "vlt5_sqnorm")
+                if g16 is None:
+                    check(lib().vlt5_sqnorm(ptr(grad), self._used_end, ptr(self._partial), ptr(self._total_sq), 0, st), "vlt5_sqnorm")
+                else:
+                    check(lib().vlt5_sqnorm_g16(ptr(g16), gs, self._used_end, ptr(self._partial), ptr(self._total_sq), 0, st),
+                          "vlt5_sqnorm_g16")
                 return self._total_sq
             return None
 
@@ -132,6 +146,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     update(self._bucket_runs[bkt], st, total)
                     self._events[bkt].record(self._side)
             model._opt_events = self._events
+        if g16 is not None:
+            dp.g16_valid = False            # consumed (the f32 gradient buffer keeps this rank's local gradients)
         model.external_bf16_sync = True
         model._bf16_version = flat._version
         return None

@@ -14,6 +14,12 @@ the optimizer and `.grad` see fp32 as before.  At 8 GPUs the fp32 reduction of 0
 ~6.5 ms of backward to hide it in; bf16 needs half.  (The rounding -- one bf16 rounding per rank contribution -- is of the same
 size as the bf16 GEMM noise already in the gradients.)
 
+With the fused optimizer the way back is not a pass of its own: `FusedAdamW` attached to a wrapped model sets `defer_cast_back`,
+the reduced buckets stay in the bf16 staging buffer and the gradient-norm and AdamW kernels read them from there
+(`vlt5_sqnorm_g16` / `vlt5_adamw_step_g16`, gradient = bf16 * 1/world: the very values the cast back would have written), which
+takes 1.35 GB of HBM traffic and one kernel per bucket out of the step's tail.  `.grad` then still holds the rank-local f32
+gradients; `materialize_grads()` writes the averaged ones there on demand.
+
 Also all-reduces the prototype sufficient statistics (class sums and counts) so that every rank holds the
 prototypes a single process would compute on the concatenated batch.
 """
@@ -48,6 +54,8 @@ class DataParallelVLT5:
         self._events = None
         self._next = 0
         self._pending_from = 0
+        self.defer_cast_back = False        # set by FusedAdamW: the optimizer reads the reduced bf16 buckets itself
+        self.g16_valid = False              # the staging buffer holds this backward's reduced gradients, not yet cast back
         # identical initial weights on every rank (what DDP's constructor would do)
         dist.broadcast(model._flat, src=0, group=process_group)
         model._bf16_version = -1
@@ -65,7 +73,21 @@ class DataParallelVLT5:
         self._pending_from = 0
         return self._events
 
-    def _allreduce_slice(self, flat, a, b):
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world if self.average else 1.0
+
+    def materialize_grads(self, model=None):
+        """Deferred mode: write the averaged gradients into the f32 gradient buffer (what `.grad` views) on the current stream."""
+        if not self.g16_valid:
+            return
+        from ._lib import check, lib, ptr, stream_ptr
+        flat = (model or self.module)._flat_grad
+        end = self.bucket_end[-1]
+        check(lib().vlt5_cast_f32(ptr(self._g16), ptr(flat), end, self.grad_scale, stream_ptr()), "vlt5_cast_f32")
+        self.g16_valid = False
+
+    def _allreduce_slice(self, flat, a, b, defer=False):
         t = flat[a:b]
         if self.grad_dtype is torch.bfloat16 and flat.is_cuda:
             from ._lib import check, lib, ptr, stream_ptr
@@ -74,8 +96,8 @@ class DataParallelVLT5:
             h = self._g16[a:b]
             check(lib().vlt5_cast_bf16(ptr(t), ptr(h), b - a, stream_ptr()), "vlt5_cast_bf16")
             dist.all_reduce(h, group=self.group)
-            check(lib().vlt5_cast_f32(ptr(h), ptr(t), b - a, 1.0 / self.world if self.average else 1.0, stream_ptr()),
-                  "vlt5_cast_f32")
+            if not defer:
+                check(lib().vlt5_cast_f32(ptr(h), ptr(t), b - a, self.grad_scale, stream_ptr()), "vlt5_cast_f32")
             return
         dist.all_reduce(t, group=self.group)
         if self.average:
@@ -92,7 +114,10 @@ class DataParallelVLT5:
                 last = (self._next == len(self.bucket_end))
                 if size >= self.bucket_bytes or last or self._next == upto:
                     self.comm_stream.wait_event(events[b])
-                    self._allreduce_slice(flat, self.bucket_start[self._pending_from], self.bucket_end[b])
+                    defer = self.defer_cast_back and self.grad_dtype is torch.bfloat16
+                    self._allreduce_slice(flat, self.bucket_start[self._pending_from], self.bucket_end[b], defer=defer)
+                    if last:
+                        self.g16_valid = defer
                     self._pending_from = self._next
 
     def finish(self):
@@ -101,4 +126,5 @@ class DataParallelVLT5:
     def reduce_flat(self, flat):
         """Non-overlapped path (gradient accumulation into a temporary buffer, or CPU/gloo tests)."""
         end = self.bucket_end[-1]
+        self.g16_valid = False
         self._allreduce_slice(flat, 0, end)
