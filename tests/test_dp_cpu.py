@@ -62,7 +62,7 @@ def _worker(rank, world, port, q):
         onehot_all = torch.zeros(8, 10).scatter_(1, ids[:, None], 1.0)
         lo, hi = rank * 4, rank * 4 + 4
         local_proto, local_cnt = R.calculate_current_prototype(pool_all[lo:hi].unsqueeze(1), onehot_all[lo:hi])
-        proto, cnt = model.proto._allreduce_stats(local_proto, local_cnt)
+        (proto, cnt), = model.proto._allreduce_stats((local_proto, local_cnt))
         ref_proto, ref_cnt = R.calculate_current_prototype(pool_all.unsqueeze(1), onehot_all)
         assert torch.allclose(proto, ref_proto, atol=1e-6) and torch.equal(cnt, ref_cnt)
         dist.barrier()

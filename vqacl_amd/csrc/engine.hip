@@ -691,14 +691,6 @@ int encoder_bwd(const Ctx& k) {
     }
     RC(vlt5_relbias_bwd(k.w<float>(p.dS_enc), s.enc_lut, k.Gr + L.enc_rel, k.w<float>(p.rel_scratch), Le * B, k.H, s.L, s.L,
                         c.rel_buckets, 0, k.st));
-    // (a third flush group of Le/4 layers was measured: batches of 3 layers fill the chip too poorly, +4 % step time)
-    const int low_end = Le > 1 ? Le / 2 : Le;
-    RC(k.fork(2));
-    {
-        const Ctx ks = k.on_side();                       // beside the embedding / visual-embedding backward below
-        RC(enc_wgrads(ks, 0, low_end));                   // lower half of the stack (the upper half was flushed mid-way)
-        for (int b = Ld + 1 + (Le - low_end); b <= Ld + Le; ++b) RC(ks.record(b));
-    }
     // inputs: text rows -> shared (scatter-add), visual rows -> visual embedding parameters
     RC(vlt5_embed_bwd(s.input_ids, dx, (long long)S * d, d, k.Gr + L.shared, B, s.L, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, 0, k.st));
     float* vpart = k.w<float>(p.vis_partial);
@@ -711,8 +703,17 @@ int encoder_bwd(const Ctx& k) {
                              k.Gr + L.vis_img, k.Gr + L.vis_bf, d, c.n_images, k.st));
     RC(k.lin_wgrad(k.w<bf16_t>(p.vis_dG), d, k.w<bf16_t>(p.feats_bf16), c.feat_dim, k.Gr + L.vis_wf, B * s.V, d, c.feat_dim));
     RC(k.ln_flush());
+    RC(k.record(Ld + 1 + Le));                            // embeddings + norms + visual embedding: complete BEFORE the last weight-
+                                                          // gradient GEMMs, so their all-reduce hides under those (data parallel)
+    // (a third flush group of Le/4 layers was measured: batches of 3 layers fill the chip too poorly, +4 % step time)
+    const int low_end = Le > 1 ? Le / 2 : Le;
+    RC(k.fork(2));
+    {
+        const Ctx ks = k.on_side();
+        RC(enc_wgrads(ks, 0, low_end));                   // lower half of the stack (the upper half was flushed mid-way)
+        for (int b = Ld + 1 + (Le - low_end); b <= Ld + Le; ++b) RC(ks.record(b));
+    }
     RC(k.join(3));                                        // every gradient is complete on the caller's stream from here on
-    RC(k.record(Ld + 1 + Le));                            // embeddings + norms + visual embedding
     return VLT5_OK;
 }
 

@@ -531,15 +531,17 @@ class VLT5(nn.Module):
         stream = stream_ptr()
         check(lib().vlt5_decoder_bwd(C.byref(c), C.byref(cs), stream), "vlt5_decoder_bwd")
         if events is not None:
-            self.dp.reduce_ready(self, events, upto=self.cfg.num_decoder_layers + 1)
+            self.dp.reduce_range(self, events, 0, self.cfg.num_decoder_layers + 1)
         check(lib().vlt5_encoder_bwd(C.byref(c), C.byref(cs), stream), "vlt5_encoder_bwd")
         if events is not None:
-            # collectives are cut where the engine releases gradients (upper half / lower half of the encoder, then
-            # embeddings + norms), so a merged bucket never waits for a later group than its own
-            Ld, Le = self.cfg.num_decoder_layers, self.cfg.num_layers
-            cuts = [Ld + 1 + (Le - Le // 2)] if Le > 1 else []
-            for upto in cuts + [Ld + 1 + Le, self._nbuckets]:
-                self.dp.reduce_ready(self, events, upto=upto)
+            # collectives are cut where the engine releases gradients: upper half of the encoder (mid-phase), then embeddings +
+            # norms + visual embedding (released BEFORE the last weight-gradient GEMMs: their all-reduce hides under those),
+            # then the lower half of the encoder -- the only group whose all-reduce stays exposed
+            Ld, Le, nb = self.cfg.num_decoder_layers, self.cfg.num_layers, self._nbuckets
+            cut = Ld + 1 + (Le - Le // 2) if Le > 1 else Ld + 1
+            self.dp.reduce_range(self, events, Ld + 1, cut)
+            self.dp.reduce_range(self, events, nb - 1, nb)
+            self.dp.reduce_range(self, events, cut, nb - 1, final=True)
             self.dp.finish()
         elif self.dp is not None:
             self.dp.reduce_flat(target)

@@ -103,22 +103,21 @@ class DataParallelVLT5:
         if self.average:
             t.div_(self.world)
 
-    def reduce_ready(self, model, events, upto):
-        """Issue the all-reduces of buckets [self._next, upto) on the comm stream, each after its event."""
+    def reduce_range(self, model, events, lo, hi, final=False):
+        """Issue the all-reduces of buckets [lo, hi) on the comm stream: consecutive buckets are merged up to `bucket_bytes`, each
+        merged slice goes after the event of its last bucket.  `final`: this call completes the gradient buffer."""
         flat = model._flat_grad
+        defer = self.defer_cast_back and self.grad_dtype is torch.bfloat16
         with torch.cuda.stream(self.comm_stream):
-            while self._next < upto:
-                b = self._next
-                self._next += 1
-                size = (self.bucket_end[b] - self.bucket_start[self._pending_from]) * 4
-                last = (self._next == len(self.bucket_end))
-                if size >= self.bucket_bytes or last or self._next == upto:
+            start = lo
+            for b in range(lo, hi):
+                size = (self.bucket_end[b] - self.bucket_start[start]) * 4
+                if size >= self.bucket_bytes or b == hi - 1:
                     self.comm_stream.wait_event(events[b])
-                    defer = self.defer_cast_back and self.grad_dtype is torch.bfloat16
-                    self._allreduce_slice(flat, self.bucket_start[self._pending_from], self.bucket_end[b], defer=defer)
-                    if last:
-                        self.g16_valid = defer
-                    self._pending_from = self._next
+                    self._allreduce_slice(flat, self.bucket_start[start], self.bucket_end[b], defer=defer)
+                    start = b + 1
+        if final:
+            self.g16_valid = defer
 
     def finish(self):
         torch.cuda.current_stream().wait_stream(self.comm_stream)

@@ -34,8 +34,7 @@ class PrototypeHead:
         curQ, numQ = ops.proto_class_mean(poolQ, ques_labels)
         curV, numV = ops.proto_class_mean(poolV, cate_labels)
         if self.dist_enabled:
-            curQ, numQ = self._allreduce_stats(curQ, numQ)
-            curV, numV = self._allreduce_stats(curV, numV)
+            (curQ, numQ), (curV, numV) = self._allreduce_stats((curQ, numQ), (curV, numV))
         first = task not in self.seen_tasks
         qmem, qinit = None, 0
         if not first and task != 0:
@@ -51,17 +50,24 @@ class PrototypeHead:
         self.seen_tasks.add(task)
         return curQ, curV
 
-    def _allreduce_stats(self, proto, cnt):
+    def _allreduce_stats(self, *stats):
         """Data parallel: class means over the GLOBAL batch = all-reduced sums / all-reduced counts, so every rank
-        holds the prototypes a single process would compute on the concatenated batch."""
+        holds the prototypes a single process would compute on the concatenated batch.  The Q and V statistics
+        travel in ONE collective (277 KB): a small all-reduce is pure latency."""
         import torch.distributed as dist
-        sums = proto * cnt.clamp(min=1).unsqueeze(1)
-        packed = torch.cat([sums.reshape(-1), cnt])
+        parts = []
+        for proto, cnt in stats:
+            parts += [(proto * cnt.clamp(min=1).unsqueeze(1)).reshape(-1), cnt]
+        packed = torch.cat(parts)
         dist.all_reduce(packed, group=self.dist_group)
-        n = proto.numel()
-        cnt = packed[n:].clone()
-        sums = packed[:n].view_as(proto)
-        return (sums / cnt.clamp(min=1).unsqueeze(1)).contiguous(), cnt
+        out, off = [], 0
+        for proto, cnt in stats:
+            n = proto.numel()
+            sums = packed[off:off + n].view_as(proto)
+            c = packed[off + n:off + n + cnt.numel()].clone()
+            off += n + cnt.numel()
+            out.append(((sums / c.clamp(min=1).unsqueeze(1)).contiguous(), c))
+        return out
 
     # ---- retrieval: cosine_similarity_multi + gather, written straight into the decoder's memory rows --
     def retrieve(self, poolQ, poolV, enc_f32, enc_bf16, S: int):
