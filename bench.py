@@ -285,14 +285,20 @@ def main():
         out["samples_per_sec_store_feed"] = round(8 * B / (time.perf_counter() - t1), 2)
         # the gather kernel against the HBM roofline: algorithmic bytes = rows read + rows written (bf16 features + f32 boxes)
         slots = store.slots(draws[0])
+        from vqacl_amd._lib import lib, ptr, stream_ptr
+        of = torch.empty(B, V, cfg.feat_dim, dtype=torch.bfloat16, device=dev)
+        ob = torch.empty(B, V, 4, device=dev)
+        gargs = (ptr(store.feats), ptr(store.boxes), ptr(slots), store.capacity, ptr(of), ptr(ob), B, V, cfg.feat_dim, stream_ptr())
+        fn = lib().vlt5_feat_gather                      # pre-bound arguments: the launch loop must not be host-bound (a launch is ~6 us)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        store.gather(slots)
+        for _ in range(10):
+            fn(*gargs)
         e0.record()
-        for _ in range(20):
-            store.gather(slots)
+        for _ in range(200):
+            fn(*gargs)
         e1.record()
         e1.synchronize()
-        us = e0.elapsed_time(e1) / 20 * 1e3
+        us = e0.elapsed_time(e1) / 200 * 1e3
         gbytes = 2 * B * V * (cfg.feat_dim * 2 + 16) / 1e9
         out["feed"] = {"kernel": "feat_gather_kernel", "bound": "hbm", "bytes_per_launch": int(gbytes * 1e9), "us": round(us, 2),
                        "achieved": round(gbytes / (us * 1e-6), 1), "peak": 8000.0, "unit": "GB/s",
