@@ -58,7 +58,7 @@ def gemm_schedule(cfg, B, L, V, T):
     return sch
 
 
-def time_gemms(cfg, B, L, V, T, dev, reps=10):
+def time_gemms(cfg, B, L, V, T, dev, reps=20):
     """HIP-event timing of each distinct GEMM launch of the step on the current stream (same tile / split-K / batching
     policy as the engine)."""
     from vqacl_amd import ops
@@ -73,12 +73,17 @@ def time_gemms(cfg, B, L, V, T, dev, reps=10):
         sk = lib().vlt5_gemm_auto_split(M, N, K, slab) if (of32 and bkm and batch == 1) else 1
         kw = dict(a_kmajor=bool(akm), b_kmajor=bool(bkm), out=out[0], split_k=sk, batch=batch,
                   batch_strides=(A.stride(0), Bm.stride(0), out.stride(0)))
+        # descriptor built once, the loop only launches: a 400-row decoder GEMM is 6-8 us, a Python-side descriptor build is more
+        import ctypes as C
+        from vqacl_amd._lib import stream_ptr
+        g, _, keep = ops.gemm_desc(A[0], Bm[0], M, N, K, **kw)
+        fn, gp, sp = lib().vlt5_gemm_bf16, C.byref(g), stream_ptr()
         for _ in range(2):
-            ops.gemm(A[0], Bm[0], M, N, K, **kw)
+            assert fn(gp, sp) == 0
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            ops.gemm(A[0], Bm[0], M, N, K, **kw)
+            fn(gp, sp)
         e1.record()
         e1.synchronize()
         ms = e0.elapsed_time(e1) / reps

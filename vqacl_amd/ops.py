@@ -25,6 +25,19 @@ def gemm(A, B, M, N, K, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=Fal
          resid=None, gate=None, gate_scale=1.0, drop_p=0.0, drop_seed=0, accum=False, split_k=1, tile=(0, 0),
          lda=None, ldb=None, ldc=None, batch=1, batch_strides=(0, 0, 0)):
     """C[M,N] = epi(alpha * sum_k A[m,k] B[n,k]); A,B bf16 2-D tensors, k-major flags as in vlt5_gemm_desc."""
+    g, out, _keep = gemm_desc(A, B, M, N, K, a_kmajor=a_kmajor, b_kmajor=b_kmajor, out=out, out_f32=out_f32, alpha=alpha, bias=bias,
+                              relu=relu, resid=resid, gate=gate, gate_scale=gate_scale, drop_p=drop_p, drop_seed=drop_seed,
+                              accum=accum, split_k=split_k, tile=tile, lda=lda, ldb=ldb, ldc=ldc, batch=batch,
+                              batch_strides=batch_strides)
+    check(lib().vlt5_gemm_bf16(C.byref(g), stream_ptr()), "vlt5_gemm_bf16")
+    return out
+
+
+def gemm_desc(A, B, M, N, K, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, alpha=1.0, bias=None, relu=False,
+              resid=None, gate=None, gate_scale=1.0, drop_p=0.0, drop_seed=0, accum=False, split_k=1, tile=(0, 0),
+              lda=None, ldb=None, ldc=None, batch=1, batch_strides=(0, 0, 0)):
+    """The filled vlt5_gemm_desc of `gemm` without launching it: (desc, out, keep-alive) -- for launch loops that must not pay the
+    descriptor construction per call (bench.py)."""
     _need(A, BF16), _need(B, BF16)
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32 if out_f32 else BF16)
@@ -49,8 +62,7 @@ def gemm(A, B, M, N, K, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=Fal
     g.tile_m, g.tile_n = tile
     g.batch = batch
     g.batch_stride_a, g.batch_stride_b, g.batch_stride_c = batch_strides
-    check(lib().vlt5_gemm_bf16(C.byref(g), stream_ptr()), "vlt5_gemm_bf16")
-    return out
+    return g, out, (A, B, ws, bias, resid, gate)
 
 
 def layernorm_fwd(x, w, eps=1e-6, want_f32=False, drop_p=0.0, drop_seed=0):
