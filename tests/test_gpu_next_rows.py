@@ -69,6 +69,43 @@ def test_feature_store_put_gather_bit_exact(dev):
     assert lib().vlt5_feat_gather(None, ptr(full.boxes), ptr(sl), 2, ptr(out), ptr(ob), 1, 4, 8, stream_ptr()) == 1001
 
 
+class _Dataset:
+    """The slice of h5py's dataset interface the reference's item read uses: `read_direct(dest)` and `ds[()]`."""
+
+    def __init__(self, arr):
+        self.arr = arr
+
+    def read_direct(self, dest):
+        dest[...] = self.arr
+
+    def __getitem__(self, key):
+        assert key == ()
+        return self.arr.copy() if self.arr.ndim else self.arr[()]
+
+
+def test_h5_layout_source_fills_the_store(dev):
+    """The reference's file layout ({img_id}/features, boxes in pixels, img_w, img_h: vqa_data_memory.py:166-187) read through
+    `H5FeatureSource` into the store (h5py itself is not in this image: the file object is a mapping with its dataset interface)."""
+    import numpy as np
+    from vqacl_amd.feed import FeatureStore, H5FeatureSource, normalize_boxes
+    rng = np.random.default_rng(2)
+    ids, f, want = [f"COCO_val2014_{k:012d}" for k in range(7)], {}, {}
+    for k, i in enumerate(ids):
+        w, h = 640 - 17 * k, 480 + 3 * k
+        feats = np.maximum(rng.standard_normal((36, 64)).astype(np.float32), 0)
+        boxes = np.sort(rng.random((36, 4)).astype(np.float32), axis=1) * np.array([w, h, w, h], dtype=np.float32)
+        f[f"{i}/features"], f[f"{i}/boxes"] = _Dataset(feats), _Dataset(boxes)
+        f[f"{i}/img_w"], f[f"{i}/img_h"] = _Dataset(np.array(w)), _Dataset(np.array(h))
+        want[i] = (torch.from_numpy(feats).to(BF), normalize_boxes(boxes, np.int64(w), np.int64(h)))
+    store = FeatureStore(8, n_boxes=36, feat_dim=64, device=dev)
+    H5FeatureSource(f, n_boxes=36, feat_dim=64).fill(store, ids, chunk=3)
+    assert len(store) == 7
+    gf, gb = store.gather(store.slots(ids[::-1]))
+    for r, i in enumerate(ids[::-1]):
+        assert torch.equal(gf[r].cpu(), want[i][0]) and torch.equal(gb[r].cpu(), want[i][1])
+        assert float(gb[r].max()) <= 1.0
+
+
 def test_train_and_test_step_from_store_equal_the_f32_batch(dev):
     """Feeding a step from the store changes nothing downstream: same encoder states bit for bit, same loss, same tokens."""
     from oracle import ref_cpu as R

@@ -180,8 +180,11 @@ class H5FeatureSource:
     ImportError when constructed without it; everything else in this module works without)."""
 
     def __init__(self, path, n_boxes=36, feat_dim=2048):
-        import h5py
-        self.f = h5py.File(path, "r")
+        if isinstance(path, (str, bytes)) or hasattr(path, "__fspath__"):
+            import h5py
+            self.f = h5py.File(path, "r")
+        else:
+            self.f = path               # an already opened file (or any mapping with h5py's dataset interface)
         self.n_boxes, self.feat_dim = n_boxes, feat_dim
 
     def read(self, img_id):
