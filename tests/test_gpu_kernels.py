@@ -121,6 +121,67 @@ def test_gemm_epilogues(dev, tile, M, N, K):
     close(out, base + 2.0, 2e-3, 2e-2, "accumulate")
 
 
+def test_gemm_randomised_shapes_layouts_and_epilogues(dev):
+    """60 seeded random problems: ragged M (any), N and K multiples of 8 (K tails below 64), every operand layout, every tile,
+    padded leading dimensions, split-K, layer batches, and the epilogue combinations the engine issues -- against torch f32."""
+    import random as _r
+    from vqacl_amd import ops
+    rr = _r.Random(2024)
+    g = torch.Generator().manual_seed(2024)
+    tiles = [(0, 0), (64, 64), (64, 128), (128, 64), (128, 128), (256, 256)]
+    for case in range(60):
+        M = rr.choice([1, 5, 17, 63, 64, 65, 200, 400, 513, 1000])
+        N = 8 * rr.randint(1, 70)
+        K = 8 * rr.randint(1, 60)
+        akm, bkm = rr.random() < 0.4, rr.random() < 0.5
+        if akm:
+            M = max(8, M // 8 * 8)                       # a k-major operand is read in 8-element vectors along its rows
+        tile = rr.choice(tiles)
+        batch = rr.choice([1, 1, 1, 3])
+        pad_a, pad_b = 8 * rr.randint(0, 2), 8 * rr.randint(0, 2)
+        Af = rnd((batch, K, M + pad_a) if akm else (batch, M, K + pad_a), g)
+        Bf = rnd((batch, K, N + pad_b) if bkm else (batch, N, K + pad_b), g) * 0.3
+        A, B = Af.to(BF).to(dev), Bf.to(BF).to(dev)
+        Av = A[:, :, :M] if akm else A[:, :, :K]
+        Bv = B[:, :, :N] if bkm else B[:, :, :K]
+        ref = torch.stack([((Av[z].float().t() if akm else Av[z].float()) @ (Bv[z].float() if bkm else Bv[z].float().t())).cpu()
+                           for z in range(batch)])
+        f32 = rr.random() < 0.6
+        mode = rr.choice(["plain", "plain", "relu", "resid", "bias", "gate", "accum", "split"]) if batch == 1 else "plain"
+        if mode in ("resid", "bias", "accum", "split"):
+            f32 = True
+        out = torch.zeros(batch, M, N, device=dev, dtype=torch.float32 if f32 else BF)
+        kw = dict(a_kmajor=akm, b_kmajor=bkm, out=out[0], tile=tile, lda=A.stride(1), ldb=B.stride(1), batch=batch,
+                  batch_strides=(A.stride(0), B.stride(0), out.stride(0)), alpha=rr.choice([1.0, 0.5]))
+        want = ref * kw["alpha"]
+        if mode == "relu":
+            kw["relu"] = True
+            want = torch.relu(want)
+        elif mode == "resid":
+            r = rnd((M, N), g)
+            kw["resid"] = r.to(dev)
+            want = want + r
+        elif mode == "bias":
+            bvec = rnd((N,), g)
+            kw["bias"] = bvec.to(dev)
+            want = want + bvec
+        elif mode == "gate":
+            gt = rnd((M, N), g).to(BF)
+            kw.update(gate=gt.to(dev), gate_scale=1.5)
+            want = torch.where(gt.float() > 0, want * 1.5, torch.zeros_like(want))
+        elif mode == "accum":
+            out.fill_(3.0)
+            kw["accum"] = True
+            want = want + 3.0
+        elif mode == "split":
+            kw["split_k"] = rr.choice([2, 3, 5])
+        ops.gemm(A[0], B[0], M, N, K, **kw)
+        scale = float(want.abs().max().clamp(min=1.0))
+        tol = (2e-3 if f32 else 1e-2) * scale + 1e-3 * (K ** 0.5)
+        err = float((out.float().cpu() - want).abs().max())
+        assert err <= tol, (case, M, N, K, akm, bkm, tile, batch, mode, f32, err, tol)
+
+
 def test_gemm_dropout_epilogue_statistics_and_determinism(dev):
     from vqacl_amd import ops
     g = torch.Generator().manual_seed(6)
@@ -272,7 +333,10 @@ def attn_ref(q, k, v, H, dk, bias_full):
 
 @pytest.mark.parametrize("B,H,Tq,Tk,dk,mode", [(3, 12, 56, 56, 64, "enc"), (2, 4, 48, 48, 16, "enc"), (5, 12, 5, 5, 64, "causal"),
                                                (4, 12, 5, 58, 64, "cross"), (2, 4, 7, 14, 16, "cross"), (2, 16, 64, 64, 64, "enc"),
-                                               (2, 4, 10, 10, 32, "causal")])
+                                               (2, 4, 10, 10, 32, "causal"),
+                                               # edges: a single query / a single key, odd lengths across the 16- and 32-wide MFMA blocks
+                                               (1, 1, 1, 1, 64, "cross"), (2, 3, 1, 64, 64, "cross"), (1, 2, 64, 17, 16, "cross"),
+                                               (2, 2, 33, 33, 32, "causal"), (2, 2, 1, 1, 64, "causal"), (1, 12, 21, 21, 64, "enc")])
 def test_attention_fwd_bwd(dev, B, H, Tq, Tk, dk, mode):
     from vqacl_amd import ops
     g = torch.Generator().manual_seed(B * 100 + Tq + Tk + dk)
