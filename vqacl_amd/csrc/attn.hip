@@ -48,6 +48,26 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, long 
     }
 }
 
+// the same in two halves, so that the loads of ALL tiles of a workgroup are in flight together before the first LDS store waits
+struct TileRegs { uint4 v[2]; };
+__device__ __forceinline__ void tile_load(const bf16_t* __restrict__ src, long long st, int T, int dk, int tid, TileRegs& r) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int c = tid + it * 256;
+        int row = c >> 3, dc = c & 7;
+        uint4 z = make_uint4(0, 0, 0, 0);
+        if (row < T && dc * 8 < dk) z = *reinterpret_cast<const uint4*>(src + (long long)row * st + dc * 8);
+        r.v[it] = z;
+    }
+}
+__device__ __forceinline__ void tile_store(bf16_t* nat, int tid, const TileRegs& r) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int c = tid + it * 256;
+        *reinterpret_cast<uint4*>(nat + (c >> 3) * TS + (c & 7) * 8) = r.v[it];
+    }
+}
+
 __device__ __forceinline__ bf16x8_t lds_frag(const bf16_t* tile, int row, int chunk) {     // 8 consecutive elements of a row
     return *reinterpret_cast<const bf16x8_t*>(tile + row * TS + chunk * 8);
 }
@@ -81,10 +101,32 @@ __device__ __forceinline__ bf16x8_t pack_slots(const float (&lo)[4], const float
     return r.v;
 }
 
-// scores of this wave's 16 query rows against all 64 key slots, + bias/masks; s[jb][r] in the swapped layout
+// what is added to the raw scores of this lane's 16 elements: relative-position bias + key mask + causal mask, -inf beyond Tk.
+// Depends on nothing in LDS, so it is requested BEFORE the tiles are staged: its global-memory round trip overlaps the staging
+// loads instead of following the Q.K^T MFMAs (one round trip less on the critical path of a latency-bound kernel).
+__device__ __forceinline__ void score_addend(const AttnArgs& p, int b, int h, int i0, int lane, float (&add)[4][4]) {
+    const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = jb * 16 + g * 4 + r;
+            float v = 0.f;
+            if (j < p.Tk) {
+                if (p.bias && i < p.bias_q && j < p.bias_k) v += p.bias[((size_t)h * p.bias_q + i) * p.bias_k + j];
+                if (p.key_mask) v += (1.0f - p.key_mask[(size_t)b * p.Tk + j]) * p.mask_value;
+                if (p.causal && j > i) v += -10000.0f;
+            } else {
+                v = -INFINITY;
+            }
+            add[jb][r] = v;
+        }
+}
+
+// scores of this wave's 16 query rows against all 64 key slots, + the addend above; s[jb][r] in the swapped layout
 template <bool DK64>
 __device__ __forceinline__ void scores_16x64(const AttnArgs& p, const bf16_t* Qs, const bf16_t* Ks, int b, int h, int i0,
-                                             int lane, float (&s)[4][4]) {
+                                             int lane, const float (&add)[4][4], float (&s)[4][4]) {
     const int lr = lane & 15, g = lane >> 4;
     f32x4_t acc[4];
 #pragma unroll
@@ -100,22 +142,10 @@ __device__ __forceinline__ void scores_16x64(const AttnArgs& p, const bf16_t* Qs
             acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq, acc[jb], 0, 0, 0);
         }
     }
-    const int i = i0 + lr;
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = jb * 16 + g * 4 + r;
-            float v = acc[jb][r];
-            if (j < p.Tk) {
-                if (p.bias && i < p.bias_q && j < p.bias_k) v += p.bias[((size_t)h * p.bias_q + i) * p.bias_k + j];
-                if (p.key_mask) v += (1.0f - p.key_mask[(size_t)b * p.Tk + j]) * p.mask_value;
-                if (p.causal && j > i) v += -10000.0f;
-            } else {
-                v = -INFINITY;
-            }
-            s[jb][r] = v;
-        }
+        for (int r = 0; r < 4; ++r) s[jb][r] = (add[jb][r] == -INFINITY) ? -INFINITY : acc[jb][r] + add[jb][r];
 }
 
 __device__ __forceinline__ float quad_lane_sum(float v) {     // the 4 lanes sharing a query row: l, l^16, l^32, l^48
@@ -139,16 +169,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     bf16_t* Vs = reinterpret_cast<bf16_t*>(smem + 2 * TILE_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
-    stage_tile(p.q + b * p.q_sb + (long long)h * p.dk, p.q_st, p.Tq, p.dk, Qs, tid);
-    stage_tile(p.k + b * p.k_sb + (long long)h * p.dk, p.k_st, p.Tk, p.dk, Ks, tid);
-    stage_tile(p.v + b * p.v_sb + (long long)h * p.dk, p.v_st, p.Tk, p.dk, Vs, tid);
-    __syncthreads();
     const int i0 = wave * 16;
+    float add[4][4];
+    if (i0 < p.Tq) score_addend(p, b, h, i0, lane, add);
+    {
+        TileRegs rq, rk, rv;
+        tile_load(p.q + b * p.q_sb + (long long)h * p.dk, p.q_st, p.Tq, p.dk, tid, rq);
+        tile_load(p.k + b * p.k_sb + (long long)h * p.dk, p.k_st, p.Tk, p.dk, tid, rk);
+        tile_load(p.v + b * p.v_sb + (long long)h * p.dk, p.v_st, p.Tk, p.dk, tid, rv);
+        tile_store(Qs, tid, rq);
+        tile_store(Ks, tid, rk);
+        tile_store(Vs, tid, rv);
+    }
+    __syncthreads();
     if (i0 >= p.Tq) return;
     const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
 
     float s[4][4];
-    scores_16x64<DK64>(p, Qs, Ks, b, h, i0, lane, s);
+    scores_16x64<DK64>(p, Qs, Ks, b, h, i0, lane, add, s);
     float m = -INFINITY;
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
@@ -211,10 +249,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const long long hoff = (long long)h * p.dk;
-    stage_tile(p.q + b * p.q_sb + hoff, p.q_st, p.Tq, p.dk, Qs, tid);
-    stage_tile(p.k + b * p.k_sb + hoff, p.k_st, p.Tk, p.dk, Ks, tid);
-    stage_tile(p.v + b * p.v_sb + hoff, p.v_st, p.Tk, p.dk, Vs, tid);
-    stage_tile(p.d_ctx + b * p.do_sb + hoff, p.do_st, p.Tq, p.dk, dOs, tid);
+    float add[4][4];
+    float lse_row = 0.f;
+    if (wave * 16 < p.Tq) {
+        score_addend(p, b, h, wave * 16, lane, add);
+        const int ir = wave * 16 + (lane & 15);
+        if (ir < p.Tq) lse_row = p.lse[((size_t)b * p.H + h) * p.Tq + ir];
+    }
+    {
+        TileRegs rq, rk, rv, ro;
+        tile_load(p.q + b * p.q_sb + hoff, p.q_st, p.Tq, p.dk, tid, rq);
+        tile_load(p.k + b * p.k_sb + hoff, p.k_st, p.Tk, p.dk, tid, rk);
+        tile_load(p.v + b * p.v_sb + hoff, p.v_st, p.Tk, p.dk, tid, rv);
+        tile_load(p.d_ctx + b * p.do_sb + hoff, p.do_st, p.Tq, p.dk, tid, ro);
+        tile_store(Qs, tid, rq);
+        tile_store(Ks, tid, rk);
+        tile_store(Vs, tid, rv);
+        tile_store(dOs, tid, ro);
+    }
     __syncthreads();
 
     const int i0 = wave * 16;
@@ -230,8 +282,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
 
     if (active) {
         float s[4][4];
-        scores_16x64<DK64>(p, Qs, Ks, b, h, i0, lane, s);
-        const float lse = (i < p.Tq) ? p.lse[((size_t)b * p.H + h) * p.Tq + i] : 0.f;
+        scores_16x64<DK64>(p, Qs, Ks, b, h, i0, lane, add, s);
+        const float lse = lse_row;
         // dPd[i][j] = sum_d dO[i][d] V[j][d]  (same swapped layout as the scores)
         f32x4_t dacc[4];
 #pragma unroll
