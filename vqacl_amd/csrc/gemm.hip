@@ -233,6 +233,13 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     // the 8-wave 256x256 kernel runs the hand-interleaved k-step (kstep_big).  (Tried for 4-wave 128x128 with both operands
     // k-major, the layer-batched weight gradients: 385 -> 650 us, the fragment double buffer pushes it into AGPR spills.)
     constexpr bool BIG_STEP = (WM * WN == 8);
+    // -DGEMM_PINGPONG=1 selects the two-role main loop below instead of the interleaved k-step.  Measured (round 1): correct, but
+    // no faster where it compiles without spills (4480x3072x768 with k-major B: 36.6 vs 34.8 us) and the all-row-major / all-k-major
+    // instantiations spill (302 / 383 VGPRs) -- four barriers and ~0.6 k cycles of DMA issue per k-step eat what the role split
+    // gains.  Kept for A/B runs while the one-wave-per-SIMD schedule is worked on.
+#ifndef GEMM_PINGPONG
+#define GEMM_PINGPONG 0
+#endif
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;        // stage s: A tile at s*STAGE_BYTES, B tile right after it
@@ -435,6 +442,81 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
             fill = (fill + 1 == NSTAGE) ? 0 : fill + 1;
         }
         if (nmain > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus prefetches land before LDS is reused / the wave ends
+        if (has_tail) __syncthreads();
+    } else if constexpr (BIG_STEP && GEMM_PINGPONG) {
+        // 8-wave kernel, two roles.  Waves w and w+4 share a SIMD (a workgroup's waves go to the SIMDs cyclically): behind a common
+        // barrier they would do the same thing at the same time -- both fetching fragments while the matrix pipe idles, then both
+        // issuing MFMAs.  Here the lower four waves ("X") and the upper four ("Y") run half a phase apart; a phase p is one 32-wide
+        // half (ks = p & 1) of k-tile t = p >> 1, i.e. FM + FN fragments and FM * FN MFMAs per wave:
+        //   segment 1 of phase p:  X: MFMAs of phase p            Y: fragments of phase p   <- stage t & 1
+        //   segment 2 of phase p:  X: fragments of phase p + 1    Y: MFMAs of phase p
+        // so every SIMD always has one wave on the matrix pipe and one on the LDS / DMA path, and a wave holds the fragments of
+        // ONE half k-tile (48 registers) instead of two.  Stage t & 1 is last read in segment 1 of phase 2t+1; tile t+2 is
+        // requested into it in the two segments that follow (half of a wave's DMA pieces in each, whatever the wave is doing
+        // there) and is awaited by every wave before the barrier that closes segment 1 of phase 2t+3 -- X reads it right after.
+        // The last steps re-request the final k-tile into the retired stage instead of branching around the loads.
+        static_assert(NSTAGE == 2, "two stages");
+        static_assert(LPT % 2 == 0, "the DMA pieces of a wave are issued in two halves");
+        const int role = wave >> 2;
+        if (nmain > 0) {
+            glds(min(kt0 + 1, kt0 + nmain - 1), 1);             // (tile 0 -> stage 0 was requested above)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            TL(2);
+            bf16x8_t fa[FM], fb[FN];
+            auto load_frags = [&](int ph) __attribute__((always_inline)) {
+                const char* at = smem + ((ph >> 1) & 1) * STAGE_BYTES;
+                const char* bt = at + A_BYTES;
+                const int ks = ph & 1;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) fa[i] = ldA(at, i, ks);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) fb[j] = ldB(bt, j, ks);
+            };
+            // MFMAs of the phase held in fa / fb; HALF >= 0: DMA pieces [HALF*LPT/2, (HALF+1)*LPT/2) of k-tile kt -> stage sdst in between
+            auto mfmas = [&](int half, int kt, int sdst) __attribute__((always_inline)) {
+                constexpr int NMF = FM * FN, HP = LPT / 2;
+#pragma unroll
+                for (int q = 0; q < NMF; ++q) {
+                    if (half >= 0) {
+#pragma unroll
+                        for (int pc = 0; pc < HP; ++pc)
+                            if (pc * NMF / HP == q) glds_piece(kt, sdst, half * HP + pc);
+                    }
+                    const int i = q / FN, j = q % FN;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                }
+            };
+            auto pieces = [&](int half, int kt, int sdst) __attribute__((always_inline)) {
+                constexpr int HP = LPT / 2;
+#pragma unroll
+                for (int pc = 0; pc < HP; ++pc) glds_piece(kt, sdst, half * HP + pc);
+            };
+            const int last = kt0 + nmain - 1;
+            const int P = 2 * nmain;
+            if (role == 0) load_frags(0);
+            for (int ph = 0; ph < P; ++ph) {
+                const int t = ph >> 1, odd = ph & 1;
+                // even phase (ph >= 2), segment 1: second half of the pieces of tile t+1 -> stage (t+1)&1 (free since phase 2t-1)
+                // odd phase, segment 2: first half of the pieces of tile t+2 -> stage t&1
+                if (role == 0) {
+                    if (!odd && ph >= 2) mfmas(1, min(kt0 + t + 1, last), (t + 1) & 1); else mfmas(-1, 0, 0);
+                    if (odd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (odd) pieces(0, min(kt0 + t + 2, last), t & 1);
+                    load_frags(ph + 1);
+                    __builtin_amdgcn_s_barrier();
+                } else {
+                    if (!odd && ph >= 2) pieces(1, min(kt0 + t + 1, last), (t + 1) & 1);
+                    load_frags(ph);
+                    if (odd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (odd) mfmas(0, min(kt0 + t + 2, last), t & 1); else mfmas(-1, 0, 0);
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus prefetches land before LDS is reused / the wave ends
+        }
         if (has_tail) __syncthreads();
     } else if constexpr (BIG_STEP) {
         // 8-wave kernel: two stages, branch-free steps.  Every step prefetches; the last one re-requests the final k-tile into
