@@ -281,6 +281,9 @@ int vlt5_feat_store_put(const float* feats, const float* boxes, const long long*
 int vlt5_feat_gather(const void* store_bf16, const float* box_store, const long long* slots, long long n_slots,
                      void* out_feats_bf16, float* out_boxes, int B, int V, int feat_dim, void* stream);
 
+/* vlt5_encoder_bwd completes the weight gradients of the encoder in two groups (events of vlt5_step.events): layers
+ * [late, num_layers) mid-phase, layers [0, late) at the end; returns `late` */
+int vlt5_encoder_late_layers(int num_layers);
 /* a lowest-priority stream for vlt5_step.side_stream (hipStreamCreateWithPriority); the caller destroys it */
 int vlt5_side_stream_create(void** stream);
 int vlt5_side_stream_destroy(void* stream);

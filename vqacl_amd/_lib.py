@@ -63,6 +63,7 @@ PROTOTYPES = {
     "vlt5_layernorm_fwd_slabs": (c_i, [vp, c_i, c_ll, vp, vp, c_f, c_u32, vp, vp, vp, vp, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),
     "vlt5_layernorm_bwd": (c_i, [vp, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, c_f, c_u32, vp]),
     "vlt5_layernorm_bwd_slabs": (c_i, [vp, c_i, c_ll, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, c_f, c_u32, vp]),
+    "vlt5_encoder_late_layers": (c_i, [c_i]),
     "vlt5_side_stream_create": (c_i, [C.POINTER(vp)]),
     "vlt5_side_stream_destroy": (c_i, [vp]),
     "vlt5_feat_store_put": (c_i, [vp, vp, vp, c_i, vp, vp, c_ll, c_i, c_i, vp]),

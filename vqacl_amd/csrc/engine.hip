@@ -4,6 +4,7 @@
 //
 // Reference being replaced: JointEncoder.forward (VL-T5/src/modeling_t5_our.py:175-339), VLT5.forward (:514-713),
 // the HF T5Stack/T5Block they call, and autograd's backward of both (src/vqacl.py:461).
+#include <cstdlib>
 #include "common.h"
 #include "vlt5_hip.h"
 #include <stdio.h>
@@ -640,6 +641,13 @@ int decoder_bwd(const Ctx& k) {
     return VLT5_OK;
 }
 
+// The encoder's weight gradients run as two batched groups: layers [cut, Le) as soon as the chain has passed layer `cut`, layers
+// [0, cut) at the end.  (experiment knob: VLT5_ENC_CUT = number of layers in the late group)
+inline int enc_cut(int Le) {
+    static const int env = getenv("VLT5_ENC_CUT") ? atoi(getenv("VLT5_ENC_CUT")) : 0;
+    const int c = env > 0 ? env : Le / 2;
+    return c < 1 ? 1 : (c > Le - 1 ? Le - 1 : c);
+}
 // weight gradients of encoder layers [lo, hi): one batched GEMM per weight kind (grid.z = layer)
 int enc_wgrads(const Ctx& k, int lo, int hi) {
     const Plan& p = k.p; const Layout& L = k.lay;
@@ -680,12 +688,12 @@ int encoder_bwd(const Ctx& k) {
         RC(k.ln_bwd(tmp, k.w<float>(p.x[2 * l]), E.ln_s, k.w<float>(p.xr[2 * l]), dx, M, 1, 0.f, 0, 0, 0,
                     l > 0 ? k.w<bf16_t>(p.e_dyd_f[l - 1]) : nullptr, l > 0 ? k.seed(SITE_ENC_BASE + (l - 1) * 8 + E_FFN_OUT) : 0u, ns_e,
                     (long long)M * d));
-        if (Le > 1 && l == Le / 2) {
+        if (Le > 1 && l == enc_cut(Le)) {
             // upper half of the stack: its weight gradients are complete early, so a data-parallel all-reduce of these
             // buckets overlaps with the backward of the lower half
             RC(k.fork(1));
             const Ctx ks = k.on_side();                   // beside the lower half's chain when there is a side stream
-            RC(enc_wgrads(ks, Le / 2, Le));
+            RC(enc_wgrads(ks, enc_cut(Le), Le));
             for (int b = Ld + 1; b <= Ld + 1 + (Le - 1 - l); ++b) RC(ks.record(b));
         }
     }
@@ -706,7 +714,7 @@ int encoder_bwd(const Ctx& k) {
     RC(k.record(Ld + 1 + Le));                            // embeddings + norms + visual embedding: complete BEFORE the last weight-
                                                           // gradient GEMMs, so their all-reduce hides under those (data parallel)
     // (a third flush group of Le/4 layers was measured: batches of 3 layers fill the chip too poorly, +4 % step time)
-    const int low_end = Le > 1 ? Le / 2 : Le;
+    const int low_end = Le > 1 ? enc_cut(Le) : Le;
     RC(k.fork(2));
     {
         const Ctx ks = k.on_side();
@@ -718,6 +726,8 @@ int encoder_bwd(const Ctx& k) {
 }
 
 }  // namespace
+
+extern "C" int vlt5_encoder_late_layers(int num_layers) { return num_layers > 1 ? enc_cut(num_layers) : num_layers; }
 
 // A stream of the LOWEST priority for vlt5_step.side_stream: the weight-gradient GEMMs then only take the workgroup slots the
 // input-gradient chain on the caller's (normal-priority) stream leaves free, instead of starving it.

@@ -538,7 +538,7 @@ class VLT5(nn.Module):
             # norms + visual embedding (released BEFORE the last weight-gradient GEMMs: their all-reduce hides under those),
             # then the lower half of the encoder -- the only group whose all-reduce stays exposed
             Ld, Le, nb = self.cfg.num_decoder_layers, self.cfg.num_layers, self._nbuckets
-            cut = Ld + 1 + (Le - Le // 2) if Le > 1 else Ld + 1
+            cut = Ld + 1 + (Le - lib().vlt5_encoder_late_layers(Le)) if Le > 1 else Ld + 1
             self.dp.reduce_range(self, events, Ld + 1, cut)
             self.dp.reduce_range(self, events, nb - 1, nb)
             self.dp.reduce_range(self, events, cut, nb - 1, final=True)
