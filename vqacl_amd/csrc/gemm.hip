@@ -427,26 +427,6 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
             if (s0 < nmain) glds(kt0 + s0, s0);
     }
     int stage = 0, fill = NSTAGE - 1;                      // stage of tile i, stage that tile i+NSTAGE-1 goes to
-    // Dropout epilogue: the keep bit of every output element this lane owns depends only on (seed, element index), so the hashes are
-    // evaluated HERE, while the first k-tiles are in flight and the wave would wait anyway, and kept as FM*FN*4 bits -- the
-    // epilogue, which sits on the serial tail of the workgroup, only tests them (the hash was ~5 us of a 256x256 launch's tail).
-    constexpr int NKW = (FM * FN * 4 + 31) / 32;
-    uint32_t keepw[NKW];
-#pragma unroll
-    for (int q = 0; q < NKW; ++q) keepw[q] = 0u;
-    if (p.drop_thr) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const uint32_t idx = (uint32_t)(m0 + wm * TM + i * 16 + (lane & 15)) * (uint32_t)p.N + (uint32_t)(n0 + wn * TN + j * 16 + (lane >> 4) * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int bit = (i * FN + j) * 4 + r;
-                    keepw[bit >> 5] |= (drop_keep(p.drop_seed, idx + r, p.drop_thr) ? 1u : 0u) << (bit & 31);
-                }
-            }
-    }
     TL(1);
     if constexpr (KM_STEP) {
         // branch-free steps (see the 8-wave loop below): the last NSTAGE-1 steps re-request the final k-tile, so the counted
@@ -704,11 +684,9 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                 }
                 if constexpr (kDrop) {
                     if (do_drop) {
+                        uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int bit = (i * FN + j) * 4 + r;
-                            v[r] = ((keepw[bit >> 5] >> (bit & 31)) & 1u) ? v[r] * dscale : 0.f;
-                        }
+                        for (int r = 0; r < 4; ++r) v[r] = drop_keep(p.drop_seed, idx + r, p.drop_thr) ? v[r] * dscale : 0.f;
                     }
                 }
                 if constexpr (kAux) { v[0] += aux[ii][j].x; v[1] += aux[ii][j].y; v[2] += aux[ii][j].z; v[3] += aux[ii][j].w; }
