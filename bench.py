@@ -183,7 +183,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # high-priority RCCL stream: the bucket all-reduces must start when their gradients are ready, not queue behind the
+        # backward GEMMs of the compute stream (measured with tools/dp_overlap_probe.py: at normal priority the casts of a
+        # bucket released mid-backward only ran after backward had finished)
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
 
     from oracle.ref_cpu import synthetic_batch, Cfg          # only the synthetic-input recipe and (rank 0) the cpu_baseline leg
     from vqacl_amd import VLT5VQA, VLT5Config, FusedAdamW, reference_param_groups

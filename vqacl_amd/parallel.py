@@ -50,7 +50,7 @@ class DataParallelVLT5:
                 ends[bucket] = max(ends.get(bucket, 0), off + n)
         self.bucket_end = [ends[b] for b in sorted(ends)]
         self.bucket_start = [0] + self.bucket_end[:-1]
-        self.comm_stream = torch.cuda.Stream() if model._flat.is_cuda else None
+        self.comm_stream = torch.cuda.Stream(priority=-1) if model._flat.is_cuda else None   # high priority: short casts + collectives must not queue behind the backward GEMMs
         self._events = None
         self._next = 0
         self._pending_from = 0
