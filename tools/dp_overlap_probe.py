@@ -25,8 +25,14 @@ marks = []
 orig = dp._allreduce_slice
 
 
+SIM_GBPS = float(os.environ.get("DP_SIM_GBPS", "0"))      # > 0: stand-in for the wire time of an N-GPU all-reduce at this algorithm
+CLOCK_HZ = 2.1e9                                          # bandwidth: a one-workgroup spin kernel on the comm stream per slice
+
+
 def spy(flat, a, b, **kw):
     orig(flat, a, b, **kw)
+    if SIM_GBPS > 0:
+        torch.cuda._sleep(int((b - a) * 2 / (SIM_GBPS * 1e9) * CLOCK_HZ))
     e = torch.cuda.Event(enable_timing=True)
     e.record()                      # on the comm stream (current inside reduce_range)
     marks.append((a, (b - a) * 2, e))
@@ -47,4 +53,14 @@ torch.cuda.synchronize()
 print(f"forward+backward {start.elapsed_time(end):.2f} ms")
 for a, nbytes, e in marks:
     print(f"slice @{a:>10d} {nbytes / 1e6:7.1f} MB (bf16)  done {e.elapsed_time(end) * -1:+.3f} ms relative to the end of backward+join")
+import time
+t0 = time.perf_counter()
+for it in range(20):
+    marks.clear()
+    dp.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
+    opt.step()
+    for p in model.parameters():
+        p.grad = None
+torch.cuda.synchronize()
+print(f"step {(time.perf_counter() - t0) / 20 * 1e3:.2f} ms   (DP_SIM_GBPS={SIM_GBPS})")
 dist.destroy_process_group()
