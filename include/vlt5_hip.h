@@ -50,6 +50,8 @@ typedef struct {
     int defer_reduce;                        /* split_k>1: leave the f32 slabs in `workspace` (slab s = partial sum of k-slice s) for
                                                 a consumer that sums them itself (vlt5_layernorm_bwd_slabs); C is not written */
     int split_used;                          /* out: the number of slabs actually written (<= split_k), 1 if not split */
+    void* c_bf16_copy;                       /* optional: plain f32 output (no epilogue option, no accum) is ALSO written rounded to bf16
+                                                here, same ldc / batch stride -- the staging copy of a data-parallel gradient bucket */
 } vlt5_gemm_desc;
 int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream);     /* writes d->split_used */
 long long vlt5_gemm_workspace_bytes(int M, int ldc, int split_k);
@@ -268,6 +270,10 @@ typedef struct {
      * main stream) and run beside the input-gradient chain; vlt5_encoder_bwd makes the main stream wait for it before it
      * returns, so the caller sees a single-stream contract.  side_events: >= 4 hipEvent_t owned by the caller.  NULL: one stream. */
     void* side_stream; void** side_events; int n_side_events;
+    /* optional bf16 mirror of `grads` (same element offsets): the backward phases write every weight gradient that a GEMM
+     * produces, and the relative-position tables, there as well, so a bf16 data-parallel all-reduce of the layer buckets needs no
+     * cast pass.  NOT covered (cast them): the last bucket (embeddings, norms, visual embedding). */
+    void* grads_bf16;
 } vlt5_step;
 
 /* ---- batch feed from a resident feature store (replaces the per-item HDF5 read + collate + H2D copy of

@@ -441,6 +441,10 @@ def test_data_parallel_overlap_path_on_one_gpu_and_rank_equivalence(dev):
         g2 = model2.flat_grads()
         assert cos(g2, g_plain) > 0.99999
         assert torch.allclose(g2, g_plain, rtol=1.0 / 128, atol=1e-6)
+        # the staging copy of every layer bucket is written by the weight-gradient GEMMs themselves (vlt5_step.grads_bf16), not by
+        # a cast pass: bit-identical to rounding the f32 gradients (one rank: the all-reduce leaves it as it is)
+        a = dp2.bucket_start[-1]
+        assert a > 0 and torch.equal(dp2._g16[:a].view(torch.int16), g_plain[:a].to(BF).view(torch.int16))
         # with the fused optimizer the cast back is deferred: the norm / AdamW kernels read the reduced bf16 buckets themselves.
         # Same weights, bit for bit, as casting back first; .grad keeps the local f32 gradients until flat_grads() is asked.
         from vqacl_amd import FusedAdamW, reference_param_groups

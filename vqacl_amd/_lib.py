@@ -24,7 +24,7 @@ class GemmDesc(C.Structure):
                 ("gate", vp), ("ldg", c_i), ("gate_scale", c_f), ("drop_p", c_f), ("drop_seed", c_u32),
                 ("relu", c_i), ("out_f32", c_i), ("accum", c_i), ("split_k", c_i), ("workspace", vp),
                 ("tile_m", c_i), ("tile_n", c_i), ("batch", c_i), ("batch_stride_a", c_ll), ("batch_stride_b", c_ll),
-                ("batch_stride_c", c_ll), ("defer_reduce", c_i), ("split_used", c_i)]
+                ("batch_stride_c", c_ll), ("defer_reduce", c_i), ("split_used", c_i), ("c_bf16_copy", vp)]
 
 
 class AttnDesc(C.Structure):
@@ -50,7 +50,7 @@ class Step(C.Structure):
                 ("enc_lut", vp), ("dec_lut", vp), ("gout", vp), ("d_loss_tok", vp), ("events", C.POINTER(vp)), ("n_events", c_i),
                 ("wait_events", C.POINTER(vp)), ("n_wait_events", c_i),
                 ("feat_store", vp), ("box_store", vp), ("feat_slots", vp), ("n_slots", c_ll),
-                ("side_stream", vp), ("side_events", C.POINTER(vp)), ("n_side_events", c_i)]
+                ("side_stream", vp), ("side_events", C.POINTER(vp)), ("n_side_events", c_i), ("grads_bf16", vp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/vlt5_hip.h

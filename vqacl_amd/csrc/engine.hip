@@ -321,9 +321,18 @@ struct Ctx {
         memset(&g, 0, sizeof g);
         g.A = dY; g.B = X; g.C = dW; g.M = N; g.N = K; g.K = M; g.lda = ldy; g.ldb = ldx; g.ldc = K;
         g.a_kmajor = 1; g.b_kmajor = 1; g.alpha = alpha; g.out_f32 = 1; g.accum = accum;
+        if (!accum) g.c_bf16_copy = g16(dW);
         int sk = pick_split(N, K, M);
         if (sk > 1) { g.split_k = sk; g.workspace = w<void>(p.slab); }
         return vlt5_gemm_bf16(&g, st);
+    }
+    // the bf16 mirror of a gradient tensor (vlt5_step.grads_bf16), or null
+    void* g16(const float* dW) const {
+        return s.grads_bf16 ? (void*)((bf16_t*)s.grads_bf16 + (dW - Gr)) : nullptr;
+    }
+    int mirror_small(long long off, long long n) const {       // gradients no GEMM writes (relative-position tables): cast them
+        if (!s.grads_bf16) return VLT5_OK;
+        return vlt5_cast_bf16(Gr + off, (bf16_t*)s.grads_bf16 + off, n, st);
     }
     // T5LayerNorm backward into the running residual gradient `dx`; `emit_next` additionally writes bf16(dropout(dx)) into
     // `next_dst` (the per-layer operand buffer of the sublayer processed next).  The weight gradient is left as per-workgroup partials in
@@ -354,6 +363,7 @@ struct Ctx {
         memset(&g, 0, sizeof g);
         g.A = w<void>(dy0); g.B = w<void>(x0); g.C = Gr + g0; g.M = N; g.N = K; g.K = M; g.lda = ldy; g.ldb = ldx; g.ldc = K;
         g.a_kmajor = 1; g.b_kmajor = 1; g.alpha = 1.f; g.out_f32 = 1;
+        g.c_bf16_copy = g16(Gr + g0);
         g.batch = layers;
         g.batch_stride_a = layers > 1 ? ((long long)dy1 - (long long)dy0) / 2 : 0;
         g.batch_stride_b = layers > 1 ? ((long long)x1 - (long long)x0) / 2 : 0;
@@ -619,6 +629,7 @@ int decoder_bwd(const Ctx& k) {
     }
     RC(vlt5_relbias_bwd(k.w<float>(p.dS_dec), s.dec_lut, k.Gr + L.dec_rel, k.w<float>(p.rel_scratch), Ld * B, k.H, T, T,
                         c.rel_buckets, 0, k.st));
+    RC(k.mirror_small(L.dec_rel, (long long)c.rel_buckets * k.H));
     // weight gradients of all decoder layers, one batched GEMM per weight kind, and of the stacked cross-attention K/V projection
     // -- on the side stream (if there is one) they run beside the rest of this phase and the first half of the encoder's chain
     RC(k.fork(0));
@@ -699,6 +710,7 @@ int encoder_bwd(const Ctx& k) {
     }
     RC(vlt5_relbias_bwd(k.w<float>(p.dS_enc), s.enc_lut, k.Gr + L.enc_rel, k.w<float>(p.rel_scratch), Le * B, k.H, s.L, s.L,
                         c.rel_buckets, 0, k.st));
+    RC(k.mirror_small(L.enc_rel, (long long)c.rel_buckets * k.H));
     // inputs: text rows -> shared (scatter-add), visual rows -> visual embedding parameters
     RC(vlt5_embed_bwd(s.input_ids, dx, (long long)S * d, d, k.Gr + L.shared, B, s.L, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, 0, k.st));
     float* vpart = k.w<float>(p.vis_partial);

@@ -54,6 +54,7 @@ struct GemmArgs {
     int relu, out_f32, accum;
     int ktiles_per_split; long long c_split_stride;
     long long batch_a, batch_b, batch_c;          // element strides between batch entries (blockIdx.z)
+    bf16_t* C2;                                   // optional bf16 copy of a plain f32 output (same indexing as C), or null
 };
 
 constexpr int BK = 64;
@@ -263,6 +264,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     const int nk_total = (p.K + BK - 1) / BK;
     int kt0 = 0, kt1 = nk_total;
     char* Cbase = reinterpret_cast<char*>(p.C) + (long long)blockIdx.z * p.batch_c * (p.out_f32 ? 4 : 2);
+    bf16_t* C2base = p.C2 ? p.C2 + (long long)blockIdx.z * p.batch_c : nullptr;
     p.A += (long long)blockIdx.z * p.batch_a;
     p.B += (long long)blockIdx.z * p.batch_b;
     if (p.resid) p.resid += (long long)blockIdx.z * p.batch_c;
@@ -589,9 +591,17 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                 float* crow = reinterpret_cast<float*>(Cbase) + (size_t)m * p.ldc + nb;
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    if (nb + j * 16 < p.N)
-                        *reinterpret_cast<float4*>(crow + j * 16) = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha,
-                                                                                acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
+                    if (nb + j * 16 < p.N) {
+                        const float4 o = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha,
+                                                     acc[i][j][3] * p.alpha);
+                        *reinterpret_cast<float4*>(crow + j * 16) = o;
+                        if (C2base) {          // the same values rounded to bf16: a data-parallel bucket's staging copy, no cast pass
+                            uint2 pk;
+                            pk.x = pack_bf16x2(o.x, o.y);
+                            pk.y = pack_bf16x2(o.z, o.w);
+                            *reinterpret_cast<uint2*>(C2base + (size_t)m * p.ldc + nb + j * 16) = pk;
+                        }
+                    }
             }
         } else {
 #pragma unroll
@@ -745,7 +755,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     gemm_body<BM, BN, WM, WN, AKM, BKM, NS>(p);
 }
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n,
-                                    int nslabs, long long stride, int accum) {
+                                    int nslabs, long long stride, int accum, bf16_t* __restrict__ out16) {
     long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
     float4 s = accum ? *reinterpret_cast<const float4*>(out + i) : make_float4(0, 0, 0, 0);
@@ -754,6 +764,12 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
         s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
     }
     *reinterpret_cast<float4*>(out + i) = s;
+    if (out16) {
+        uint2 pk;
+        pk.x = pack_bf16x2(s.x, s.y);
+        pk.y = pack_bf16x2(s.z, s.w);
+        *reinterpret_cast<uint2*>(out16 + i) = pk;
+    }
 }
 
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
@@ -808,6 +824,13 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
     a.drop_thr = d->drop_p > 0.f ? drop_thr16(d->drop_p) : 0u; a.drop_seed = d->drop_seed;
     a.relu = d->relu; a.out_f32 = d->out_f32; a.accum = d->accum;
     a.ktiles_per_split = 0; a.c_split_stride = 0;
+    a.C2 = nullptr;
+    if (d->c_bf16_copy) {
+        // plain f32 outputs only (the weight-gradient GEMMs): not accumulated, no fused epilogue, dense rows
+        if (!d->out_f32 || d->accum || d->bias || d->relu || d->gate || d->resid || d->drop_p > 0.f || d->defer_reduce) return VLT5_ERR_ARG;
+        if ((((uintptr_t)d->c_bf16_copy) & 7)) return VLT5_ERR_ALIGN;
+        a.C2 = (bf16_t*)d->c_bf16_copy;
+    }
     a.batch_a = d->batch_stride_a; a.batch_b = d->batch_stride_b; a.batch_c = d->batch_stride_c;
     const int batch = d->batch > 1 ? d->batch : 1;
     if (batch > 1 && (d->split_k > 1 || d->gate)) return VLT5_ERR_ARG;
@@ -845,6 +868,7 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         a.c_split_stride = (long long)d->M * d->ldc;
         a.C = d->workspace;
         a.accum = 0;
+        a.C2 = nullptr;                                    // the slab reduction writes the bf16 copy
     }
     int rc;
     if (bm == 256) rc = launch_tile<256, 256>(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
@@ -858,7 +882,7 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         long long n = (long long)d->M * d->ldc;
         int blocks = (int)((n / 4 + 255) / 256);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace,
-                           (float*)d->C, n, splits, n, d->accum);
+                           (float*)d->C, n, splits, n, d->accum, (bf16_t*)d->c_bf16_copy);
         LAUNCH_CHECK();
     }
     return VLT5_OK;

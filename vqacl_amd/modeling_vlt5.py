@@ -516,6 +516,11 @@ class VLT5(nn.Module):
             arr = (L.vp * len(events))(*[L.vp(e.cuda_event) for e in events])
             cs.events, cs.n_events = arr, len(events)
             keep = keep + (arr,)
+        mirrored = False
+        if events is not None and self.dp.grad_dtype is torch.bfloat16 and os.environ.get("VQACL_DP_MIRROR", "1") != "0":
+            # bf16 buckets: the weight-gradient GEMMs write the staging copy of every layer bucket themselves (no cast pass)
+            cs.grads_bf16 = ptr(self.dp.staging(target))
+            mirrored = True
         if self.side_stream_enabled:
             # the batched weight-gradient GEMMs run on a second stream beside the input-gradient chain; vlt5_encoder_bwd joins it
             if self._side is None:
@@ -531,7 +536,7 @@ class VLT5(nn.Module):
         stream = stream_ptr()
         check(lib().vlt5_decoder_bwd(C.byref(c), C.byref(cs), stream), "vlt5_decoder_bwd")
         if events is not None:
-            self.dp.reduce_range(self, events, 0, self.cfg.num_decoder_layers + 1)
+            self.dp.reduce_range(self, events, 0, self.cfg.num_decoder_layers + 1, mirrored=mirrored)
         check(lib().vlt5_encoder_bwd(C.byref(c), C.byref(cs), stream), "vlt5_encoder_bwd")
         if events is not None:
             # collectives are cut where the engine releases gradients: upper half of the encoder (mid-phase), then embeddings +
@@ -539,9 +544,9 @@ class VLT5(nn.Module):
             # then the lower half of the encoder -- the only group whose all-reduce stays exposed
             Ld, Le, nb = self.cfg.num_decoder_layers, self.cfg.num_layers, self._nbuckets
             cut = Ld + 1 + (Le - lib().vlt5_encoder_late_layers(Le)) if Le > 1 else Ld + 1
-            self.dp.reduce_range(self, events, Ld + 1, cut)
-            self.dp.reduce_range(self, events, nb - 1, nb)
-            self.dp.reduce_range(self, events, cut, nb - 1, final=True)
+            self.dp.reduce_range(self, events, Ld + 1, cut, mirrored=mirrored)
+            self.dp.reduce_range(self, events, nb - 1, nb)                      # embeddings / norms: no GEMM output, cast as before
+            self.dp.reduce_range(self, events, cut, nb - 1, final=True, mirrored=mirrored)
             self.dp.finish()
         elif self.dp is not None:
             self.dp.reduce_flat(target)

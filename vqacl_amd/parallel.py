@@ -87,14 +87,20 @@ class DataParallelVLT5:
         check(lib().vlt5_cast_f32(ptr(self._g16), ptr(flat), end, self.grad_scale, stream_ptr()), "vlt5_cast_f32")
         self.g16_valid = False
 
-    def _allreduce_slice(self, flat, a, b, defer=False):
+    def staging(self, flat):
+        """The bf16 mirror of the flat gradient buffer (same element offsets).  Zero-initialised once: alignment gaps are never
+        written and must reduce to zero."""
+        if self._g16 is None or self._g16.numel() < flat.numel():
+            self._g16 = torch.zeros(flat.numel(), device=flat.device, dtype=torch.bfloat16)
+        return self._g16
+
+    def _allreduce_slice(self, flat, a, b, defer=False, mirrored=False):
         t = flat[a:b]
         if self.grad_dtype is torch.bfloat16 and flat.is_cuda:
             from ._lib import check, lib, ptr, stream_ptr
-            if self._g16 is None or self._g16.numel() < flat.numel():
-                self._g16 = torch.empty(flat.numel(), device=flat.device, dtype=torch.bfloat16)
-            h = self._g16[a:b]
-            check(lib().vlt5_cast_bf16(ptr(t), ptr(h), b - a, stream_ptr()), "vlt5_cast_bf16")
+            h = self.staging(flat)[a:b]
+            if not mirrored:        # (mirrored: the engine's weight-gradient GEMMs wrote the bf16 copy themselves: vlt5_step.grads_bf16)
+                check(lib().vlt5_cast_bf16(ptr(t), ptr(h), b - a, stream_ptr()), "vlt5_cast_bf16")
             dist.all_reduce(h, group=self.group)
             if not defer:
                 check(lib().vlt5_cast_f32(ptr(h), ptr(t), b - a, self.grad_scale, stream_ptr()), "vlt5_cast_f32")
@@ -103,7 +109,7 @@ class DataParallelVLT5:
         if self.average:
             t.div_(self.world)
 
-    def reduce_range(self, model, events, lo, hi, final=False):
+    def reduce_range(self, model, events, lo, hi, final=False, mirrored=False):
         """Issue the all-reduces of buckets [lo, hi) on the comm stream: consecutive buckets are merged up to `bucket_bytes`, each
         merged slice goes after the event of its last bucket.  `final`: this call completes the gradient buffer."""
         flat = model._flat_grad
@@ -114,7 +120,7 @@ class DataParallelVLT5:
                 size = (self.bucket_end[b] - self.bucket_start[start]) * 4
                 if size >= self.bucket_bytes or b == hi - 1:
                     self.comm_stream.wait_event(events[b])
-                    self._allreduce_slice(flat, self.bucket_start[start], self.bucket_end[b], defer=defer)
+                    self._allreduce_slice(flat, self.bucket_start[start], self.bucket_end[b], defer=defer, mirrored=mirrored)
                     start = b + 1
         if final:
             self.g16_valid = defer
