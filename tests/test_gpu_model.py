@@ -615,3 +615,46 @@ def test_full_size_batch_properties(dev):
             assert torch.allclose(grads[1][n], 2 * grads[0][n], rtol=1e-4, atol=1e-7), n
         else:
             assert torch.equal(grads[1][n], 2 * grads[0][n]), n
+
+
+def test_data_parallel_bucket_math_on_deep_stack(dev):
+    """VL-T5-large depth (24 + 24 layers, narrow) through the overlapped RCCL path on one rank: 50 gradient buckets, merged slices,
+    the early embedding bucket, the bf16 mirror written by the weight-gradient GEMMs and the deferred cast-back must leave the
+    same weights as the plain single-process run (up to the bf16 rounding of the gradients)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from oracle import ref_cpu as R
+    from vqacl_amd import FusedAdamW, reference_param_groups
+    from vqacl_amd.parallel import DataParallelVLT5
+    ocfg = R.tiny_cfg(num_layers=24, num_decoder_layers=24)
+    params = R.init_params(ocfg, seed=21)
+    batch = R.synthetic_batch(ocfg, B=6, L=12, V=36, T=4, seed=9)
+
+    def run(wrap):
+        m = make_model(ocfg, params, dev, dropout=0.0)
+        m.train()
+        h = DataParallelVLT5(m, bucket_mb=0.2) if wrap else m
+        opt = FusedAdamW(reference_param_groups(m, 0.01), m, lr=1e-3, eps=1e-6, max_grad_norm=1.0)
+        for _ in range(3):
+            h.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
+            opt.step()
+            for p in m.parameters():
+                p.grad = None
+        torch.cuda.synchronize()
+        return m.flat_params().clone(), (h if wrap else None)
+
+    plain, _ = run(False)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        wrapped, dp = run(True)
+        assert len(dp.bucket_end) == 24 + 24 + 2 and dp.defer_cast_back and dp.grad_dtype is torch.bfloat16
+    finally:
+        dist.destroy_process_group()
+    assert cos(wrapped, plain) > 0.999999
+    assert float((wrapped - plain).abs().max()) < 5e-3            # three steps at lr 1e-3 bound any difference
