@@ -658,3 +658,28 @@ def test_data_parallel_bucket_math_on_deep_stack(dev):
         dist.destroy_process_group()
     assert cos(wrapped, plain) > 0.999999
     assert float((wrapped - plain).abs().max()) < 5e-3            # three steps at lr 1e-3 bound any difference
+
+
+def test_memory_loss_through_the_model_surface(dev):
+    """`memory=True` (modeling_t5_our.py:590-592 -> nextqa memory_loss): the two scalars the forward reports equal the
+    restatement evaluated on the model's own encoder states and the prototypes in force BEFORE the update of that step;
+    `train_step(..., memory=True)` returns the same record as without (the reference drops the memory terms, vqa_model.py:61-64)."""
+    from oracle import ref_cpu as R
+    ocfg = R.tiny_cfg()
+    params = R.init_params(ocfg, seed=31)
+    model = make_model(ocfg, params, dev)
+    model.train()
+    batch = R.synthetic_batch(ocfg, B=6, L=20, V=36, T=4, seed=12)
+    model.train_step(batch, 0, 0.5, 0.3)["loss"].backward()            # one step so the prototypes are non-trivial
+    for p in model.parameters():
+        p.grad = None
+    q_before, v_before = model.Q_prototype.clone().cpu(), model.V_prototype.clone().cpu()
+    out = model(input_ids=batch["input_ids"], vis_inputs=(batch["vis_feats"], batch["boxes"]), labels=batch["target_ids"],
+                cate_labels=batch["cate_labels"], ques_labels=batch["ques_labels"], proto_update=True, memory=True,
+                current_task_id=0, proto_alpha=0.5, proto_beta=0.3)
+    h = out["encoder_hidden_states"].float().cpu()
+    lq, lv = R.memory_loss(h[:, :20], h[:, 20:], batch["ques_labels"], batch["cate_labels"], q_before, v_before)
+    assert abs(float(out["loss_memory_Q"]) - float(lq)) <= 1e-4 * max(1.0, abs(float(lq)))
+    assert abs(float(out["loss_memory_V"]) - float(lv)) <= 1e-4 * max(1.0, abs(float(lv)))
+    res = model.train_step(batch, 0, 0.5, 0.3, memory=True)
+    assert set(res) == {"loss", "encoder_hidden_states", "BL", "encoder_attention_mask"} and res["loss"].requires_grad
