@@ -683,3 +683,23 @@ def test_memory_loss_through_the_model_surface(dev):
     assert abs(float(out["loss_memory_V"]) - float(lv)) <= 1e-4 * max(1.0, abs(float(lv)))
     res = model.train_step(batch, 0, 0.5, 0.3, memory=True)
     assert set(res) == {"loss", "encoder_hidden_states", "BL", "encoder_attention_mask"} and res["loss"].requires_grad
+
+
+@pytest.mark.parametrize("B,L,V,T", [(1, 5, 36, 2), (1, 20, 36, 10), (3, 1, 36, 1), (2, 20, 42, 10)])
+def test_extreme_batch_shapes_vs_oracle(dev, B, L, V, T):
+    """A single sample, a single question / answer token, the longest answer (10 tokens), and the largest sequence the attention
+    kernels take (L + V + 2 = 64): loss and every gradient against the CPU oracle."""
+    from oracle import ref_cpu as R
+    ocfg = R.tiny_cfg()
+    params = R.init_params(ocfg, seed=41)
+    batch = R.synthetic_batch(ocfg, B=B, L=L, V=V, T=T, seed=17 + B + L)
+    model = make_model(ocfg, params, dev)
+    model.train()
+    oracle = R.OracleModel(ocfg, params)
+    o = oracle.train_step(batch, 0, 0.5, 0.3, training=True)
+    o["loss"].backward()
+    res = model.train_step(batch, 0, 0.5, 0.3)
+    res["loss"].backward()
+    assert abs(float(res["loss"].detach()) - float(o["loss"].detach())) < 2e-2
+    assert rel_max_err(res["encoder_hidden_states"], o["encoder_hidden_states"]) < 3e-2
+    check_grads(model, {k: p.grad for k, p in oracle.P.items()}, min_cos=0.97)
