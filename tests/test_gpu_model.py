@@ -703,3 +703,17 @@ def test_extreme_batch_shapes_vs_oracle(dev, B, L, V, T):
     assert abs(float(res["loss"].detach()) - float(o["loss"].detach())) < 2e-2
     assert rel_max_err(res["encoder_hidden_states"], o["encoder_hidden_states"]) < 3e-2
     check_grads(model, {k: p.grad for k, p in oracle.P.items()}, min_cos=0.97)
+
+
+def test_out_of_range_shapes_fail_loudly(dev):
+    """Beyond what the on-chip attention tiles hold (L + V + 2 > 64 keys) the engine refuses instead of computing something."""
+    from oracle import ref_cpu as R
+    from vqacl_amd._lib import Vlt5Error
+    ocfg = R.tiny_cfg()
+    model = make_model(ocfg, R.init_params(ocfg, seed=43), dev)
+    model.train()
+    batch = R.synthetic_batch(ocfg, B=2, L=20, V=44, T=3, seed=2)             # 20 + 44 + 2 = 66
+    with pytest.raises(Vlt5Error):
+        model.train_step(batch, 0, 0.5, 0.3)
+    ok = R.synthetic_batch(ocfg, B=2, L=20, V=36, T=3, seed=2)                # the model is still usable afterwards
+    assert torch.isfinite(model.train_step(ok, 0, 0.5, 0.3)["loss"].detach()).item()
