@@ -717,3 +717,24 @@ def test_out_of_range_shapes_fail_loudly(dev):
         model.train_step(batch, 0, 0.5, 0.3)
     ok = R.synthetic_batch(ocfg, B=2, L=20, V=36, T=3, seed=2)                # the model is still usable afterwards
     assert torch.isfinite(model.train_step(ok, 0, 0.5, 0.3)["loss"].detach()).item()
+
+
+def test_degenerate_rows_vs_oracle(dev):
+    """A question that is all padding, an answer with no token to predict, a zero answer score: same loss and gradients as the
+    oracle (the masks and the per-sample normalisation of vqa_model.py:46-54 on their edge cases)."""
+    from oracle import ref_cpu as R
+    ocfg = R.tiny_cfg()
+    params = R.init_params(ocfg, seed=47)
+    batch = R.synthetic_batch(ocfg, B=5, L=12, V=36, T=4, seed=23)
+    batch["input_ids"][1, :] = 0
+    batch["target_ids"][2, :] = -100
+    batch["scores"][0] = 0.0
+    model = make_model(ocfg, params, dev)
+    model.train()
+    oracle = R.OracleModel(ocfg, params)
+    o = oracle.train_step(batch, 0, 0.5, 0.3, training=True)
+    o["loss"].backward()
+    res = model.train_step(batch, 0, 0.5, 0.3)
+    res["loss"].backward()
+    assert torch.isfinite(o["loss"].detach()) and abs(float(res["loss"].detach()) - float(o["loss"].detach())) < 2e-2
+    check_grads(model, {k: p.grad for k, p in oracle.P.items()}, min_cos=0.97)
