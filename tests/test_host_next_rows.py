@@ -241,3 +241,44 @@ def test_dual_level_schedule_order():
     assert g5["total_train_num"] == 24                                                    # doubled when the group has rehearsal data
     assert kinds.count("eval") == (5 + 4 + 4) * 2 and kinds.count("test") == 3
     assert float(tr.task_total_num[1]) == 60.0 and all(p.grad is None for p in model.parameters())
+
+
+def test_predict_evaluate_and_result_matrix():
+    """`Trainer.predict` / `evaluate` / the test pass (vqacl.py:527-631) over a stub model: answers keyed by question id, raw
+    accuracy + topk score, result matrix filled for the tasks trained so far only, then the continual metrics on it."""
+    from types import SimpleNamespace
+    from vqacl_amd.evaluate import VQAEvaluator, evaluate_metric
+    from vqacl_amd.loop import evaluate, predict, test_seen_tasks
+
+    class Stub:
+        def __init__(self, answers):
+            self.answers, self.mode = answers, None
+
+        def eval(self):
+            self.mode = "eval"
+
+        def test_step(self, batch):
+            return {"pred_ans": [self.answers[q] for q in batch["question_ids"]]}
+
+    def dataset(qids, truth):
+        id2datum = {q: {"label": {truth[q]: 1.0}} for q in qids}
+        gt = {q: {"answers": [{"answer": truth[q], "answer_id": k} for k in range(10)], "question_type": "what", "answer_type": "other"}
+              for q in qids}
+        return SimpleNamespace(id2datum=id2datum, id2datum_gt=gt)
+
+    truth = {q: ("yes" if q % 2 else "2 dogs") for q in range(12)}
+    model = Stub({q: ("yes" if q % 2 else ("Two dogs!" if q < 8 else "cat")) for q in range(12)})
+    loaders = {"q_recognition": [{"question_ids": [0, 1, 2]}, {"question_ids": [3, 4, 5]}], "q_location": [{"question_ids": [6, 7, 8, 9]}],
+               "q_judge": [{"question_ids": [10, 11]}]}
+    evals = {t: VQAEvaluator(dataset([q for b in l for q in b["question_ids"]], truth)) for t, l in loaders.items()}
+    got = predict(model, loaders["q_recognition"])
+    assert model.mode == "eval" and got == {q: model.answers[q] for q in range(6)}
+    acc = evaluate(model, loaders["q_location"], evals["q_location"])
+    assert acc["overall"] == 75.0 and acc["topk_score"] == 0.5          # "Two dogs!" normalises to "2 dogs": counted by the raw score, not by the exact-match topk score
+    tasks = ["q_recognition", "q_location", "q_judge"]
+    matrix = {}
+    test_seen_tasks(model, "q_recognition", tasks, {"q_recognition": 1, "q_location": 0, "q_judge": 0}, loaders, evals, matrix)
+    test_seen_tasks(model, "q_location", tasks, {"q_recognition": 1, "q_location": 1, "q_judge": 0}, loaders, evals, matrix)
+    assert matrix == {"q_recognition": {"q_recognition": 100.0}, "q_location": {"q_recognition": 100.0, "q_location": 75.0}}
+    m = evaluate_metric(matrix)
+    assert m["Avg_acc"] == 87.5 and m["Avg_forget"] == 0.0

@@ -91,6 +91,47 @@ def constant_schedule_with_warmup(optimizer, n_warmup):
     return torch.optim.lr_scheduler.LambdaLR(optimizer, lambda step: float(step) / float(max(1.0, n_warmup)) if step < n_warmup else 1.0)
 
 
+def predict(model, loader, group=None):
+    """`Trainer.predict` (vqacl.py:585-620): greedy answers of every batch of `loader` -> {question_id: answer}; under
+    torch.distributed the per-rank dicts are gathered and merged (the reference's `dist_utils.all_gather`), every rank returns the
+    union."""
+    import torch.distributed as dist
+    model.eval()
+    quesid2ans = {}
+    with torch.no_grad():
+        for batch in loader:
+            results = model.test_step(batch)
+            for qid, ans in zip(batch["question_ids"], results["pred_ans"]):
+                quesid2ans[qid] = ans
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        parts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(parts, quesid2ans, group=group)
+        quesid2ans = {}
+        for part in parts:
+            quesid2ans.update(part)
+    return quesid2ans
+
+
+def evaluate(model, loader, evaluator, group=None):
+    """`Trainer.evaluate` (vqacl.py:622-631): the evaluator's raw accuracies plus `topk_score`."""
+    quesid2ans = predict(model, loader, group)
+    acc = evaluator.evaluate_raw(quesid2ans)
+    acc["topk_score"] = evaluator.evaluate(quesid2ans) if quesid2ans else 0.0
+    return acc
+
+
+def test_seen_tasks(model, task, task_list, task_iftrain, test_loaders, evaluators, result_matrix, group=None):
+    """The test pass after task `task` (vqacl.py:527-582): every task trained so far is predicted and scored; the overall raw
+    accuracy goes into result_matrix[task][test_task] (the matrix `evaluate_metric` reads).  Stops at the first untrained task."""
+    result_matrix.setdefault(task, {})
+    for test_task in task_list:
+        if task_iftrain.get(test_task, 0) == 0:
+            break
+        acc = evaluators[test_task].evaluate_raw(predict(model, test_loaders[test_task], group))
+        result_matrix[task][test_task] = acc["overall"]
+    return result_matrix
+
+
 class ContinualTrainer:
     """Sequences the reference's `Trainer.train` over an engine-backed model.
 
