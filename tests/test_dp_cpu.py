@@ -65,6 +65,19 @@ def _worker(rank, world, port, q):
         (proto, cnt), = model.proto._allreduce_stats((local_proto, local_cnt))
         ref_proto, ref_cnt = R.calculate_current_prototype(pool_all.unsqueeze(1), onehot_all)
         assert torch.allclose(proto, ref_proto, atol=1e-6) and torch.equal(cnt, ref_cnt)
+
+        # evaluation: every rank predicts its shard of the questions, every rank ends up with the union (vqacl.py:585-620)
+        from vqacl_amd.loop import predict
+
+        class Stub:
+            def eval(self):
+                pass
+
+            def test_step(self, batch):
+                return {"pred_ans": [f"a{q}" for q in batch["question_ids"]]}
+        mine = [{"question_ids": [10 * rank + k for k in range(3)]}, {"question_ids": [10 * rank + 5]}]
+        merged = predict(Stub(), mine)
+        assert merged == {q: f"a{q}" for r in range(world) for q in [10 * r, 10 * r + 1, 10 * r + 2, 10 * r + 5]}
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
