@@ -215,3 +215,34 @@ def test_continual_trainer_over_engine_and_checkpoint_round_trip(dev, tmp_path):
     model.eval()
     fresh.eval()
     assert torch.equal(model.test_step(batch, max_length=5)["token_ids"], fresh.test_step(batch, max_length=5)["token_ids"])
+
+
+def test_predict_and_score_with_the_real_model(dev):
+    """`loop.predict` -> `VLT5VQA.test_step` (greedy decoding with the key/value cache, fed from the store) -> answers through a
+    tokenizer -> `VQAEvaluator`: the evaluation path of `Trainer.test` end to end on the tiny model."""
+    from types import SimpleNamespace
+    from vqacl_amd.evaluate import VQAEvaluator
+    from vqacl_amd.feed import FeatureStore, collate
+    from vqacl_amd.loop import evaluate, predict
+    ocfg, model = _tiny(dev)
+    g = torch.Generator().manual_seed(8)
+
+    class Tok:                                               # token id -> word; specials (pad 0, eos 1) dropped like skip_special_tokens
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return [" ".join(f"w{int(t)}" for t in row if int(t) > 1) for row in ids.tolist()]
+    model.tokenizer = Tok()
+    store = FeatureStore(8, n_boxes=36, feat_dim=ocfg.feat_dim, device=dev)
+    imgs = [f"im{k}" for k in range(8)]
+    store.put(imgs, torch.relu(torch.randn(8, 36, ocfg.feat_dim, generator=g)), torch.rand(8, 36, 4, generator=g).sort(-1).values)
+    items = [{"img_id": imgs[k % 8], "img_cate": k % 80, "question_id": 500 + k, "ques_label": 0, "sent": f"q{k}",
+              "input_ids": torch.randint(2, ocfg.vocab_size, (5 + k % 4,), generator=g), "input_length": 5 + k % 4} for k in range(10)]
+    loader = [collate(items[a:a + 4], store=store) for a in range(0, 10, 4)]
+    ans = predict(model, loader)
+    assert sorted(ans) == [500 + k for k in range(10)] and all(isinstance(a, str) for a in ans.values())
+    assert ans == predict(model, loader)                     # greedy decoding is deterministic
+    # score against "annotations" built from the model's own answers for half of the questions
+    gt = {q: {"answers": [{"answer": (a if q % 2 else "zzz"), "answer_id": i} for i in range(10)], "question_type": "t", "answer_type": "other"}
+          for q, a in ans.items()}
+    ds = SimpleNamespace(id2datum={q: {"label": {a: 1.0}} for q, a in ans.items()}, id2datum_gt=gt)
+    acc = evaluate(model, loader, VQAEvaluator(ds))
+    assert acc["overall"] == 50.0 and acc["topk_score"] == 1.0
