@@ -25,4 +25,5 @@ for f in files:
 subprocess.check_call(["make", "-C", os.path.join(work, "vqacl_amd", "csrc"), "-j8"])
 out = os.path.join(ROOT, "vqacl_amd", f"libvlt5_{tag}.so")
 shutil.copy(os.path.join(work, "vqacl_amd", "libvlt5_hip.so"), out)
+shutil.rmtree(work, ignore_errors=True)         # (build/ travels to the GPU box with every gpurun call)
 print(out)
