@@ -29,95 +29,86 @@ __device__ __forceinline__ void b_dma(const bf16_t* __restrict__ W, int n0, int 
     }
 }
 
+// Variant 2: A-stationary in REGISTERS.  A wave owns 16 rows and keeps their normalised bf16 MFMA fragments for the whole K = 768
+// (24 fragments = 96 VGPRs); LDS holds only weight tiles, 384 columns wide (3 stages x 48 KB).  Waves: 4 row blocks x 2 column halves.
+constexpr int NCW2 = 384;
+constexpr int B2_STAGE = NCW2 * 128;             // 48 KB
+__device__ __forceinline__ void b_dma2(const bf16_t* __restrict__ W, int n0, int kt, char* stage, int tid) {
+    const int wave_base = tid & ~63;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = tid + i * 512;
+        const int row = c >> 3, kc = (c & 7) ^ (row & 7);
+        __builtin_amdgcn_global_load_lds(W + (size_t)(n0 + row) * D + kt * 64 + kc * 8, (lds_ptr_t)(stage + (i * 512 + wave_base) * 16), 16, 0, 0);
+    }
+}
+
 __global__ __launch_bounds__(512) void ln_qkv_probe_kernel(const float* __restrict__ x, const float* __restrict__ lnw,
                                                            const bf16_t* __restrict__ W, bf16_t* __restrict__ out, float* __restrict__ rstd_out,
                                                            int S, int ncols_per_group, int ldo, float eps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* A = smem;
-    char* Bs = smem + A_BYTES;
+    char* Bs = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ngroups = gridDim.y;
     const int b = blockIdx.x, hg = blockIdx.y;
-    (void)ngroups;
-    // first weight tile in flight while the rows are normalised
-    const int ncol0 = hg * ncols_per_group;
-    b_dma(W, ncol0, 0, Bs, tid);
-    // ---- phase 1: RMS norm of rows wave, wave+8, ... into the A-panel (bf16, times the norm weight) ----
-    float4 wv[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) wv[k] = *reinterpret_cast<const float4*>(lnw + lane * 4 + k * 256);
-    for (int row = wave; row < ROWS; row += 8) {                 // (rows S..55 are zero filled)
-        float4 xv[3];
-        float ss = 0.f;
-        if (row < S) {
-            const float* xr = x + ((size_t)b * S + row) * D;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                xv[k] = *reinterpret_cast<const float4*>(xr + lane * 4 + k * 256);
-                ss += xv[k].x * xv[k].x + xv[k].y * xv[k].y + xv[k].z * xv[k].z + xv[k].w * xv[k].w;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        ss = wave_sum(ss);
-        const float rs = rsqrtf(ss / (float)D + eps);
-        if (lane == 0 && row < S && hg == 0 && rstd_out) rstd_out[(size_t)b * S + row] = rs;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int c = lane * 4 + k * 256;                      // column; k-tile c/64, 16-byte chunk (c%64)/8, 4 elements inside it
-            uint2 pk;
-            pk.x = pack_bf16x2(wv[k].x * (xv[k].x * rs), wv[k].y * (xv[k].y * rs));
-            pk.y = pack_bf16x2(wv[k].z * (xv[k].z * rs), wv[k].w * (xv[k].w * rs));
-            *reinterpret_cast<uint2*>(A + (c >> 6) * (ROWS * 128) + lds_off(row, (c & 63) >> 3) + (c & 7) * 2) = pk;
-        }
-    }
-    // ---- phase 2: out[b, :, ncol0 + ...] = A-panel x W[ncol0.., :]^T, 192 columns per pass, 12 k-tiles per pass ----
-    const int wm = wave >> 2, wn = wave & 3;                       // 2 x 4 waves: wave tile 32 rows x 48 columns
+    const int wr = wave & 3, wc = wave >> 2;                       // row block (16 rows), column half (192 of 384)
     const int lrow = lane & 15, lg = lane >> 4;
-    const int npass = ncols_per_group / NCW;
-    // ring: tile t (t = ps * KT + kt) lives in stage t % 3; tiles t+1 and t+2 are in flight while t is consumed
-    const int ntiles = npass * KT;
-    if (ntiles > 1) b_dma(W, ncol0 + (1 / KT) * NCW, 1 % KT, Bs + 1 * B_STAGE, tid);
+    const int ncol0 = hg * ncols_per_group;
+    const int npass = ncols_per_group / NCW2, ntiles = npass * KT;
+    b_dma2(W, ncol0, 0, Bs, tid);
+    if (ntiles > 1) b_dma2(W, ncol0 + (1 / KT) * NCW2, 1 % KT, Bs + B2_STAGE, tid);
+    // ---- phase 1: this wave's 16 rows, normalised, straight into MFMA A-fragment layout (lane: row lrow, k = 32*f + 8*lg .. +7) ----
+    const int row = wr * 16 + lrow;
+    const float* xr = x + ((size_t)b * S + (row < S ? row : 0)) * D;
+    float ss = 0.f;
+#pragma unroll
+    for (int f = 0; f < 24; ++f) {
+        const float4 p0 = *reinterpret_cast<const float4*>(xr + f * 32 + lg * 8), p1 = *reinterpret_cast<const float4*>(xr + f * 32 + lg * 8 + 4);
+        ss += p0.x * p0.x + p0.y * p0.y + p0.z * p0.z + p0.w * p0.w + p1.x * p1.x + p1.y * p1.y + p1.z * p1.z + p1.w * p1.w;
+    }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float rs = (row < S) ? rsqrtf(ss / (float)D + eps) : 0.f;       // rows beyond the sample: zero operand
+    if (lg == 0 && wc == 0 && hg == 0 && row < S && rstd_out) rstd_out[(size_t)b * S + row] = rs;
+    bf16x8_t fa[24];
+#pragma unroll
+    for (int f = 0; f < 24; ++f) {
+        const float4 p0 = *reinterpret_cast<const float4*>(xr + f * 32 + lg * 8), p1 = *reinterpret_cast<const float4*>(xr + f * 32 + lg * 8 + 4);
+        const float4 w0 = *reinterpret_cast<const float4*>(lnw + f * 32 + lg * 8), w1 = *reinterpret_cast<const float4*>(lnw + f * 32 + lg * 8 + 4);
+        union { uint32_t u[4]; bf16x8_t v; } r;
+        r.u[0] = pack_bf16x2(w0.x * (p0.x * rs), w0.y * (p0.y * rs)); r.u[1] = pack_bf16x2(w0.z * (p0.z * rs), w0.w * (p0.w * rs));
+        r.u[2] = pack_bf16x2(w1.x * (p1.x * rs), w1.y * (p1.y * rs)); r.u[3] = pack_bf16x2(w1.z * (p1.z * rs), w1.w * (p1.w * rs));
+        fa[f] = r.v;
+    }
+    // ---- phase 2: 384 columns per pass; tile t = ps*KT + kt in stage t % 3, tiles t+1, t+2 in flight ----
     int t = 0;
     for (int ps = 0; ps < npass; ++ps) {
-        f32x4_t acc[2][3];
+        f32x4_t acc[12];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 12; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < KT; ++kt, ++t) {
-            if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");     // tile t landed, tile t+1 may still fly
+            if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (t + 2 < ntiles) b_dma(W, ncol0 + ((t + 2) / KT) * NCW, (t + 2) % KT, Bs + ((t + 2) % NSTG) * B_STAGE, tid);
-            const char* at = A + kt * (ROWS * 128);
-            const char* bt = Bs + (t % NSTG) * B_STAGE;
+            if (t + 2 < ntiles) b_dma2(W, ncol0 + ((t + 2) / KT) * NCW2, (t + 2) % KT, Bs + ((t + 2) % 3) * B2_STAGE, tid);
+            const char* bt = Bs + (t % 3) * B2_STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8_t fa[2], fb[3];
+                bf16x8_t fb[12];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(at + lds_off(wm * 32 + i * 16 + lrow, ks * 4 + lg));
+                for (int j = 0; j < 12; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(bt + lds_off(wc * 192 + j * 16 + lrow, ks * 4 + lg));
 #pragma unroll
-                for (int j = 0; j < 3; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(bt + lds_off(wn * 48 + j * 16 + lrow, ks * 4 + lg));
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 12; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[kt * 2 + ks], acc[j], 0, 0, 0);
             }
         }
-        // epilogue of the pass: lane holds C[m][n..n+3], m = .. + lrow, n = .. + lg*4
+        if (row < S) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = wm * 32 + i * 16 + lrow;
-            if (m >= S) continue;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int n = ncol0 + ps * NCW + wn * 48 + j * 16 + lg * 4;
+            for (int j = 0; j < 12; ++j) {
+                const int n = ncol0 + ps * NCW2 + wc * 192 + j * 16 + lg * 4;
                 uint2 pk;
-                pk.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
-                pk.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
-                *reinterpret_cast<uint2*>(out + ((size_t)b * S + m) * ldo + n) = pk;
+                pk.x = pack_bf16x2(acc[j][0], acc[j][1]);
+                pk.y = pack_bf16x2(acc[j][2], acc[j][3]);
+                *reinterpret_cast<uint2*>(out + ((size_t)b * S + row) * ldo + n) = pk;
             }
         }
     }
@@ -128,8 +119,8 @@ __global__ __launch_bounds__(512) void ln_qkv_probe_kernel(const float* __restri
 // x f32 [B*S, 768]; lnw f32 [768]; W bf16 [ngroups*ncols_per_group, 768]; out bf16 [B*S, ldo]; rstd f32 [B*S] or null
 extern "C" int xp_ln_qkv(const float* x, const float* lnw, const void* W, void* out, float* rstd, int B, int S, int ngroups,
                          int ncols_per_group, int ldo, float eps, void* stream) {
-    if (!x || !lnw || !W || !out || S < 1 || S > ROWS || ncols_per_group % NCW) return 1001;
-    const size_t lds = A_BYTES + NSTG * B_STAGE;
+    if (!x || !lnw || !W || !out || S < 1 || S > 64 || ncols_per_group % NCW2) return 1001;
+    const size_t lds = 3 * B2_STAGE;
     static bool set = false;
     if (!set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_qkv_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
