@@ -309,6 +309,14 @@ enum { VLT5_WS_ENC_OUT = 0, VLT5_WS_ENC_EXT = 1, VLT5_WS_LOGITS = 2, VLT5_WS_LOS
        VLT5_WS_ENC_MASK_EXT = 5, VLT5_WS_DEC_OUT = 6 };
 long long vlt5_workspace_offset(const vlt5_config* c, int B, int L, int V, int T, int which);   /* byte offset, -1 = unknown */
 
+/* Phase entry points: each enqueues a whole phase of one train / eval step on `stream` from C++ (no host round trips).
+ * vlt5_encoder_fwd  = JointEncoder.forward (src/modeling_t5_our.py:175-339): token gather (:196), VisualEmbedding (:93-143),
+ *                     relative-position bias + masks (:225-273), the encoder T5Blocks (:282-293), final norm + dropout; leaves the
+ *                     encoder output (f32 and bf16, rows 0..S-1 of S+2 per sample) in the workspace for the prototype head.
+ * vlt5_decoder_fwd  = the rest of VLT5.forward (:618-713): _shift_right (:620), decoder T5Stack over the S+2 memory rows (:641-655),
+ *                     rescale + tied lm_head (:661-671), CrossEntropyLoss(ignore_index=-100, reduction='none') (:680-686) and, when
+ *                     s->scores is given, the per-sample reduction of src/vqa_model.py:46-54.
+ * vlt5_decoder_bwd / vlt5_encoder_bwd = loss.backward() (src/vqacl.py:461) through the same two halves, gradients into s->grads. */
 int vlt5_encoder_fwd(const vlt5_config* c, const vlt5_step* s, void* stream);
 int vlt5_decoder_fwd(const vlt5_config* c, const vlt5_step* s, void* stream);
 /* One greedy-decoding step with a key/value cache (replaces HF generate -> VLT5.forward(decoder_input_ids[:, -1:],
