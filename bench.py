@@ -3,15 +3,22 @@
 
 One "step" = VLT5VQA.train_step forward + backward + clip_grad_norm(5) + AdamW on one synthetic batch of 80 samples
 per GPU (BASELINE.json configs[1]; batch 80 is what the reference's launch scripts use), dropout 0.1 ON, bf16 MFMA
-compute with fp32 accumulation / fp32 master weights, inputs already resident in HBM.
+compute with fp32 accumulation / fp32 master weights.
+
+The timed loop is the designed feed path: the region features of 4096 synthetic images are resident in HBM
+(bf16 feature store) before the timed region starts, and EVERY step draws a fresh random batch of 80 of them -- only token ids,
+labels, scores and the 80 slot indices come from the host, as the reference's collate_fn would hand them over.  Side values
+(never `value`): the same step re-fed from one device-resident f32 batch, and the PCIe-inclusive step (pinned host f32 batch).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0): metric/value (whole-job samples/s), roofline of the dominant kernel (HIP-event timed
-inside this process) and the CPU baseline (the oracle restatement timed on the host cores, bounded sample).
+Prints ONE JSON line (rank 0): metric/value (whole-job samples/s), `roofline` of the dominant kernel family (every GEMM
+dispatch of real train steps timed in situ with HIP events attached to the dispatch), `parity` of the benched configuration
+against the CPU oracle, and `cpu_baseline` (the oracle timed on the host cores, bounded sample).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -26,11 +33,42 @@ sys.path.insert(0, ROOT)
 
 FWD_BWD_GFLOP_PER_SAMPLE = 37.90          # 2*M*N*K per GEMM/bmm, L=20 V=36 T=5
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+N_QUES, N_CATE, VOCAB, FEAT_DIM = 10, 80, 32200, 2048
+
+
+def synthetic_batch(B, L=20, V=36, T=5, seed=66666, task_id=0, cate_group=0, with_feats=True):
+    """Synthetic batch of SURVEY 8(d) in the reference's collate_fn schema: non-negative sparse-ish region features
+    (relu(N(0,1)) * 1.5), sorted box corners in [0,1], ragged questions (pad 0, row 0 forced to the full length so S = L + V),
+    ragged answers ending in EOS = 1 (pad -100), one-hot task / category labels, answer scores out of {0.3, 0.6, 0.9, 1.0}."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    if with_feats:
+        out["vis_feats"] = torch.relu(torch.randn(B, V, FEAT_DIM, generator=g)) * 1.5
+        xs = torch.rand(B, V, 2, generator=g).sort(dim=2).values
+        ys = torch.rand(B, V, 2, generator=g).sort(dim=2).values
+        out["boxes"] = torch.stack([xs[..., 0], ys[..., 0], xs[..., 1], ys[..., 1]], dim=2)
+    ids = torch.randint(2, 32000, (B, L), generator=g)
+    lens = torch.randint(min(6, L), L + 1, (B,), generator=g)
+    lens[0] = L
+    out["input_ids"] = ids * (torch.arange(L)[None, :] < lens[:, None])
+    tgt = torch.randint(2, 32000, (B, T), generator=g)
+    tl = torch.randint(2, T + 1, (B,), generator=g)
+    tl[0] = T
+    pos = torch.arange(T)[None, :]
+    tgt = torch.where(pos == (tl[:, None] - 1), torch.ones_like(tgt), tgt)
+    out["target_ids"] = torch.where(pos < tl[:, None], tgt, torch.full_like(tgt, -100))
+    out["ques_labels"] = torch.zeros(B, N_QUES)
+    out["ques_labels"][:, task_id] = 1
+    cate_ids = cate_group * 16 + torch.randint(0, 16, (B,), generator=g)
+    out["cate_labels"] = torch.zeros(B, N_CATE).scatter_(1, cate_ids[:, None] % N_CATE, 1.0)
+    out["scores"] = torch.tensor([0.3, 0.6, 0.9, 1.0])[torch.randint(0, 4, (B,), generator=g)]
+    return out
 
 
 def gemm_schedule(cfg, B, L, V, T):
     """Every GEMM launch of one train step as (count, batch, M, N, K, a_kmajor, b_kmajor, out_f32): mirrors csrc/engine.hip
-    (the weight-gradient GEMMs of all layers of a stack run as one batched launch per weight kind)."""
+    (the weight-gradient GEMMs of all layers of a stack run as one batched launch per weight kind).  Only used by the
+    warm-replay side figure (`frac_warm`)."""
     d, inner, ff, Le, Ld, vocab, fd = cfg.d_model, cfg.num_heads * cfg.d_kv, cfg.d_ff, cfg.num_layers, cfg.num_decoder_layers, cfg.vocab_size, cfg.feat_dim
     S, Sx = L + V, L + V + 2
     M, Mx, Md = B * S, B * Sx, B * T
@@ -60,25 +98,21 @@ def gemm_schedule(cfg, B, L, V, T):
     return sch
 
 
-def time_gemms(cfg, B, L, V, T, dev, reps=20):
-    """HIP-event timing of each distinct GEMM launch of the step on the current stream (same tile / split-K / batching
-    policy as the engine)."""
+def time_gemms_warm(cfg, B, L, V, T, dev, reps=20):
+    """Warm replay: each distinct GEMM shape of the step launched `reps` times back to back on the same operands (L2/MALL warm).
+    An upper bound of what the kernels do in situ; reported as `frac_warm`, never as `frac`."""
     from vqacl_amd import ops
-    from vqacl_amd._lib import lib
+    from vqacl_amd._lib import lib, stream_ptr
     BF = torch.bfloat16
-    rows = []
+    tot_ms = tot_gflop = 0.0
     slab = 8 * max(cfg.d_ff, 3 * cfg.num_heads * cfg.d_kv) * cfg.d_model * 4
     for count, batch, M, N, K, akm, bkm, of32 in gemm_schedule(cfg, B, L, V, T):
         A = torch.randn((batch, K, M) if akm else (batch, M, K), device=dev).to(BF)
         Bm = torch.randn((batch, K, N) if bkm else (batch, N, K), device=dev).to(BF)
         out = torch.empty(batch, M, N, device=dev, dtype=torch.float32 if of32 else BF)
         sk = lib().vlt5_gemm_auto_split(M, N, K, slab) if (of32 and bkm and batch == 1) else 1
-        kw = dict(a_kmajor=bool(akm), b_kmajor=bool(bkm), out=out[0], split_k=sk, batch=batch,
-                  batch_strides=(A.stride(0), Bm.stride(0), out.stride(0)))
-        # descriptor built once, the loop only launches: a 400-row decoder GEMM is 6-8 us, a Python-side descriptor build is more
-        import ctypes as C
-        from vqacl_amd._lib import stream_ptr
-        g, _, keep = ops.gemm_desc(A[0], Bm[0], M, N, K, **kw)
+        g, _, keep = ops.gemm_desc(A[0], Bm[0], M, N, K, a_kmajor=bool(akm), b_kmajor=bool(bkm), out=out[0], split_k=sk, batch=batch,
+                                   batch_strides=(A.stride(0), Bm.stride(0), out.stride(0)))
         fn, gp, sp = lib().vlt5_gemm_bf16, C.byref(g), stream_ptr()
         for _ in range(2):
             assert fn(gp, sp) == 0
@@ -88,10 +122,119 @@ def time_gemms(cfg, B, L, V, T, dev, reps=20):
             fn(gp, sp)
         e1.record()
         e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        rows.append(dict(count=count, batch=batch, M=M, N=N, K=K, akm=akm, bkm=bkm, ms=ms, gflop=2.0 * batch * M * N * K / 1e9))
+        tot_ms += count * e0.elapsed_time(e1) / reps
+        tot_gflop += count * 2.0 * batch * M * N * K / 1e9
         del A, Bm, out
-    return rows
+    return tot_gflop / tot_ms, tot_ms
+
+
+def insitu_gemm_roofline(step_fn, n_steps):
+    """Every gemm_kernel dispatch of `n_steps` REAL train steps (fresh store-fed batches, dropout on, optimizer included) timed
+    with HIP events attached to the dispatch (vlt5_gemm_timing_*): achieved = sum of 2*M*N*K*batch / sum of the kernels' durations."""
+    from vqacl_amd._lib import GemmTimingRec, lib
+    cap = 1024 * n_steps
+    assert lib().vlt5_gemm_timing_enable(cap) == 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_steps):
+        step_fn(i)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / n_steps * 1e3
+    recs = (GemmTimingRec * cap)()
+    n = lib().vlt5_gemm_timing_collect(recs, cap)
+    lib().vlt5_gemm_timing_enable(0)
+    assert 0 < n <= cap, n
+    by = {}
+    tot_ms = tot_gflop = 0.0
+    for r in recs[:n]:
+        gf = 2.0 * r.batch * r.M * r.N * r.K / 1e9
+        tot_ms += r.ms
+        tot_gflop += gf
+        key = (f"gemm_kernel<{r.tile_m},{r.tile_n},{'km' if r.a_kmajor else 'rm'},{'km' if r.b_kmajor else 'rm'}>")
+        k = by.setdefault(key, [0, 0.0, 0.0])
+        k[0] += 1
+        k[1] += r.ms
+        k[2] += gf
+    launches = n / n_steps
+    achieved = tot_gflop / tot_ms                       # GFLOP/ms == TFLOP/s
+    per_kernel = {k: dict(calls_per_step=round(v[0] / n_steps, 1), avg_us=round(v[1] / v[0] * 1e3, 2), ms_per_step=round(v[1] / n_steps, 3),
+                          tflops=round(v[2] / v[1], 1)) for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
+    return dict(bound="mfma", kernel="gemm_kernel<BM,BN,AKM,BKM> (all instantiations, in situ)", achieved=round(achieved, 2),
+                peak=MFMA_BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), traffic=None,
+                launches_per_step=round(launches, 1), avg_launch_us=round(tot_ms / n * 1e3, 2),
+                gflop_per_launch=round(tot_gflop / n, 3), gemm_ms_per_step=round(tot_ms / n_steps, 3),
+                timed_steps=n_steps, ms_per_step_while_timed=round(wall_ms, 3), per_kernel=per_kernel)
+
+
+def parity_vs_oracle(model, dev, B):
+    """Parity figure of the BENCHED configuration (VL-T5-base, B = 80 launch shapes, current weights) against the fp32 CPU oracle:
+    forward of the whole batch with dropout off, compared on 4 of the 80 samples (per-sample independence of the path is proven
+    bit-exact by tests/test_gpu_model.py::test_full_size_batch_properties); gradients from a B = 4 step of the same weights."""
+    from oracle import ref_cpu as R
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+    ocfg = R.Cfg(dropout=0.0)
+    batch = synthetic_batch(B, seed=424242)
+    pick = [0, 1, B // 2, B - 1]
+    sub = {k: v[pick] for k, v in batch.items()}
+    params = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items() if k in R.param_shapes(ocfg)}
+    Qp, Vp = model.Q_prototype.detach().cpu().clone(), model.V_prototype.detach().cpu().clone()
+    was_training, p_drop = model.training, model.cfg.dropout_rate
+    model.cfg.dropout_rate = 0.0
+    model.train()
+    try:
+        out = model(input_ids=batch["input_ids"], vis_inputs=(batch["vis_feats"], batch["boxes"]), labels=batch["target_ids"],
+                    proto_update=False)
+        logits = out["logits"][pick].float().cpu()
+        loss_tok = out["loss"].detach().view(B, -1)[pick].float().cpu()
+        idx = (out["max_idx_Q"].cpu()[pick], out["max_idx_V"].cpu()[pick])
+        oracle = R.OracleModel(ocfg, params)
+        oracle.state.Q_prototype, oracle.state.V_prototype = Qp.clone(), Vp.clone()
+        o = R.vlt5_forward(oracle.P, oracle.state, ocfg, input_ids=sub["input_ids"], vis_feats=sub["vis_feats"], boxes=sub["boxes"],
+                           labels=sub["target_ids"], proto_update=False, training=False)
+        ol = o["logits"].detach()
+        res = dict(samples=pick, logits_rel_max_err=float((logits - ol).abs().max() / ol.abs().max()),
+                   loss_tok_abs_err=float((loss_tok.flatten() - o["loss"].detach()).abs().max()))
+        # integer outputs: retrieved prototype indices, exact wherever the oracle's top-2 cosine margin exceeds 1e-2
+        h = o["encoder_hidden_states"].detach()
+        exact, gated = 0, 0
+        for protos, pooled, mine, ref in ((Qp, h[:, :20].mean(1), idx[0], o["max_idx_Q"]), (Vp, h[:, 20:].mean(1), idx[1], o["max_idx_V"])):
+            a = torch.nn.functional.normalize(torch.tanh(protos), dim=1)
+            b = torch.nn.functional.normalize(torch.tanh(pooled), dim=1)
+            top = (b @ a.t()).topk(2, dim=1).values
+            ok = (top[:, 0] - top[:, 1]) > 1e-2
+            gated += int(ok.sum())
+            exact += int((mine[ok] == ref[ok]).sum())
+        res["proto_idx_checked"], res["proto_idx_equal"] = gated, exact
+        # gradients: the same 4 samples as a B = 4 step (fused train_step reduction, dropout off, prototypes retrieved but not
+        # updated so that both sides see the same state) against the oracle's backward of the forward above
+        for p in model.parameters():
+            p.grad = None
+        r = model(input_ids=sub["input_ids"], vis_inputs=(sub["vis_feats"], sub["boxes"]), labels=sub["target_ids"],
+                  proto_update=False, scores=sub["scores"])
+        r["loss_reduced"].backward()
+        lo = R.train_step_loss(o["loss"], sub["target_ids"], sub["scores"])
+        lo.backward()
+        res["loss_abs_err"] = abs(float(r["loss_reduced"]) - float(lo))
+        worst, worst_name = 1.0, None
+        named = dict(model.named_parameters())
+        for k, p in oracle.P.items():
+            if p.grad is None or k not in named or named[k].grad is None or float(p.grad.abs().max()) < 1e-10:
+                continue
+            a, b = named[k].grad.float().cpu().flatten(), p.grad.flatten()
+            c = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp(min=1e-30))
+            if c < worst:
+                worst, worst_name = c, k
+        res["worst_grad_cos"], res["worst_grad_tensor"] = round(worst, 5), worst_name
+        res["logits_rel_max_err"] = round(res["logits_rel_max_err"], 5)
+        res["loss_tok_abs_err"] = round(res["loss_tok_abs_err"], 5)
+        res["loss_abs_err"] = round(res["loss_abs_err"], 6)
+        res["tolerance"] = "logits 3e-2 rel, loss 2e-2 abs, grad cos >= 0.97, indices exact where the top-2 margin > 1e-2"
+        return res
+    finally:
+        for p in model.parameters():
+            p.grad = None
+        model.cfg.dropout_rate = p_drop
+        model.train(was_training)
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -107,7 +250,7 @@ def cpu_baseline(seconds_budget=25.0):
     Bc = 8
     model = R.OracleModel(cfg, seed=0)
     opt = R.HFAdamW(model.used, lr=1e-4, eps=1e-6, weight_decay=0.01)
-    batch = R.synthetic_batch(cfg, B=Bc, L=20, V=36, T=5, seed=66666)
+    batch = synthetic_batch(Bc, seed=66666)
     times = []
     t_start = time.time()
     for it in range(3):
@@ -132,7 +275,7 @@ def eager_gpu_baseline(dev, B=80, steps=5):
     from oracle import ref_cpu as R
     cfg = R.Cfg(dropout=0.1)
     params = {k: v.to(dev) for k, v in R.init_params(cfg, seed=0).items()}
-    batch = {k: v.to(dev) for k, v in R.synthetic_batch(cfg, B=B, L=20, V=36, T=5, seed=66666).items()}
+    batch = {k: v.to(dev) for k, v in synthetic_batch(B, seed=66666).items()}
     out = {}
     torch.set_default_device(dev)                 # the restatement builds its index tensors with default-device factories
     try:
@@ -167,10 +310,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=80)
+    ap.add_argument("--store-images", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-side-values", action="store_true", help="skip the resident-batch / PCIe / feed-kernel / warm-replay side figures")
     ap.add_argument("--eager-baseline", action="store_true", help="also time the torch-eager restatement on the GPU (SURVEY 8d)")
     ap.add_argument("--overlap-optimizer", action="store_true", help="run the optimizer update on a second stream (see FusedAdamW)")
+    ap.add_argument("--dp-algo", default=os.environ.get("VQACL_DP_ALGO", "auto"), help="gradient exchange of the DP wrapper (parallel.py)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,48 +330,68 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        # high-priority RCCL stream: the bucket all-reduces must start when their gradients are ready, not queue behind the
+        # high-priority RCCL stream: the bucket collectives must start when their gradients are ready, not queue behind the
         # backward GEMMs of the compute stream (measured with tools/dp_overlap_probe.py: at normal priority the casts of a
         # bucket released mid-backward only ran after backward had finished)
         opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
 
-    from oracle.ref_cpu import synthetic_batch, Cfg          # only the synthetic-input recipe and (rank 0) the cpu_baseline leg
     from vqacl_amd import VLT5VQA, VLT5Config, FusedAdamW, reference_param_groups
+    from vqacl_amd.feed import FeatureStore
     cfg = VLT5Config(dropout_rate=0.1)
     torch.manual_seed(66666)
     model = VLT5VQA(cfg, device=dev)
     model.train()
     handle = model
+    dp_info = None
     if distributed:
         from vqacl_amd.parallel import DataParallelVLT5
-        handle = DataParallelVLT5(model)
+        handle = DataParallelVLT5(model, algo=args.dp_algo)
     # --overlap-optimizer: the update of step n runs on a second stream under the forward of step n+1 (still inside the
     # timed region: the final synchronisation waits for every stream).  Measured 2 % SLOWER on MI355X (the 6.7 GB update
     # stream evicts the forward's operands from L2/MALL), so it is off by default.
-    opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-4, eps=1e-6, max_grad_norm=5.0,
+    opt = FusedAdamW(reference_param_groups(model, 0.01), handle, lr=1e-4, eps=1e-6, max_grad_norm=5.0,
                      overlap=args.overlap_optimizer)
+    if distributed:
+        dp_info = handle.describe()
     B, L, V, T = args.batch, 20, 36, 5
-    batch = synthetic_batch(Cfg(), B=B, L=L, V=V, T=T, seed=66666 + rank, task_id=0)
-    batch = {k: v.to(dev) for k, v in batch.items()}          # inputs resident in HBM before the timed region
 
-    def step():
-        res = handle.train_step(batch, 0, 0.5, 0.3)
+    # ---- the feed: region features resident in HBM (bf16 store) before anything is timed -----------------------------------
+    n_img = args.store_images
+    store = FeatureStore(n_img, n_boxes=V, feat_dim=cfg.feat_dim, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(66666 + rank)
+    for a in range(0, n_img, 256):
+        store.put(list(range(a, a + 256)), torch.relu(torch.randn(256, V, cfg.feat_dim, device=dev, generator=gen)) * 1.5,
+                  torch.rand(256, V, 4, device=dev, generator=gen).sort(-1).values)
+    n_total = args.warmup + args.steps
+    hg = torch.Generator().manual_seed(1234 + rank)
+    # one host-side batch per step, as the loader would hand it over: pinned small tensors + the image ids of a fresh draw
+    feeds = []
+    for i in range(n_total + 16):
+        small = synthetic_batch(B, L, V, T, seed=66666 + 1000 * rank + i, with_feats=False)
+        small = {k: v.pin_memory() for k, v in small.items()}
+        small["img_ids"] = torch.randint(0, n_img, (B,), generator=hg).tolist()
+        feeds.append(small)
+
+    def step_store(i):
+        fed = {k: v for k, v in feeds[i].items() if k != "img_ids"}
+        fed["feat_ref"] = store.ref(feeds[i]["img_ids"])
+        res = handle.train_step(fed, 0, 0.5, 0.3)
         res["loss"].backward()
         opt.step()
         for p in model.parameters():
             p.grad = None
         return res["loss"]
 
-    for _ in range(args.warmup):
-        loss = step()
+    for i in range(args.warmup):
+        loss = step_store(i)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    for i in range(args.warmup, n_total):
+        loss = step_store(i)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -242,61 +409,49 @@ def main():
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "VL-T5-base VQA v2 train step (fwd+bwd+clip+AdamW), 36x2048 regions, 20 question tokens, "
-                                  "5 answer tokens, dropout 0.1", "batch_per_gpu": B, "global_batch": B * world,
-                      "parallelism": f"dp{world}",
-                      "grad_allreduce": (str(handle.grad_dtype).replace("torch.", "") if distributed else "none")},
+                                  "5 answer tokens, dropout 0.1; batch drawn fresh every step from an HBM-resident bf16 feature store",
+                      "batch_per_gpu": B, "global_batch": B * world, "store_images": n_img, "parallelism": f"dp{world}",
+                      "grad_exchange": (dp_info if distributed else "none")},
            "samples_per_sec_per_gpu": round(value / world, 2), "final_loss": round(final_loss, 4),
            "step_tflops_per_gpu": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms, 2),
            "step_frac_of_mfma_peak": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
-    if rank == 0 and world == 1 and not distributed:
-        # PCIe-inclusive rate (never `value`): the boundary normally hands over pinned HOST tensors (collate_fn output);
-        # train_step then copies 23.6 MB of fp32 region features per batch of 80 before the engine starts.
-        host = {k: v.cpu().pin_memory() for k, v in batch.items()}
+    if distributed:
+        out["rccl_ranks_seen"] = dist.get_world_size()
+    solo = rank == 0 and world == 1 and not distributed
 
-        def step_host():
-            res = handle.train_step(host, 0, 0.5, 0.3)
+    if solo and not args.no_roofline:
+        # in-situ roofline of the dominant kernel family: real steps, every GEMM dispatch timed
+        out["roofline"] = insitu_gemm_roofline(lambda i: step_store(n_total + i), 8)
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_hbm_traffic.json")))
+        if pmcs:          # HBM bytes per GEMM launch from the committed PMC passes of THIS round's build (tagged; not measured in this run)
+            g = [r for r in json.load(open(pmcs[-1])) if "gemm_kernel" in r["kernel"]]
+            if g:
+                out["roofline"]["traffic"] = round(sum(r["calls"] * r["hbm_mb"] for r in g) / sum(r["calls"] for r in g) * 1e6)
+                out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(pmcs[-1])} (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"
+
+    if solo and not args.no_side_values:
+        resident = {k: v.to(dev) for k, v in synthetic_batch(B, L, V, T, seed=66666).items()}
+
+        def step_batch(b):
+            res = handle.train_step(b, 0, 0.5, 0.3)
             res["loss"].backward()
             opt.step()
             for p in model.parameters():
                 p.grad = None
-        for _ in range(2):
-            step_host()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            step_host()
-        torch.cuda.synchronize()
-        out["samples_per_sec_pcie_inclusive"] = round(5 * B / (time.perf_counter() - t1), 2)
-        # f-2 feed: the same step fed from the HBM-resident bf16 feature store (vqacl_amd/feed.py): a fresh random draw of
-        # 80 images out of 4096 per step, only ids / labels / slot indices come from the host.  Also never `value`.
-        from vqacl_amd.feed import FeatureStore
-        n_img = 4096
-        store = FeatureStore(n_img, n_boxes=V, feat_dim=cfg.feat_dim, device=dev)
-        for a in range(0, n_img, 256):
-            store.put(list(range(a, a + 256)), torch.relu(torch.randn(256, V, cfg.feat_dim, device=dev)) * 1.5,
-                      torch.rand(256, V, 4, device=dev).sort(-1).values)
-        small = {k: v for k, v in host.items() if k not in ("vis_feats", "boxes")}
-        draws = [torch.randint(0, n_img, (B,)).tolist() for _ in range(8)]
-
-        def step_store(i):
-            fed = dict(small)
-            fed["feat_ref"] = store.ref(draws[i % 8])
-            res = handle.train_step(fed, 0, 0.5, 0.3)
-            res["loss"].backward()
-            opt.step()
-            for p in model.parameters():
-                p.grad = None
-        for i in range(2):
-            step_store(i)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(8):
-            step_store(i)
-        torch.cuda.synchronize()
-        out["samples_per_sec_store_feed"] = round(8 * B / (time.perf_counter() - t1), 2)
+        for tag, b, n in (("samples_per_sec_resident_batch", resident, 10),
+                          ("samples_per_sec_pcie_inclusive", {k: v.cpu().pin_memory() for k, v in resident.items()}, 5)):
+            for _ in range(2):
+                step_batch(b)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                step_batch(b)
+            torch.cuda.synchronize()
+            out[tag] = round(n * B / (time.perf_counter() - t1), 2)
         # the gather kernel against the HBM roofline: algorithmic bytes = rows read + rows written (bf16 features + f32 boxes)
-        slots = store.slots(draws[0])
         from vqacl_amd._lib import lib, ptr, stream_ptr
+        slots = store.slots(feeds[0]["img_ids"])
         of = torch.empty(B, V, cfg.feat_dim, dtype=torch.bfloat16, device=dev)
         ob = torch.empty(B, V, 4, device=dev)
         gargs = (ptr(store.feats), ptr(store.boxes), ptr(slots), store.capacity, ptr(of), ptr(ob), B, V, cfg.feat_dim, stream_ptr())
@@ -315,36 +470,16 @@ def main():
                        "achieved": round(gbytes / (us * 1e-6), 1), "peak": 8000.0, "unit": "GB/s",
                        "frac": round(gbytes / (us * 1e-6) / 8000.0, 4), "store_images": n_img,
                        "store_gb": round(n_img * V * (cfg.feat_dim * 2 + 16) / 1e9, 3)}
-        del store
-    if rank == 0 and world == 1 and not distributed and not args.no_roofline:
-        rows = time_gemms(cfg, B, L, V, T, dev)
-        launches = sum(r["count"] for r in rows)
-        tot_ms = sum(r["count"] * r["ms"] for r in rows)
-        tot_gflop = sum(r["count"] * r["gflop"] for r in rows)
-        achieved = tot_gflop / tot_ms                      # GFLOP/ms == TFLOP/s
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<BM,BN,AKM,BKM> (all instantiations)",
-                           "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
-                           "launches_per_step": launches, "avg_launch_us": round(tot_ms / launches * 1e3, 2),
-                           "gflop_per_launch": round(tot_gflop / launches, 3), "gemm_ms_per_step": round(tot_ms, 3)}
-        # HBM traffic of the same kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
-        # separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md): launch-weighted bytes per launch
-        import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
-        if pmcs:
-            g = [r for r in json.load(open(pmcs[-1])) if "gemm_kernel" in r["kernel"]]
-            if g:
-                out["roofline"]["traffic"] = round(sum(r["calls"] * r["hbm_mb"] for r in g) / sum(r["calls"] for r in g) * 1e6)
-                out["roofline"]["traffic_unit"] = f"bytes/launch (PMC, profiles/{os.path.basename(pmcs[-1])})"
-                out["roofline"]["algorithmic_bytes_per_launch"] = round(sum(
-                    r["count"] * r["batch"] * 2 * (r["M"] * r["K"] + r["N"] * r["K"] + r["M"] * r["N"] * (2 if r["akm"] else 1)) for r in rows) / launches)
-        worst = sorted(rows, key=lambda r: -r["count"] * r["ms"])[:6]
-        out["roofline"]["top_shapes"] = [dict(M=r["M"], N=r["N"], K=r["K"], akm=r["akm"], bkm=r["bkm"], count=r["count"], batch=r["batch"],
-                                              us=round(r["ms"] * 1e3, 1), tflops=round(r["gflop"] / r["ms"], 1)) for r in worst]
-    if rank == 0 and world == 1 and not distributed and not args.no_cpu_baseline:
+        if "roofline" in out:
+            warm, warm_ms = time_gemms_warm(cfg, B, L, V, T, dev)
+            out["roofline"]["frac_warm"] = round(warm / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)
+            out["roofline"]["gemm_ms_per_step_warm_replay"] = round(warm_ms, 3)
+    if solo and not args.no_parity:
+        out["parity"] = parity_vs_oracle(model, dev, B)
+    if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
-    if rank == 0 and world == 1 and not distributed and args.eager_baseline:
-        del model, opt
+    if solo and args.eager_baseline:
+        del model, opt, store
         torch.cuda.empty_cache()
         out["eager_gpu_baseline"] = eager_gpu_baseline(dev, B)
     if rank == 0:

@@ -24,7 +24,7 @@ extern "C" {
 #define VLT5_OK 0
 #define VLT5_ERR_ARG 1001
 #define VLT5_ERR_ALIGN 1002
-#define VLT5_ABI_VERSION 2
+#define VLT5_ABI_VERSION 3
 
 int vlt5_abi_version(void);
 
@@ -57,6 +57,13 @@ int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream);     /* writes d->split_used
 long long vlt5_gemm_workspace_bytes(int M, int ldc, int split_k);
 /* the split-K factor the engine uses for a plain f32 output [M,N] reduced over Kred (1 = no split) */
 int vlt5_gemm_auto_split(int M, int N, int Kred, long long slab_bytes);
+
+/* measurement hook for bench.py's roofline (no counterpart in the reference): while enabled (max_launches > 0; 0 disables and
+ * frees), every GEMM kernel dispatch carries its own start/stop HIP events; collect() waits for them and returns one record per
+ * dispatch in launch order (the number of records, -1 on error), then resets.  Process-global, not thread-safe. */
+typedef struct { int M, N, K, batch, tile_m, tile_n, a_kmajor, b_kmajor, splits, workgroups; float ms; } vlt5_gemm_timing_rec;
+int vlt5_gemm_timing_enable(int max_launches);
+int vlt5_gemm_timing_collect(vlt5_gemm_timing_rec* out, int cap);
 
 /* ---- T5LayerNorm (RMS, no mean, no bias): HF T5LayerNorm.forward ------------------------------
  * y = x * rsqrt(mean(x^2)+eps) * w, statistics in f32.  Optional inverted dropout on y
@@ -214,6 +221,13 @@ int vlt5_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);
 int vlt5_cast_f32(const void* src_bf16, float* dst, long long n, float scale, void* stream);
 int vlt5_scale_add(float* dst, const float* src, float a, float b, long long n, void* stream); /* dst = a*dst + b*src */
 
+/* ---- gated-GELU FFN activation (HF T5DenseGatedActDense.forward: gelu_new(wi_0 x) * wi_1 x, dropout) --------------------
+ * u bf16 [rows, 2*ff] = x [wi_0; wi_1]^T from one GEMM; h bf16 [rows, ff] = dropout(gelu_new(u[:, :ff]) * u[:, ff:]),
+ * dropout element index r*ff+c.  bwd: du[:, :ff] = dh' u1 gelu_new'(u0), du[:, ff:] = dh' gelu_new(u0), dh' = dropout-backward(dh). */
+int vlt5_glu_fwd(const void* u_bf16, void* h_bf16, long long rows, int ff, float drop_p, uint32_t drop_seed, void* stream);
+int vlt5_glu_bwd(const void* dh_bf16, const void* u_bf16, void* du_bf16, long long rows, int ff, float drop_p, uint32_t drop_seed,
+                 void* stream);
+
 /* dst_bf16 = dropout(src) (inverted, element index r*cols+c) cast to bf16; the bf16 operand of the backward GEMMs */
 int vlt5_drop_cast(const float* src, void* dst_bf16, long long rows, int cols, float drop_p, uint32_t drop_seed, void* stream);
 
@@ -237,6 +251,8 @@ typedef struct {
     int pad_id, dec_start_id;
     int n_ques, n_cate;            /* prototype classes (10 question types, 80 categories) */
     float eps, dropout;
+    int gated_act;                 /* 0: ReLU FFN (t5-base / t5-large: every reference configuration); 1: gated GELU (HF
+                                      T5DenseGatedActDense, feed_forward_proj = "gated-gelu"): wi_0 | wi_1 adjacent in the layout */
 } vlt5_config;
 
 typedef struct {

@@ -42,7 +42,7 @@ def _worker(rank, world, port, q):
         # buckets: contiguous, ordered, cover exactly the gradient-bearing region, exclude prototype_fc*
         assert dp.bucket_start[0] == 0 and all(a == b for a, b in zip(dp.bucket_start[1:], dp.bucket_end[:-1]))
         used_end = max(off + n for (off, n, b, d, used) in model._pinfo.values() if used)
-        assert dp.bucket_end[-1] == used_end
+        assert dp.bucket_end[-1] == (used_end + 63) // 64 * 64
         unused_start = min(off for (off, n, b, d, used) in model._pinfo.values() if not used)
         assert unused_start >= used_end
         assert len(dp.bucket_end) == model._nbuckets == 2 + 2 + 2
@@ -54,6 +54,26 @@ def _worker(rank, world, port, q):
         exp = torch.arange(g.numel(), dtype=torch.float32) * 1.5
         assert torch.allclose(g[:used_end], exp[:used_end])
         assert torch.equal(g[used_end:], (torch.arange(g.numel(), dtype=torch.float32) * (rank + 1))[used_end:])
+
+        # reduce-scatter + all-gather of merged slices == all-reduce (algo "rs_ag" / the gradient half of "zero1"); chunks tile a slice
+        dp2 = DataParallelVLT5(model, algo="rs_ag", bucket_mb=0.05)
+        assert dp2.algo == "rs_ag" and DataParallelVLT5(model).algo == "zero1", "auto picks the sharded path when world | 64"
+        model.dp = dp
+        nbk = len(dp2.bucket_end)
+        sl = dp2.slices_of(0, nbk)
+        assert sl[0][0] == 0 and sl[-1][1] == dp2.bucket_end[-1] and all(x[1] == y[0] for x, y in zip(sl, sl[1:]))
+        assert len(sl) > 1 and all((b - a) % (64 * world) == 0 or (b - a) % world == 0 for a, b, _, _ in sl)
+        for a, b, _, _ in sl:
+            parts = [dp2.chunk(a, b, r) for r in range(world)]
+            assert parts[0][0] == a and parts[-1][1] == b and all(x[1] == y[0] for x, y in zip(parts, parts[1:]))
+        g2 = torch.arange(g.numel(), dtype=torch.float32) * (rank + 1)
+        for a, b, _, _ in sl:
+            dp2._reduce_slice(g2, a, b)
+            ca, cb = dp2.chunk(a, b)
+            assert torch.allclose(g2[ca:cb], exp[ca:cb]), "own chunk holds the mean after the reduce-scatter"
+        assert dp2._slices_done == [(a, b) for a, b, _, _ in sl]
+        dp2._allgather_grads(g2)
+        assert torch.allclose(g2[:used_end], exp[:used_end]) and dp2._slices_done == []
 
         # prototype statistics: N ranks x b  ==  1 process x N*b  
         gen = torch.Generator().manual_seed(7)

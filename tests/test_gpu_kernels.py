@@ -453,6 +453,79 @@ def test_attention_layer_vs_hf_golden(dev, case):
         close_norm(dtable, G[f"{case}_grel"], 6e-2, 1.5e-1, f"{case} rel-bias grad vs HF")
 
 
+@pytest.mark.parametrize("case", ["ff", "gff"])
+def test_ffn_layer_vs_hf_golden(dev, case):
+    """Whole T5LayerFF (norm, input projection(s), activation, output projection, residual) against the transformers-5.15 module
+    outputs and gradients: `ff` = T5DenseActDense (ReLU, t5-base / t5-large), `gff` = T5DenseGatedActDense (gated GELU)."""
+    from vqacl_amd import ops
+    G = load_golden("g3_hf_leaves")
+    d, ff = 64, 128
+    gated = case == "gff"
+    x = G[case + "_x"].reshape(-1, d).to(dev)
+    M = x.shape[0]
+    wln = G[case + "_layer_norm__weight"].to(dev)
+    Wo = G[case + "_DenseReluDense__wo__weight"].to(BF).to(dev)
+    if gated:
+        Wi = torch.cat([G[case + "_DenseReluDense__wi_0__weight"], G[case + "_DenseReluDense__wi_1__weight"]]).to(BF).to(dev)
+    else:
+        Wi = G[case + "_DenseReluDense__wi__weight"].to(BF).to(dev)
+    ffw = Wi.shape[0]
+    xn, _, rstd = ops.layernorm_fwd(x, wln)
+    if gated:
+        u = ops.gemm(xn, Wi, M, ffw, d)
+        h = ops.glu_fwd(u, ff)
+    else:
+        h = ops.gemm(xn, Wi, M, ff, d, relu=True)
+    y = ops.gemm(h, Wo, M, d, ff, out_f32=True, resid=x)
+    close_norm(y, G[case + "_y"].reshape(-1, d), 2e-2, 5e-2, f"{case} layer output vs HF")
+    # backward
+    gy = G[case + "_gy"].reshape(-1, d).to(dev)
+    dyd = gy.to(BF)
+    if gated:
+        dhid = ops.gemm(dyd, Wo, M, ff, d, b_kmajor=True)
+        dh = ops.glu_bwd(dhid, u, ff)
+    else:
+        dh = ops.gemm(dyd, Wo, M, ff, d, b_kmajor=True, gate=h, gate_scale=1.0)
+    dWo = ops.gemm(dyd, h, d, ff, M, a_kmajor=True, b_kmajor=True, out_f32=True)
+    dWi = ops.gemm(dh, xn, ffw, d, M, a_kmajor=True, b_kmajor=True, out_f32=True)
+    dxn = ops.gemm(dh, Wi, M, d, ffw, b_kmajor=True, out_f32=True)
+    dx, dw = ops.layernorm_bwd(dxn, x, wln, rstd)
+    dx = dx + gy
+    close_norm(dWo, G[case + "_g__DenseReluDense__wo__weight"], 4e-2, 1e-1, f"{case} dWo vs HF")
+    if gated:
+        gWi = torch.cat([G[case + "_g__DenseReluDense__wi_0__weight"], G[case + "_g__DenseReluDense__wi_1__weight"]])
+    else:
+        gWi = G[case + "_g__DenseReluDense__wi__weight"]
+    close_norm(dWi, gWi, 4e-2, 1e-1, f"{case} dWi vs HF")
+    close_norm(dw, G[case + "_g__layer_norm__weight"], 4e-2, 1e-1, f"{case} norm weight grad vs HF")
+    close_norm(dx, G[case + "_gx"].reshape(-1, d), 4e-2, 1e-1, f"{case} input grad vs HF")
+
+
+def test_gated_gelu_activation_kernels(dev):
+    """vlt5_glu_fwd / vlt5_glu_bwd against torch autograd of gelu_new(u0) * u1 on the same bf16 inputs, with and without dropout
+    (the mask of the backward equals the forward's)."""
+    from vqacl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    rows, ff = 137, 256
+    u = rnd((rows, 2 * ff), g, 1.5).to(BF).to(dev)
+    dh = rnd((rows, ff), g).to(BF).to(dev)
+    uf = u.float().requires_grad_(True)
+    act = torch.nn.functional.gelu(uf[:, :ff], approximate="tanh") * uf[:, ff:]
+    h = ops.glu_fwd(u, ff)
+    close(h, act.detach(), 1e-2, 1e-3, "glu fwd")
+    act.backward(dh.float())
+    du = ops.glu_bwd(dh, u, ff)
+    close(du, uf.grad, 1.5e-2, 2e-3, "glu bwd")
+    hd = ops.glu_fwd(u, ff, drop_p=0.25, drop_seed=77)
+    keep = (hd.float() != 0) | (act.detach() == 0)
+    frac = float((hd.float() == 0).float().mean())
+    assert 0.2 < frac < 0.3, frac
+    close(hd.float()[keep], (act.detach() / 0.75)[keep], 1e-2, 1e-3, "glu fwd dropout scale")
+    dud = ops.glu_bwd(dh, u, ff, drop_p=0.25, drop_seed=77)
+    dropped = (hd.float() == 0) & (act.detach().abs() > 1e-3)
+    assert float(dud[:, :ff].float()[dropped].abs().max()) == 0.0 and float(dud[:, ff:].float()[dropped].abs().max()) == 0.0
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # integer / small kernels
 # ---------------------------------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@ def test_library_exports_every_symbol_of_the_header(built):
     for name in sorted(declared):
         assert hasattr(raw, name), f"libvlt5_hip.so does not export {name}"
     assert set(built.PROTOTYPES) == declared, (set(built.PROTOTYPES) ^ declared)
-    assert built.lib().vlt5_abi_version() == 2
+    assert built.lib().vlt5_abi_version() == 3
 
 
 def test_struct_sizes_match_the_c_side(built, tmp_path):
@@ -125,6 +125,55 @@ def test_module_tree_is_drop_in_on_cpu(built):
     b = R.synthetic_batch(ocfg, B=2, L=8, V=36, T=3)
     with pytest.raises(Vlt5Error):
         m.train_step(b, 0, 0.5, 0.3)
+
+
+def test_init_weights_follows_the_reference_distributions(built):
+    """a-18: `TrainerBase.init_weights` (trainer_base.py:218-238: every nn.Linear / nn.Embedding weight ~ N(0,1), biases 0) followed
+    by HF T5 `_init_weights` (factor 1.0): q ~ N(0,(d*d_kv)^-1/2); k, v, wi, relative_attention_bias ~ N(0,d^-1/2);
+    o ~ N(0,(H*d_kv)^-1/2); wo ~ N(0,d_ff^-1/2); shared ~ N(0,1); every T5LayerNorm weight = 1.  What T5 does not touch keeps N(0,1):
+    the VisualEmbedding linears, img_order_embedding, prototype_fc1/2.  Checked per tensor on the sample mean / std."""
+    import math
+    from vqacl_amd import VLT5VQA, VLT5Config
+    torch.manual_seed(11)
+    d, dkv, H, ff = 128, 32, 4, 512
+    for proj in ("relu", "gated-gelu"):
+        m = VLT5VQA(VLT5Config(d_model=d, d_kv=dkv, num_heads=H, d_ff=ff, num_layers=2, vocab_size=1000, feat_dim=256,
+                               feed_forward_proj=proj), device="cpu")
+        seen = set()
+        for name, p in m.named_parameters():
+            v = p.detach().float()
+            if name.endswith("layer_norm.weight") or name.endswith("feat_embedding.1.weight") or name.endswith("absolute_vis_pos_embedding.1.weight"):
+                assert bool((v == 1).all()), name
+                seen.add("norm")
+                continue
+            if name.endswith(".bias"):
+                assert bool((v == 0).all()), name
+                seen.add("bias")
+                continue
+            if ".SelfAttention.q." in name or ".EncDecAttention.q." in name:
+                kind, std = "q", (d * dkv) ** -0.5
+            elif "Attention.k." in name or "Attention.v." in name:
+                kind, std = "kv", d ** -0.5
+            elif "relative_attention_bias" in name:
+                kind, std = "rel", d ** -0.5
+            elif "Attention.o." in name:
+                kind, std = "o", (H * dkv) ** -0.5
+            elif ".wi." in name or ".wi_0." in name or ".wi_1." in name:
+                kind, std = "wi", d ** -0.5
+            elif ".wo." in name:
+                kind, std = "wo", ff ** -0.5
+            else:
+                kind, std = "unit:" + name.split(".")[-2], 1.0       # shared, visual-embedding linears, img_order, prototype_fc
+            n = v.numel()
+            tol = 6.0 / math.sqrt(2 * n)                               # six standard errors of a sample standard deviation
+            assert abs(float(v.std()) / std - 1.0) < tol, (name, float(v.std()), std)
+            assert abs(float(v.mean())) < 6.0 * std / math.sqrt(n), (name, float(v.mean()))
+            seen.add(kind)
+        expect = {"norm", "bias", "q", "kv", "rel", "o", "wi", "wo", "unit:shared", "unit:0", "unit:img_order_embedding",
+                  "unit:prototype_fc1", "unit:prototype_fc2"}
+        assert expect <= seen, expect - seen
+        wi_names = [n for n, _ in m.named_parameters() if "DenseReluDense.wi" in n]
+        assert all((".wi_0." in n or ".wi_1." in n) == (proj == "gated-gelu") for n in wi_names)
 
 
 def test_workspace_plan_is_consistent(built):

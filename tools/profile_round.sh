@@ -8,13 +8,13 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 python3 $ROOT/bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o r -- python3 $ROOT/bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-roofline > $OUT/${TAG}_kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o r -- python3 $ROOT/bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-roofline --no-parity --no-side-values > $OUT/${TAG}_kt.log 2>&1
 python3 $ROOT/tools/rocpd_stats.py $(find $OUT/${TAG}_kt -name "*.db" | head -1) > $OUT/${TAG}_kernel_stats_bench_b80.txt
 python3 $ROOT/tools/rocpd_timeline.py $(find $OUT/${TAG}_kt -name "*.db" | head -1) > $OUT/${TAG}_step_timeline.txt
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pf -o r -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_pf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pw -o r -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_pw.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pf -o r -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-side-values > $OUT/${TAG}_pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pw -o r -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-side-values > $OUT/${TAG}_pw.log 2>&1
 python3 $ROOT/tools/rocpd_pmc.py $(find $OUT/${TAG}_pf -name "*.db" | head -1) $(find $OUT/${TAG}_pw -name "*.db" | head -1) $OUT/${TAG}_pmc_hbm_traffic.json > $OUT/${TAG}_pmc_hbm_traffic.txt
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace -d $OUT/${TAG}_pm -o r -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_pm.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace -d $OUT/${TAG}_pm -o r -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-side-values > $OUT/${TAG}_pm.log 2>&1
 python3 $ROOT/tools/rocpd_counters.py $(find $OUT/${TAG}_pm -name "*.db" | head -1) --match gemm_kernel > $OUT/${TAG}_pmc_mfma_util.txt
 cd $ROOT && python3 tools/gemm_sweep.py --graph --torch-ref > $OUT/${TAG}_gemm_tile_sweep.txt 2>&1
 # the raw rocpd databases are tens of MB each and gpurun only copies 64 MiB back: keep the summaries, drop the databases

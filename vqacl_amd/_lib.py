@@ -37,10 +37,16 @@ class AttnDesc(C.Structure):
                 ("dbias", vp)]
 
 
+class GemmTimingRec(C.Structure):
+    _fields_ = [("M", c_i), ("N", c_i), ("K", c_i), ("batch", c_i), ("tile_m", c_i), ("tile_n", c_i), ("a_kmajor", c_i),
+                ("b_kmajor", c_i), ("splits", c_i), ("workgroups", c_i), ("ms", c_f)]
+
+
 class Config(C.Structure):
     _fields_ = [("d_model", c_i), ("d_kv", c_i), ("num_heads", c_i), ("d_ff", c_i), ("num_layers", c_i),
                 ("num_decoder_layers", c_i), ("vocab", c_i), ("rel_buckets", c_i), ("feat_dim", c_i), ("n_images", c_i),
-                ("pad_id", c_i), ("dec_start_id", c_i), ("n_ques", c_i), ("n_cate", c_i), ("eps", c_f), ("dropout", c_f)]
+                ("pad_id", c_i), ("dec_start_id", c_i), ("n_ques", c_i), ("n_cate", c_i), ("eps", c_f), ("dropout", c_f),
+                ("gated_act", c_i)]
 
 
 class Step(C.Structure):
@@ -59,6 +65,8 @@ PROTOTYPES = {
     "vlt5_gemm_bf16": (c_i, [C.POINTER(GemmDesc), vp]),
     "vlt5_gemm_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
     "vlt5_gemm_auto_split": (c_i, [c_i, c_i, c_i, c_ll]),
+    "vlt5_gemm_timing_enable": (c_i, [c_i]),
+    "vlt5_gemm_timing_collect": (c_i, [C.POINTER(GemmTimingRec), c_i]),
     "vlt5_layernorm_fwd": (c_i, [vp, vp, vp, vp, vp, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),
     "vlt5_layernorm_fwd_slabs": (c_i, [vp, c_i, c_ll, vp, vp, c_f, c_u32, vp, vp, vp, vp, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),
     "vlt5_layernorm_bwd": (c_i, [vp, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, c_f, c_u32, vp]),
@@ -101,6 +109,8 @@ PROTOTYPES = {
     "vlt5_cast_f32": (c_i, [vp, vp, c_ll, c_f, vp]),
     "vlt5_scale_add": (c_i, [vp, vp, c_f, c_f, c_ll, vp]),
     "vlt5_drop_cast": (c_i, [vp, vp, c_ll, c_i, c_f, c_u32, vp]),
+    "vlt5_glu_fwd": (c_i, [vp, vp, c_ll, c_i, c_f, c_u32, vp]),
+    "vlt5_glu_bwd": (c_i, [vp, vp, vp, c_ll, c_i, c_f, c_u32, vp]),
     "vlt5_layout_count": (c_i, [C.POINTER(Config)]),
     "vlt5_layout_get": (c_i, [C.POINTER(Config), c_i, C.c_char_p, c_i, C.POINTER(c_ll), C.POINTER(c_i), C.POINTER(c_i),
                               C.POINTER(c_i), C.POINTER(c_i), C.POINTER(c_i)]),
@@ -136,7 +146,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.vlt5_abi_version() != 2:
+        if L.vlt5_abi_version() != 3:
             raise Vlt5Error("libvlt5_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -60,7 +60,12 @@ void build_layout(const vlt5_config& c, Layout& L, bool names) {
     for (int i = Ld - 1; i >= 0; --i) {
         auto& D = L.dec[i];
         D.wo = add(nm("decoder.block.%d.layer.2.DenseReluDense.wo.weight", i), d, ff, bucket);
-        D.wi = add(nm("decoder.block.%d.layer.2.DenseReluDense.wi.weight", i), ff, d, bucket);
+        if (c.gated_act) {        // t5-v1.1: wi_0 | wi_1 adjacent = one [2*ff, d] GEMM operand
+            D.wi = add(nm("decoder.block.%d.layer.2.DenseReluDense.wi_0.weight", i), ff, d, bucket);
+            add(nm("decoder.block.%d.layer.2.DenseReluDense.wi_1.weight", i), ff, d, bucket);
+        } else {
+            D.wi = add(nm("decoder.block.%d.layer.2.DenseReluDense.wi.weight", i), ff, d, bucket);
+        }
         norm(&D.ln_f, nm("decoder.block.%d.layer.2.layer_norm.weight", i));
         D.co = add(nm("decoder.block.%d.layer.1.EncDecAttention.o.weight", i), d, inner, bucket);
         D.cq = add(nm("decoder.block.%d.layer.1.EncDecAttention.q.weight", i), inner, d, bucket);
@@ -83,7 +88,12 @@ void build_layout(const vlt5_config& c, Layout& L, bool names) {
     for (int i = Le - 1; i >= 0; --i) {
         auto& E = L.enc[i];
         E.wo = add(nm("encoder.block.%d.layer.1.DenseReluDense.wo.weight", i), d, ff, bucket);
-        E.wi = add(nm("encoder.block.%d.layer.1.DenseReluDense.wi.weight", i), ff, d, bucket);
+        if (c.gated_act) {
+            E.wi = add(nm("encoder.block.%d.layer.1.DenseReluDense.wi_0.weight", i), ff, d, bucket);
+            add(nm("encoder.block.%d.layer.1.DenseReluDense.wi_1.weight", i), ff, d, bucket);
+        } else {
+            E.wi = add(nm("encoder.block.%d.layer.1.DenseReluDense.wi.weight", i), ff, d, bucket);
+        }
         norm(&E.ln_f, nm("encoder.block.%d.layer.1.layer_norm.weight", i));
         E.so = add(nm("encoder.block.%d.layer.0.SelfAttention.o.weight", i), d, inner, bucket);
         E.sqkv = add(nm("encoder.block.%d.layer.0.SelfAttention.q.weight", i), inner, d, bucket);
@@ -118,11 +128,11 @@ struct Plan {
     size_t total;
     size_t feats_bf16, boxes_g, visG, vis_rf, vis_rp, mask, enc_bias;
     size_t x[2 * MAXL + 1], xr[2 * MAXL + 1];
-    size_t xn_a[MAXL], qkv[MAXL], lse[MAXL], ctx[MAXL], xn_f[MAXL], h[MAXL];
+    size_t xn_a[MAXL], qkv[MAXL], lse[MAXL], ctx[MAXL], xn_f[MAXL], h[MAXL], u[MAXL];     // u: gated FFN pre-activations [M, 2*ff]
     size_t enc_out, enc_ext, mask_ext;
     size_t dec_ids, dec_bias, kv_all;
     size_t y[3 * MAXL + 1], yr[3 * MAXL + 1];
-    size_t yn_a[MAXL], dqkv_s[MAXL], lse_s[MAXL], ctx_s[MAXL], yn_c[MAXL], qc[MAXL], lse_c[MAXL], ctx_c[MAXL], yn_f[MAXL], hd[MAXL];
+    size_t yn_a[MAXL], dqkv_s[MAXL], lse_s[MAXL], ctx_s[MAXL], yn_c[MAXL], qc[MAXL], lse_c[MAXL], ctx_c[MAXL], yn_f[MAXL], hd[MAXL], ud[MAXL];
     size_t dec_out, logits, lse_ce, loss_tok, row_w, loss;
     // backward scratch
     size_t dx, tmp, dctx, dkv_all, d_enc_ext, dS_enc, dS_dec, dlogits, slab, ln_partial, vis_partial, rel_scratch, vis_dG, small, slab2;
@@ -135,6 +145,7 @@ struct Plan {
 
 void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     const size_t d = c.d_model, inner = (size_t)c.num_heads * c.d_kv, ff = c.d_ff, H = c.num_heads;
+    const size_t ffw = c.gated_act ? 2 * ff : ff;          // width of the FFN input projection (gated: wi_0 | wi_1)
     const int Le = c.num_layers, Ld = c.num_decoder_layers;
     p.B = B; p.L = L; p.V = V; p.T = T; p.S = L + V; p.Sx = p.S + 2;
     p.M = B * p.S; p.Mx = B * p.Sx; p.Md = B * T;
@@ -152,6 +163,7 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     for (int l = 0; l < Le; ++l) {
         p.xn_a[l] = take(M * d * 2); p.qkv[l] = take(M * 3 * inner * 2); p.lse[l] = take((size_t)B * H * p.S * 4);
         p.ctx[l] = take(M * inner * 2); p.xn_f[l] = take(M * d * 2); p.h[l] = take(M * ff * 2);
+        p.u[l] = c.gated_act ? take(M * ffw * 2) : 0;
     }
     p.enc_out = take(Mx * d * 4);
     p.enc_ext = take(Mx * d * 2);
@@ -165,6 +177,7 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
         p.ctx_s[l] = take(Md * inner * 2); p.yn_c[l] = take(Md * d * 2); p.qc[l] = take(Md * inner * 2);
         p.lse_c[l] = take((size_t)B * H * T * 4); p.ctx_c[l] = take(Md * inner * 2); p.yn_f[l] = take(Md * d * 2);
         p.hd[l] = take(Md * ff * 2);
+        p.ud[l] = c.gated_act ? take(Md * ffw * 2) : 0;
     }
     p.dec_out = take(Md * d * 2);
     p.logits = take(Md * (size_t)c.vocab * 4);
@@ -172,13 +185,13 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     const size_t Mmax = Mx > Md ? Mx : Md;
     p.dx = take(Mmax * d * 4);
     p.tmp = take(Mmax * d * 4);
-    p.dctx = take(Mmax * inner * 2);
+    p.dctx = take(Mmax * (inner > (c.gated_act ? ff : 0) ? inner : ff) * 2);     // (gated FFN: also the hidden-gradient scratch [M, ff])
     for (int l = 0; l < Le; ++l) {
-        p.e_dyd_f[l] = take(M * d * 2); p.e_dh[l] = take(M * ff * 2); p.e_dyd_a[l] = take(M * d * 2);
+        p.e_dyd_f[l] = take(M * d * 2); p.e_dh[l] = take(M * ffw * 2); p.e_dyd_a[l] = take(M * d * 2);
         p.e_dqkv[l] = take(M * 3 * inner * 2);
     }
     for (int l = 0; l < Ld; ++l) {
-        p.d_dyd_f[l] = take(Md * d * 2); p.d_dh[l] = take(Md * ff * 2); p.d_dyd_c[l] = take(Md * d * 2);
+        p.d_dyd_f[l] = take(Md * d * 2); p.d_dh[l] = take(Md * ffw * 2); p.d_dyd_c[l] = take(Md * d * 2);
         p.d_dq_c[l] = take(Md * inner * 2); p.d_dyd_s[l] = take(Md * d * 2); p.d_dqkv[l] = take(Md * 3 * inner * 2);
     }
     p.dkv_all = take(Mx * (size_t)Ld * 2 * inner * 2);
@@ -186,7 +199,7 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     p.dS_enc = take((size_t)Le * B * H * L * L * 4);
     p.dS_dec = take((size_t)Ld * B * H * T * T * 4);
     p.dlogits = take(Md * (size_t)c.vocab * 2);
-    size_t wmax = ff * d;
+    size_t wmax = ffw * d;
     if (3 * inner * d > wmax) wmax = 3 * inner * d;
     p.slab_bytes = 8 * wmax * 4;
     p.slab = take(p.slab_bytes);
@@ -272,6 +285,15 @@ struct Ctx {
         return vlt5_gemm_bf16(&g, st);
     }
     int pick_split(int M, int N, int Kred) const { return vlt5_gemm_auto_split(M, N, Kred, (long long)p.slab_bytes); }
+    int ffw() const { return c.gated_act ? 2 * ff : ff; }
+    // hidden activation of an FFN: h = dropout(act(xn Wi^T)).  ReLU: one GEMM with the activation in its epilogue.  Gated GELU (HF
+    // T5DenseGatedActDense): u = xn [wi_0; wi_1]^T kept for the backward, then h = dropout(gelu_new(u0) * u1)
+    int ffn_hidden(const bf16_t* xn, long long wi, bf16_t* u, bf16_t* h, int M, float dp, uint32_t dseed) const {
+        if (!c.gated_act) return lin_fwd(xn, Pb + wi, h, M, ff, d, 0, 1.f, nullptr, 1, dp, dseed);
+        int rc = lin_fwd(xn, Pb + wi, u, M, 2 * ff, d, 0);
+        if (rc) return rc;
+        return vlt5_glu_fwd(u, h, M, ff, dp, dseed, st);
+    }
     // y = resid + dropout(x W^T) for a sublayer output that only a LayerNorm consumes next: when the reduction is long and the output
     // small (decoder FFN: 400 x 768 over K = 3072, 84 tiles for 256 CUs) the GEMM is cut into split-K slices that stay in the slab
     // scratch, and ln_fwd_pending() assembles the row (slab sum, dropout, residual) while it normalises it.  *pending = number
@@ -441,7 +463,7 @@ int encoder_fwd(const Ctx& k) {
                      -10000.f, 0, S, S, k.seed(sb + E_PROBS)));
         RC(k.lin_fwd(k.w<bf16_t>(p.ctx[l]), k.Pb + E.so, xf, M, d, inner, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + E_ATTN_OUT), xa));
         RC(vlt5_layernorm_fwd(xf, k.P + E.ln_f, k.w<void>(p.xn_f[l]), nullptr, k.w<float>(p.xr[2 * l + 1]), M, d, c.eps, 0.f, 0, 0, 0, k.st));
-        RC(k.lin_fwd(k.w<bf16_t>(p.xn_f[l]), k.Pb + E.wi, k.w<void>(p.h[l]), M, ff, d, 0, 1.f, nullptr, 1, k.pdrop, k.seed(sb + E_FFN_H)));
+        RC(k.ffn_hidden(k.w<bf16_t>(p.xn_f[l]), E.wi, k.w<bf16_t>(p.u[l]), k.w<bf16_t>(p.h[l]), M, k.pdrop, k.seed(sb + E_FFN_H)));
         RC(k.lin_fwd_for_norm(k.w<bf16_t>(p.h[l]), k.Pb + E.wo, xo, M, d, ff, k.pdrop, k.seed(sb + E_FFN_OUT), xf, &pending));
     }
     const int Le = c.num_layers;
@@ -488,7 +510,7 @@ int decoder_fwd(const Ctx& k) {
                      k.seed(sb + D_CPROBS)));
         RC(k.lin_fwd(k.w<bf16_t>(p.ctx_c[l]), k.Pb + D.co, y2, Md, d, inner, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + D_COUT), y1));
         RC(vlt5_layernorm_fwd(y2, k.P + D.ln_f, k.w<void>(p.yn_f[l]), nullptr, k.w<float>(p.yr[3 * l + 2]), Md, d, c.eps, 0.f, 0, 0, 0, k.st));
-        RC(k.lin_fwd(k.w<bf16_t>(p.yn_f[l]), k.Pb + D.wi, k.w<void>(p.hd[l]), Md, ff, d, 0, 1.f, nullptr, 1, k.pdrop, k.seed(sb + D_FFN_H)));
+        RC(k.ffn_hidden(k.w<bf16_t>(p.yn_f[l]), D.wi, k.w<bf16_t>(p.ud[l]), k.w<bf16_t>(p.hd[l]), Md, k.pdrop, k.seed(sb + D_FFN_H)));
         RC(k.lin_fwd_for_norm(k.w<bf16_t>(p.hd[l]), k.Pb + D.wo, y3, Md, d, ff, k.pdrop, k.seed(sb + D_FFN_OUT), y2, &pending));
     }
     RC(k.ln_fwd_pending(pending, k.w<float>(p.y[3 * Ld]), k.w<float>(p.y[3 * Ld - 1]), k.pdrop,
@@ -551,7 +573,7 @@ int decoder_step(const Ctx& k, const long long* tokens, int t, bf16_t* cache, fl
                      k.w<bf16_t>(p.ctx_c[l]), nullptr, nullptr, 0, 0, k.w<float>(p.mask_ext), -1e9f, 0, 1, Sx, 0));
         RC(k.lin_fwd(k.w<bf16_t>(p.ctx_c[l]), k.Pb + D.co, y2, B, d, inner, 1, 1.f, nullptr, 0, 0.f, 0, y1));
         RC(vlt5_layernorm_fwd(y2, k.P + D.ln_f, k.w<void>(p.yn_f[l]), nullptr, nullptr, B, d, c.eps, 0.f, 0, 0, 0, k.st));
-        RC(k.lin_fwd(k.w<bf16_t>(p.yn_f[l]), k.Pb + D.wi, k.w<void>(p.hd[l]), B, ff, d, 0, 1.f, nullptr, 1, 0.f, 0));
+        RC(k.ffn_hidden(k.w<bf16_t>(p.yn_f[l]), D.wi, k.w<bf16_t>(p.ud[l]), k.w<bf16_t>(p.hd[l]), B, 0.f, 0));
         RC(k.lin_fwd(k.w<bf16_t>(p.hd[l]), k.Pb + D.wo, y3, B, d, ff, 1, 1.f, nullptr, 0, 0.f, 0, y2));
     }
     RC(vlt5_layernorm_fwd(k.w<float>(p.y[3 * Ld]), k.P + L.dec_final_ln, k.w<void>(p.dec_out), nullptr, nullptr, B, d, c.eps, 0.f, 0,
@@ -565,15 +587,22 @@ int decoder_step(const Ctx& k, const long long* tokens, int t, bf16_t* cache, fl
 // backward (data path only) of one  x_out = x_in + drop(W_o . drop(relu(W_i . LN(x_in))))  sublayer; dx is updated in place.
 // `dyd` holds bf16(dropout_out(dx)) on entry (emitted by the producer of dx); `dh` receives the hidden gradient; both are
 // kept for the batched weight-gradient GEMMs at the end of the phase.  `next_dst` receives the operand of the next sublayer.
-int ffn_bwd(const Ctx& k, int M, float* dx, const float* x_in, const float* rstd, const bf16_t* h, const bf16_t* dyd, bf16_t* dh,
-            long long wi, long long wo, long long ln, bf16_t* next_dst, uint32_t next_seed) {
+int ffn_bwd(const Ctx& k, int M, float* dx, const float* x_in, const float* rstd, const bf16_t* h, const bf16_t* u, uint32_t h_seed,
+            const bf16_t* dyd, bf16_t* dh, long long wi, long long wo, long long ln, bf16_t* next_dst, uint32_t next_seed) {
     const Plan& p = k.p;
     const int d = k.d, ff = k.ff;
     float* tmp = k.w<float>(p.tmp);
-    const float gs = k.pdrop > 0.f ? drop_scale(drop_thr16(k.pdrop)) : 1.f;
-    RC(k.lin_dgrad(dyd, k.Pb + wo, dh, M, d, ff, 0, 1.f, h, gs));
+    if (k.c.gated_act) {
+        // dh_hidden = dyd Wo (scratch), then back through dropout and gelu_new(u0) * u1 into du = [du0 | du1] (kept for the wgrad)
+        bf16_t* dhid = k.w<bf16_t>(p.dctx);
+        RC(k.lin_dgrad(dyd, k.Pb + wo, dhid, M, d, ff, 0));
+        RC(vlt5_glu_bwd(dhid, u, dh, M, ff, k.pdrop, h_seed, k.st));
+    } else {
+        const float gs = k.pdrop > 0.f ? drop_scale(drop_thr16(k.pdrop)) : 1.f;
+        RC(k.lin_dgrad(dyd, k.Pb + wo, dh, M, d, ff, 0, 1.f, h, gs));
+    }
     int ns = 1;
-    RC(k.lin_dgrad(dh, k.Pb + wi, tmp, M, ff, d, 1, 1.f, nullptr, 1.f, &ns));
+    RC(k.lin_dgrad(dh, k.Pb + wi, tmp, M, k.ffw(), d, 1, 1.f, nullptr, 1.f, &ns));
     RC(k.ln_bwd(tmp, x_in, ln, rstd, dx, M, 1, 0.f, 0, 0, 0, next_dst, next_seed, ns, (long long)M * d));
     return VLT5_OK;
 }
@@ -606,8 +635,8 @@ int decoder_bwd(const Ctx& k) {
         bf16_t* dyd_s = k.w<bf16_t>(p.d_dyd_s[l]);
         bf16_t* dq_c = k.w<bf16_t>(p.d_dq_c[l]);
         bf16_t* dqkv = k.w<bf16_t>(p.d_dqkv[l]);
-        RC(ffn_bwd(k, Md, dx, k.w<float>(p.y[3 * l + 2]), k.w<float>(p.yr[3 * l + 2]), k.w<bf16_t>(p.hd[l]), k.w<bf16_t>(p.d_dyd_f[l]),
-                   k.w<bf16_t>(p.d_dh[l]), D.wi, D.wo, D.ln_f, dyd_c, k.seed(sb + D_COUT)));
+        RC(ffn_bwd(k, Md, dx, k.w<float>(p.y[3 * l + 2]), k.w<float>(p.yr[3 * l + 2]), k.w<bf16_t>(p.hd[l]), k.w<bf16_t>(p.ud[l]),
+                   k.seed(sb + D_FFN_H), k.w<bf16_t>(p.d_dyd_f[l]), k.w<bf16_t>(p.d_dh[l]), D.wi, D.wo, D.ln_f, dyd_c, k.seed(sb + D_COUT)));
         // cross-attention sublayer
         RC(k.lin_dgrad(dyd_c, k.Pb + D.co, dctx, Md, d, inner, 0));
         RC(attn_call(k, true, k.w<bf16_t>(p.qc[l]), (long long)T * inner, inner, kv, kv + inner, (long long)Sx * kvw, kvw, nullptr,
@@ -637,7 +666,7 @@ int decoder_bwd(const Ctx& k) {
         const Ctx ks = k.on_side();
         const int l1 = Ld > 1 ? 1 : 0;
         RC(ks.wgrad_batched(p.d_dyd_f[0], p.d_dyd_f[l1], d, p.hd[0], p.hd[l1], ff, L.dec[0].wo, L.dec[l1].wo, Ld, Md, d, ff));
-        RC(ks.wgrad_batched(p.d_dh[0], p.d_dh[l1], ff, p.yn_f[0], p.yn_f[l1], d, L.dec[0].wi, L.dec[l1].wi, Ld, Md, ff, d));
+        RC(ks.wgrad_batched(p.d_dh[0], p.d_dh[l1], k.ffw(), p.yn_f[0], p.yn_f[l1], d, L.dec[0].wi, L.dec[l1].wi, Ld, Md, k.ffw(), d));
         RC(ks.wgrad_batched(p.d_dyd_c[0], p.d_dyd_c[l1], d, p.ctx_c[0], p.ctx_c[l1], inner, L.dec[0].co, L.dec[l1].co, Ld, Md, d, inner));
         RC(ks.wgrad_batched(p.d_dq_c[0], p.d_dq_c[l1], inner, p.yn_c[0], p.yn_c[l1], d, L.dec[0].cq, L.dec[l1].cq, Ld, Md, inner, d));
         RC(ks.wgrad_batched(p.d_dyd_s[0], p.d_dyd_s[l1], d, p.ctx_s[0], p.ctx_s[l1], inner, L.dec[0].so, L.dec[l1].so, Ld, Md, d, inner));
@@ -666,7 +695,7 @@ int enc_wgrads(const Ctx& k, int lo, int hi) {
     if (n <= 0) return VLT5_OK;
     const int l1 = n > 1 ? lo + 1 : lo;
     RC(k.wgrad_batched(p.e_dyd_f[lo], p.e_dyd_f[l1], d, p.h[lo], p.h[l1], ff, L.enc[lo].wo, L.enc[l1].wo, n, M, d, ff));
-    RC(k.wgrad_batched(p.e_dh[lo], p.e_dh[l1], ff, p.xn_f[lo], p.xn_f[l1], d, L.enc[lo].wi, L.enc[l1].wi, n, M, ff, d));
+    RC(k.wgrad_batched(p.e_dh[lo], p.e_dh[l1], k.ffw(), p.xn_f[lo], p.xn_f[l1], d, L.enc[lo].wi, L.enc[l1].wi, n, M, k.ffw(), d));
     RC(k.wgrad_batched(p.e_dyd_a[lo], p.e_dyd_a[l1], d, p.ctx[lo], p.ctx[l1], inner, L.enc[lo].so, L.enc[l1].so, n, M, d, inner));
     RC(k.wgrad_batched(p.e_dqkv[lo], p.e_dqkv[l1], 3 * inner, p.xn_a[lo], p.xn_a[l1], d, L.enc[lo].sqkv, L.enc[l1].sqkv, n, M, 3 * inner, d));
     return VLT5_OK;
@@ -687,8 +716,8 @@ int encoder_bwd(const Ctx& k) {
         bf16_t* qkv = k.w<bf16_t>(p.qkv[l]);
         bf16_t* dyd_a = k.w<bf16_t>(p.e_dyd_a[l]);
         bf16_t* dqkv = k.w<bf16_t>(p.e_dqkv[l]);
-        RC(ffn_bwd(k, M, dx, k.w<float>(p.x[2 * l + 1]), k.w<float>(p.xr[2 * l + 1]), k.w<bf16_t>(p.h[l]), k.w<bf16_t>(p.e_dyd_f[l]),
-                   k.w<bf16_t>(p.e_dh[l]), E.wi, E.wo, E.ln_f, dyd_a, k.seed(sb + E_ATTN_OUT)));
+        RC(ffn_bwd(k, M, dx, k.w<float>(p.x[2 * l + 1]), k.w<float>(p.xr[2 * l + 1]), k.w<bf16_t>(p.h[l]), k.w<bf16_t>(p.u[l]),
+                   k.seed(sb + E_FFN_H), k.w<bf16_t>(p.e_dyd_f[l]), k.w<bf16_t>(p.e_dh[l]), E.wi, E.wo, E.ln_f, dyd_a, k.seed(sb + E_ATTN_OUT)));
         RC(k.lin_dgrad(dyd_a, k.Pb + E.so, dctx, M, d, inner, 0));
         RC(attn_call(k, true, qkv, (long long)S * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)S * 3 * inner,
                      3 * inner, nullptr, k.w<float>(p.lse[l]), k.w<float>(p.enc_bias), s.L, s.L, k.w<float>(p.mask), -10000.f, 0, S, S,

@@ -1,0 +1,7 @@
+// 256 x 256 tile instantiations of the GEMM kernel template (all four operand layouts); see gemm_kernel.h / gemm.hip.
+#include "gemm_kernel.h"
+namespace vlt5gemm {
+int launch_256x256(const GemmArgs& a, int akm, int bkm, int splits, int batch, hipStream_t st) {
+    return launch_tile<256, 256>(a, akm, bkm, splits, batch, st);
+}
+}  // namespace vlt5gemm

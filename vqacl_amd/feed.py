@@ -34,74 +34,46 @@ def normalize_boxes(boxes, img_w, img_h):
 
 
 def collate(entries, pad_token_id=0, n_cate=80, n_task=10, store=None):
-    """The reference's `collate_fn` (vqa_data_memory.py:291-396) over the dicts its `__getitem__` returns.
+    """Batch dict with the schema of the reference's `collate_fn` (vqa_data_memory.py:291-396) from the dicts its `__getitem__`
+    returns -- the golden fixture G7 (the reference's own function run on the same entries) holds it to the bit.
 
-    Same keys, dtypes and padding: `input_ids` padded with `pad_token_id`; `target_ids` padded and every pad position set to -100;
-    `boxes`/`vis_feats` f32 [B,V,4]/[B,V,F]; `scores` f32; `cate_labels` [B,80] and `ques_labels` [B,n_task] one-hot f32;
-    host lists `sent`, `question_ids`, `answers`, `all_answers`, `labels`; `task` = 'vqa'; `args` passed through.
-    With `store`, entries need `img_id` only and the batch carries `feat_ref` instead of `vis_feats`/`boxes`."""
-    B = len(entries)
+    `input_ids` i64 [B, max len] padded with `pad_token_id`; `target_ids` i64 padded the same way, then -100 wherever the
+    pad id stands; `vis_feats` f32 [B,V,F], `boxes` f32 [B,V,4]; `targets` f32 [B,n_answers] when entries carry a dense answer
+    vector; `scores` f32 [B]; `cate_labels` [B,n_cate] / `ques_labels` [B,n_task] one-hot f32; the host-side lists (`sent`,
+    `question_ids`, `answers`, `all_answers`, `labels`) in entry order; `task` = 'vqa'; `args` of the first entry.
+    With `store`, entries need `img_id` only and the batch carries `feat_ref` instead of `vis_feats` / `boxes`."""
+    from torch.nn.utils.rnn import pad_sequence
     first = entries[0]
-    batch = {}
-    S = max(e["input_length"] for e in entries)
-    input_ids = torch.full((B, S), pad_token_id, dtype=torch.long)
-    use_vision = "boxes" in first and store is None
-    if use_vision:
-        V, F = len(first["boxes"]), first["vis_feats"].shape[-1]
-        boxes = torch.zeros(B, V, 4, dtype=torch.float)
-        vis_feats = torch.zeros(B, V, F, dtype=torch.float)
-    if "target" in first:
-        targets = torch.zeros(B, len(first["target"]), dtype=torch.float)
+
+    def ids(key, length):
+        rows = [torch.as_tensor(e[key], dtype=torch.long)[:e[length]] for e in entries]
+        return pad_sequence(rows, batch_first=True, padding_value=pad_token_id)
+
+    def dense(key):
+        # (+ 0.0: the reference accumulates onto a zero tensor, which maps -0.0 to +0.0)
+        return torch.stack([torch.as_tensor(e[key], dtype=torch.float) for e in entries]) + 0.0
+
+    def column(key):
+        return [e[key] for e in entries if key in e]
+
+    def one_hot(key, width):
+        idx = torch.tensor(column(key), dtype=torch.long)
+        return torch.nn.functional.one_hot(idx, width).to(torch.float) if idx.numel() else torch.zeros(0, width)
+
+    batch = {"input_ids": ids("input_ids", "input_length")}
     if "target_ids" in first:
-        T = max(e["target_length"] for e in entries)
-        target_ids = torch.full((B, T), pad_token_id, dtype=torch.long)
-    sentences, question_ids, answers, all_answers, labels, scores, cate, ques = [], [], [], [], [], [], [], []
-    for i, e in enumerate(entries):
-        input_ids[i, :e["input_length"]] = e["input_ids"]
-        if use_vision:
-            boxes[i] += e["boxes"]
-            vis_feats[i] += e["vis_feats"]
-        if "target_ids" in e:
-            target_ids[i, :e["target_length"]] = e["target_ids"]
-        if "target" in e:
-            targets[i] += e["target"]
-        sentences.append(e["sent"])
-        question_ids.append(e["question_id"])
-        if "answer" in e:
-            answers.append(e["answer"])
-        if "all_answers" in e:
-            all_answers.append(e["all_answers"])
-        if "score" in e:
-            scores.append(e["score"])
-        if "label" in e:
-            labels.append(e["label"])
-        if "img_cate" in e:
-            cate.append(e["img_cate"])
-        if "ques_label" in e:
-            ques.append(e["ques_label"])
-    batch["input_ids"] = input_ids
-    if "target_ids" in first:
-        target_ids[target_ids == pad_token_id] = -100
-        batch["target_ids"] = target_ids
+        t = ids("target_ids", "target_length")
+        batch["target_ids"] = t.masked_fill(t == pad_token_id, -100)
     if "target" in first:
-        batch["targets"] = targets
-    if use_vision:
-        batch["boxes"] = boxes
-        batch["vis_feats"] = vis_feats
+        batch["targets"] = dense("target")
     if store is not None:
-        batch["feat_ref"] = store.ref([e["img_id"] for e in entries])
-    batch["sent"] = sentences
-    batch["question_ids"] = question_ids
-    batch["answers"] = answers
-    batch["all_answers"] = all_answers
-    batch["scores"] = torch.FloatTensor(scores)
-    batch["labels"] = labels
-    batch["args"] = first.get("args")
-    batch["task"] = "vqa"
-    cate_idx = torch.LongTensor(cate).unsqueeze(1)
-    batch["cate_labels"] = torch.zeros(cate_idx.shape[0], n_cate).scatter_(1, cate_idx, 1)
-    ques_idx = torch.LongTensor(ques).unsqueeze(1)
-    batch["ques_labels"] = torch.zeros(cate_idx.shape[0], n_task).scatter_(1, ques_idx, 1)
+        batch["feat_ref"] = store.ref(column("img_id"))
+    elif "boxes" in first:
+        batch["boxes"], batch["vis_feats"] = dense("boxes"), dense("vis_feats")
+    batch.update(sent=column("sent"), question_ids=column("question_id"), answers=column("answer"),
+                 all_answers=column("all_answers"), labels=column("label"), args=first.get("args"), task="vqa",
+                 scores=torch.tensor(column("score"), dtype=torch.float),
+                 cate_labels=one_hot("img_cate", n_cate), ques_labels=one_hot("ques_label", n_task))
     return batch
 
 

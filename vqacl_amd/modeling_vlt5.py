@@ -48,8 +48,10 @@ class VLT5Config:
         self.feed_forward_proj = feed_forward_proj
         self.tie_word_embeddings = tie_word_embeddings
         self.classifier = classifier
-        if feed_forward_proj != "relu":
-            raise NotImplementedError("only the ReLU FFN of t5-base/large is implemented (SURVEY 0.4)")
+        # HF T5Config: "relu" (t5-base / t5-large: every reference launch script) or "gated-gelu" (t5-v1.1: T5DenseGatedActDense)
+        if feed_forward_proj not in ("relu", "gated-gelu"):
+            raise NotImplementedError(f"feed_forward_proj={feed_forward_proj!r}: the engine implements 'relu' and 'gated-gelu'")
+        self.is_gated_act = feed_forward_proj == "gated-gelu"
         if pos_dim != 4 or not tie_word_embeddings:
             raise NotImplementedError("pos_dim must be 4 and embeddings tied, as in every reference launch script")
 
@@ -71,6 +73,7 @@ class VLT5Config:
         c.pad_id, c.dec_start_id = self.pad_token_id, self.decoder_start_token_id
         c.n_ques, c.n_cate = self.n_ques, self.n_cate
         c.eps, c.dropout = self.layer_norm_epsilon, self.dropout_rate
+        c.gated_act = int(self.is_gated_act)
         return c
 
 
@@ -303,7 +306,7 @@ class VLT5(nn.Module):
                     std = d ** -0.5
                 elif "Attention.o." in name:
                     std = inner ** -0.5
-                elif ".wi." in name:
+                elif ".wi." in name or ".wi_0." in name or ".wi_1." in name:
                     std = d ** -0.5
                 elif ".wo." in name:
                     std = cfg.d_ff ** -0.5
@@ -331,6 +334,8 @@ class VLT5(nn.Module):
 
     # ------------------------------------------------------------------ engine plumbing ---------------
     def flat_params(self):
+        if self.dp is not None and getattr(self.dp, "params_sharded", False):
+            self.dp.materialize_params(self)     # ZeRO-1 data parallel: collective, every rank must call it
         return self._flat
 
     def flat_grads(self):
@@ -342,11 +347,20 @@ class VLT5(nn.Module):
         return self._flat_bf16
 
     def sync_bf16(self, force=False):
-        """Refresh the bf16 shadow when the fp32 master changed (any in-place update bumps the version counter)."""
-        v = self._flat._version
-        if force or (not self.external_bf16_sync and v != self._bf16_version) or self._bf16_version < 0:
+        """Refresh the bf16 shadow when the fp32 master changed.  Every torch-side in-place write (load_state_dict,
+        load_checkpoint, `p.data.copy_`, a stock optimizer) bumps the flat buffer's version counter; the fused optimizer
+        writes both buffers through raw pointers (no bump) and records the version it left behind, so a plain version
+        compare is exact in both cases."""
+        if force or self._flat._version != self._bf16_version or self._bf16_version < 0:
             ops.cast_bf16(self._flat, self._flat_bf16)
             self._bf16_version = self._flat._version
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """nn.Module.load_state_dict + a forced refresh of the bf16 shadow (the engine reads the shadow, not the master)."""
+        self.sync_optimizer()
+        res = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._bf16_version = -1
+        return res
 
     def _lut(self, q, k, bidirectional):
         key = (q, k, bidirectional)
@@ -416,15 +430,21 @@ class VLT5(nn.Module):
 
     def state_dict(self, *a, **k):
         self.sync_optimizer()
+        if self.dp is not None and getattr(self.dp, "params_sharded", False):
+            self.dp.materialize_params(self)     # ZeRO-1 data parallel: collective, every rank must call it
         return super().state_dict(*a, **k)
 
     # ------------------------------------------------------------------ forward ----------------------
     def forward(self, input_ids=None, vis_inputs=None, labels=None, decoder_input_ids=None, cate_labels=None,
                 ques_labels=None, proto_update=False, memory=False, current_task_id=0, proto_alpha=0.5, proto_beta=0.3,
-                return_dict=True, reduce_loss=False, scores=None, _reuse_encoder=False, **kwargs):
+                return_dict=True, reduce_loss=False, scores=None, _reuse_encoder=False, _alias_workspace=False, **kwargs):
         """Same keyword surface as the reference `VLT5.forward` (modeling_t5_our.py:514-713).  `scores` (optional,
         ours) fuses the train_step reduction of vqa_model.py:46-54 into the engine: the output then also carries the
-        reduced scalar under 'loss_reduced'."""
+        reduced scalar under 'loss_reduced'.
+
+        The returned record has the fields of `VLSeq2SeqLMOutput` (modeling_t5_our.py:695-713, 774-833).  Its tensors are
+        OWNED copies, as in the reference; `_alias_workspace=True` (used by `train_step`, which only hands two small tensors
+        on) returns views of the engine's workspace instead, valid until the next forward."""
         if not self._flat.is_cuda:
             raise L.Vlt5Error("the engine-backed VLT5 needs a GPU (no CPU fallback)")
         if labels is None:
@@ -483,12 +503,17 @@ class VLT5(nn.Module):
             out["loss"] = st["loss_tok"].detach()
         else:
             out["loss"] = loss_out if not reduce_loss else loss_out.sum() / (labels != -100).sum().clamp(min=1)
-        out["logits"] = self._ws_view(c, dims, L.WS_LOGITS, torch.float32, (B, T, self.cfg.vocab_size))
-        out["encoder_hidden_states"] = enc_f32[:, :S]
-        out["encoder_attention_mask"] = self._ws_view(c, dims, L.WS_ENC_MASK_EXT, torch.float32, (B, Sx))
+        own = (lambda t: t) if _alias_workspace else (lambda t: t.clone())
+        out["logits"] = own(self._ws_view(c, dims, L.WS_LOGITS, torch.float32, (B, T, self.cfg.vocab_size)))
+        out["past_key_values"] = None          # (use_cache decoding is `greedy_generate` / `vlt5_decoder_step`)
+        # output of the decoder stack (final norm + dropout, before the 1/sqrt(d) rescale), as `decoder_outputs.last_hidden_state`;
+        # the engine keeps it as the bf16 operand of the lm_head GEMM, returned here widened to f32
+        out["decoder_last_hidden_state"] = self._ws_view(c, dims, L.WS_DEC_OUT, torch.bfloat16, (B, T, d)).to(torch.float32)
+        out["decoder_hidden_states"] = None    # (`output_hidden_states` is never set by the reference's generative path)
+        out["encoder_hidden_states"] = own(enc_f32[:, :S])
+        out["encoder_attention_mask"] = own(self._ws_view(c, dims, L.WS_ENC_MASK_EXT, torch.float32, (B, Sx)))
         out["loss_memory_Q"], out["loss_memory_V"] = loss_mem_Q, loss_mem_V
         out["max_idx_Q"], out["max_idx_V"] = idxQ, idxV
-        out["past_key_values"] = None
         return out
 
     # ------------------------------------------------------------------ backward ---------------------

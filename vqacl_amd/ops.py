@@ -236,3 +236,18 @@ def drop_cast(src, drop_p=0.0, drop_seed=0):
     dst = torch.empty(rows, cols, device=src.device, dtype=BF16)
     check(lib().vlt5_drop_cast(ptr(_need(src, torch.float32)), ptr(dst), rows, cols, drop_p, drop_seed, stream_ptr()), "vlt5_drop_cast")
     return dst
+
+
+def glu_fwd(u, ff, drop_p=0.0, drop_seed=0):
+    """u bf16 [rows, 2*ff] -> h bf16 [rows, ff] = dropout(gelu_new(u[:, :ff]) * u[:, ff:])  (HF T5DenseGatedActDense)."""
+    rows = u.shape[0]
+    h = torch.empty(rows, ff, device=u.device, dtype=BF16)
+    check(lib().vlt5_glu_fwd(ptr(_need(u, BF16)), ptr(h), rows, ff, drop_p, drop_seed, stream_ptr()), "vlt5_glu_fwd")
+    return h
+
+
+def glu_bwd(dh, u, ff, drop_p=0.0, drop_seed=0):
+    rows = u.shape[0]
+    du = torch.empty(rows, 2 * ff, device=u.device, dtype=BF16)
+    check(lib().vlt5_glu_bwd(ptr(_need(dh, BF16)), ptr(_need(u, BF16)), ptr(du), rows, ff, drop_p, drop_seed, stream_ptr()), "vlt5_glu_bwd")
+    return du

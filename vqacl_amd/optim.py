@@ -33,6 +33,7 @@ class FusedAdamW(torch.optim.Optimizer):
         Everything that goes through train_step/test_step/state_dict() is ordered automatically; code that reads
         parameters directly on another stream must call `model.sync_optimizer()` (or `optimizer.synchronize()`) first."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        model = getattr(model, "module", model)      # a DataParallelVLT5 wrapper: the engine-backed module carries the state
         self.model = model
         self.max_grad_norm = max_grad_norm
         self.hf_mode = int(hf_mode)
@@ -72,6 +73,11 @@ class FusedAdamW(torch.optim.Optimizer):
         dp = getattr(model, "dp", None)
         if dp is not None and dp.grad_dtype is torch.bfloat16 and flat.is_cuda:
             dp.defer_cast_back = True
+        if dp is not None and dp.algo == "zero1":
+            # ZeRO-1 style step: this rank clips and updates only its chunk of every reduce-scattered slice, then the updated
+            # chunks are all-gathered (parallel.py).  The all-gathers are ordered against the next forward by per-bucket events.
+            dp.sharded_optimizer = True
+            self._z_events = None
         self.overlap = bool(overlap)
         if self.overlap:
             # the same runs cut at bucket boundaries, grouped by bucket
@@ -98,7 +104,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             raise L.Vlt5Error("closures are not supported")
         model = self.model
-        flat, grad, bf16 = model.flat_params(), model._flat_grad, model.flat_bf16()     # (flat_grads() would cast a deferred bucket back)
+        flat, grad, bf16 = model._flat, model._flat_grad, model.flat_bf16()     # (flat_grads() would cast a deferred bucket back)
         anchor = model._params_by_name["shared.weight"]
         if anchor.grad is None:
             return None
@@ -108,6 +114,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     model._gviews[name].copy_(p.grad)
         self._t += 1
         dp = getattr(model, "dp", None)
+        if dp is not None and dp.shards_valid and dp.sharded_optimizer and grad.data_ptr() == model._flat_grad.data_ptr():
+            return self._step_zero1(model, dp, flat, grad, bf16)
         g16 = dp._g16 if (dp is not None and dp.g16_valid and grad.data_ptr() == model._flat_grad.data_ptr()) else None
         gs = dp.grad_scale if g16 is not None else 1.0
 
@@ -148,6 +156,76 @@ class FusedAdamW(torch.optim.Optimizer):
             model._opt_events = self._events
         if g16 is not None:
             dp.g16_valid = False            # consumed (the f32 gradient buffer keeps this rank's local gradients)
+        model.external_bf16_sync = True
+        model._bf16_version = flat._version
+        return None
+
+    def _step_zero1(self, model, dp, flat, grad, bf16):
+        """Sharded step (DataParallelVLT5(algo="zero1")): the backward left chunk `rank` of every slice reduced; clip with the
+        all-reduced squared norm of the chunks, update the chunks, all-gather them slice by slice in the order the next forward
+        reads the weights."""
+        import torch.distributed as dist
+        slices = list(dp._slices_done)
+        use16 = dp.grad_dtype is torch.bfloat16 and flat.is_cuda
+        g16 = dp._g16 if use16 else None
+        gs = dp.grad_scale if use16 else 1.0
+        st = stream_ptr()
+        clip = self.max_grad_norm is not None and self.max_grad_norm > 0
+        if clip:
+            first = True
+            for a, b in slices:
+                ca, cb = dp.chunk(a, b)
+                cb = min(cb, self._used_end)
+                if cb <= ca:
+                    continue
+                if use16:
+                    check(lib().vlt5_sqnorm_g16(L.vp(g16.data_ptr() + 2 * ca), gs, cb - ca, ptr(self._partial), ptr(self._total_sq),
+                                                int(not first), st), "vlt5_sqnorm_g16")
+                else:
+                    check(lib().vlt5_sqnorm(L.vp(grad.data_ptr() + 4 * ca), cb - ca, ptr(self._partial), ptr(self._total_sq),
+                                            int(not first), st), "vlt5_sqnorm")
+                first = False
+            if first:
+                self._total_sq.zero_()
+            dist.all_reduce(self._total_sq, group=dp.group)
+        total = self._total_sq if clip else None
+        nb = len(dp.bucket_end)
+        if self._z_events is None or len(self._z_events[0]) != len(slices):
+            self._z_events = ([torch.cuda.Event() for _ in slices], [torch.cuda.Event() for _ in slices])
+        done_main, done_ag = self._z_events
+        bucket_events = [None] * nb
+        # forward order: the last bucket (embeddings, norms) first, then descending offsets (encoder bottom -> decoder top)
+        order = sorted(range(len(slices)), key=lambda i: -slices[i][0])
+        cur = torch.cuda.current_stream()
+        for j, i in enumerate(order):
+            a, b = slices[i]
+            ca, cb = dp.chunk(a, b)
+            for ra, rb, gi in self._runs:
+                x, y = max(ra, ca), min(rb, cb)
+                if x >= y:
+                    continue
+                g = self.param_groups[gi]
+                tail = (L.vp(self._m.data_ptr() + 4 * x), L.vp(self._v.data_ptr() + 4 * x), L.vp(bf16.data_ptr() + 2 * x), y - x,
+                        float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._t,
+                        ptr(total), float(self.max_grad_norm or 0.0), self.hf_mode, st)
+                if use16:
+                    check(lib().vlt5_adamw_step_g16(L.vp(flat.data_ptr() + 4 * x), L.vp(g16.data_ptr() + 2 * x), gs, *tail),
+                          "vlt5_adamw_step_g16")
+                else:
+                    check(lib().vlt5_adamw_step(L.vp(flat.data_ptr() + 4 * x), L.vp(grad.data_ptr() + 4 * x), *tail), "vlt5_adamw_step")
+            done_main[j].record(cur)
+            dp.allgather_updated(model, [(a, b)], done_main[j])
+            done_ag[j].record(dp.comm_stream)
+            for bkt in range(nb):
+                if a <= dp.bucket_start[bkt] and dp.bucket_end[bkt] <= b:
+                    bucket_events[bkt] = done_ag[j]
+        assert all(e is not None for e in bucket_events), "slices do not cover the buckets"
+        model._opt_events = bucket_events
+        dp._param_slices = slices
+        dp._slices_done = []
+        dp.shards_valid = False
+        dp.g16_valid = False
+        dp.params_sharded = dp.world > 1
         model.external_bf16_sync = True
         model._bf16_version = flat._version
         return None

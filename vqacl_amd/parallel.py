@@ -1,24 +1,36 @@
-"""Data parallelism for the engine-backed VLT5: one process per GPU, RCCL all-reduce over xGMI.
+"""Data parallelism for the engine-backed VLT5: one process per GPU, RCCL collectives over xGMI.
 
 The reference wraps the model in DDP but calls `model.module.train_step`, which bypasses DDP's reducer, so its
 ranks never synchronise gradients.  This wrapper provides the synchronisation the north star asks
 for: because the gradients live in ONE flat buffer laid out in backward-completion order, a bucket is just a
 slice -- no flatten/unflatten copies.  The engine records a HIP event when each layer's gradients are complete;
-the comm stream waits on the event and all-reduces that slice while the compute stream continues with the next
+the comm stream waits on the event and reduces that slice while the compute stream continues with the next
 layer (overlap with backward).  xGMI is point-to-point, so few, large collectives are preferred: consecutive
 layer buckets are merged up to `bucket_mb`.
 
-`grad_dtype=torch.bfloat16` (default on the GPU) halves the bytes on the links: each merged bucket is cast to a bf16 staging
-buffer, all-reduced in bf16 and cast back (scaled by 1/world) into the fp32 gradient buffer on the comm stream, so clipping,
-the optimizer and `.grad` see fp32 as before.  At 8 GPUs the fp32 reduction of 0.9 GB is ~5 ms of ring time per step against
-~6.5 ms of backward to hide it in; bf16 needs half.  (The rounding -- one bf16 rounding per rank contribution -- is of the same
-size as the bf16 GEMM noise already in the gradients.)
+Gradient exchange (`algo`):
+  * "allreduce": one `all_reduce` per merged slice.
+  * "rs_ag":     `reduce_scatter_tensor` in backward (rank r ends up with the reduced chunk r of every slice, in place) and
+                 `all_gather_into_tensor` of the chunks when backward is done -- the two halves of a ring all-reduce as separate
+                 calls, so that only the first half has to hide under backward.
+  * "zero1":     the same reduce-scatter, but the all-gather moves PARAMETERS instead of gradients: `FusedAdamW` clips and
+                 updates only this rank's chunk of every slice (1/N of the 30 B/param optimizer pass: 1.15 ms -> 0.14 ms at
+                 N = 8, optimizer state effectively sharded), then the updated chunks are all-gathered -- the bf16 shadow the
+                 GEMMs read for the layer buckets (2 B/param) and the f32 master for the last bucket (embeddings, norm weights,
+                 visual embedding: read in f32 by the gather / norm kernels), slice by slice in the order the NEXT forward
+                 needs them, each behind an event the engine's forward waits for (`vlt5_step.wait_events`).  Bytes on the links
+                 per step and GPU, N = 8, bf16 buckets: reduce-scatter 7/8 x 451 MB + all-gather 7/8 x (401 + 99) MB = 0.83 GB,
+                 against 2 x 7/8 x 451 MB = 0.79 GB for the all-reduce of the gradients alone and 1.58 GB for an f32 all-reduce.
+                 The f32 master of the layer buckets is then only current on the owning rank; `materialize_params()` (called by
+                 `state_dict()` / `flat_params()`) all-gathers it on demand.  Needs `FusedAdamW`; with any other optimizer the
+                 wrapper completes the gradients like "rs_ag".
+  * "auto":      "zero1" when the world size divides 64 (every slice length is a multiple of 64 elements, so the chunks stay
+                 16-byte aligned), "allreduce" otherwise.
 
-With the fused optimizer the way back is not a pass of its own: `FusedAdamW` attached to a wrapped model sets `defer_cast_back`,
-the reduced buckets stay in the bf16 staging buffer and the gradient-norm and AdamW kernels read them from there
-(`vlt5_sqnorm_g16` / `vlt5_adamw_step_g16`, gradient = bf16 * 1/world: the very values the cast back would have written), which
-takes 1.35 GB of HBM traffic and one kernel per bucket out of the step's tail.  `.grad` then still holds the rank-local f32
-gradients; `materialize_grads()` writes the averaged ones there on demand.
+`grad_dtype=torch.bfloat16` (default on the GPU) halves the bytes on the links: each merged slice travels as bf16 (the engine's
+weight-gradient GEMMs write the bf16 staging copy themselves, `vlt5_step.grads_bf16`; only the last bucket is cast) and the
+gradient-norm / AdamW kernels read the reduced bf16 values times 1/world straight from the staging buffer (`vlt5_sqnorm_g16`,
+`vlt5_adamw_step_g16`).  `.grad` then holds the rank-local f32 gradients; `materialize_grads()` writes the averaged ones there.
 
 Also all-reduces the prototype sufficient statistics (class sums and counts) so that every rank holds the
 prototypes a single process would compute on the concatenated batch.
@@ -26,18 +38,28 @@ prototypes a single process would compute on the concatenated batch.
 import torch
 import torch.distributed as dist
 
+ALGOS = ("auto", "allreduce", "rs_ag", "zero1")
+
 
 class DataParallelVLT5:
-    def __init__(self, model, process_group=None, bucket_mb=128, average=True, grad_dtype=None):
+    def __init__(self, model, process_group=None, bucket_mb=128, average=True, grad_dtype=None, algo="auto"):
         self.module = model
         if grad_dtype is None:
             grad_dtype = torch.bfloat16 if model._flat.is_cuda else torch.float32
         if grad_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("grad_dtype must be torch.float32 or torch.bfloat16")
+        if algo not in ALGOS:
+            raise ValueError(f"algo must be one of {ALGOS}")
         self.grad_dtype = grad_dtype
         self._g16 = None
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        if algo == "auto":
+            algo = "zero1" if (self.world > 1 and 64 % self.world == 0) else "allreduce"
+        if algo != "allreduce" and 64 % self.world != 0:
+            raise ValueError("rs_ag / zero1 need a world size that divides 64 (chunks of a slice must stay 16-byte aligned)")
+        self.algo = algo
         self.average = average
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         model.dp = self
@@ -46,16 +68,18 @@ class DataParallelVLT5:
         # bucket b covers flat elements [start_b, end_b)
         ends = {}
         for name, (off, n, bucket, decay, used) in model._pinfo.items():
-            if used:
-                ends[bucket] = max(ends.get(bucket, 0), off + n)
+            if used:       # (rounded up to the 64-element alignment of the layout: the gap holds zeros and belongs to the bucket)
+                ends[bucket] = max(ends.get(bucket, 0), (off + n + 63) // 64 * 64)
         self.bucket_end = [ends[b] for b in sorted(ends)]
         self.bucket_start = [0] + self.bucket_end[:-1]
         self.comm_stream = torch.cuda.Stream(priority=-1) if model._flat.is_cuda else None   # high priority: short casts + collectives must not queue behind the backward GEMMs
         self._events = None
-        self._next = 0
-        self._pending_from = 0
         self.defer_cast_back = False        # set by FusedAdamW: the optimizer reads the reduced bf16 buckets itself
         self.g16_valid = False              # the staging buffer holds this backward's reduced gradients, not yet cast back
+        self.sharded_optimizer = False      # set by FusedAdamW under algo == "zero1"
+        self.shards_valid = False           # this backward left only this rank's chunks reduced (zero1, between backward and step)
+        self.params_sharded = False         # the f32 master of the layer buckets is only current on the owning rank (zero1)
+        self._slices_done = []              # slices reduce-scattered by the current backward, in issue order
         # identical initial weights on every rank (what DDP's constructor would do)
         dist.broadcast(model._flat, src=0, group=process_group)
         model._bf16_version = -1
@@ -63,14 +87,35 @@ class DataParallelVLT5:
     def __getattr__(self, name):            # .train_step, .train(), .eval(), .state_dict() ... go to the model
         return getattr(self.__dict__["module"], name)
 
+    def describe(self):
+        return {"algo": self.algo, "grad_dtype": str(self.grad_dtype).replace("torch.", ""), "world": self.world,
+                "bucket_mb": self.bucket_bytes >> 20, "sharded_optimizer": bool(self.sharded_optimizer)}
+
+    # ---- slice plan -----------------------------------------------------------------------------------
+    def slices_of(self, lo, hi):
+        """Buckets [lo, hi) merged into slices of >= bucket_bytes: [(a, b, first_bucket, last_bucket)] in flat elements."""
+        out, start = [], lo
+        for b in range(lo, hi):
+            size = (self.bucket_end[b] - self.bucket_start[start]) * 4
+            if size >= self.bucket_bytes or b == hi - 1:
+                out.append((self.bucket_start[start], self.bucket_end[b], start, b))
+                start = b + 1
+        return out
+
+    def chunk(self, a, b, rank=None):
+        """Rank `rank`'s chunk of slice [a, b): equal parts (slice lengths are multiples of 64 elements)."""
+        c = (b - a) // self.world
+        r = self.rank if rank is None else rank
+        return a + r * c, a + (r + 1) * c
+
     # ---- called by VLT5._engine_backward -------------------------------------------------------------
     def make_events(self, n):
         if self._events is None or len(self._events) != n:
             self._events = [torch.cuda.Event() for _ in range(n)]
             for e in self._events:          # force creation of the underlying hipEvent_t
                 e.record()
-        self._next = 0
-        self._pending_from = 0
+        self._slices_done = []
+        self.shards_valid = False
         return self._events
 
     @property
@@ -78,7 +123,12 @@ class DataParallelVLT5:
         return 1.0 / self.world if self.average else 1.0
 
     def materialize_grads(self, model=None):
-        """Deferred mode: write the averaged gradients into the f32 gradient buffer (what `.grad` views) on the current stream."""
+        """Deferred mode: write the averaged gradients into the f32 gradient buffer (what `.grad` views) on the current stream.
+        (zero1: between backward and the optimizer step only this rank's chunks are reduced; the chunks are all-gathered first.)"""
+        if self.shards_valid:
+            self._allgather_grads((model or self.module)._flat_grad)
+            if self.comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
         if not self.g16_valid:
             return
         from ._lib import check, lib, ptr, stream_ptr
@@ -94,42 +144,124 @@ class DataParallelVLT5:
             self._g16 = torch.zeros(flat.numel(), device=flat.device, dtype=torch.bfloat16)
         return self._g16
 
-    def _allreduce_slice(self, flat, a, b, defer=False, mirrored=False):
+    def _wire(self, flat):
+        """The buffer that travels: the bf16 staging mirror (GPU, bf16 buckets) or the f32 gradient buffer itself."""
+        return self.staging(flat) if (self.grad_dtype is torch.bfloat16 and flat.is_cuda) else flat
+
+    def _reduce_slice(self, flat, a, b, defer=False, mirrored=False):
+        """One merged slice on the current (comm) stream: all-reduce, or reduce-scatter leaving chunk `rank` reduced in place."""
         t = flat[a:b]
-        if self.grad_dtype is torch.bfloat16 and flat.is_cuda:
+        bf16 = self.grad_dtype is torch.bfloat16 and flat.is_cuda
+        if bf16:
             from ._lib import check, lib, ptr, stream_ptr
             h = self.staging(flat)[a:b]
             if not mirrored:        # (mirrored: the engine's weight-gradient GEMMs wrote the bf16 copy themselves: vlt5_step.grads_bf16)
                 check(lib().vlt5_cast_bf16(ptr(t), ptr(h), b - a, stream_ptr()), "vlt5_cast_bf16")
-            dist.all_reduce(h, group=self.group)
+            wire = h
+        else:
+            wire = t
+        if self.algo == "allreduce":
+            dist.all_reduce(wire, group=self.group)
+        else:
+            ca, cb = self.chunk(a, b)
+            dist.reduce_scatter_tensor(wire[ca - a:cb - a], wire, group=self.group)
+            if not bf16 and self.average:
+                wire[ca - a:cb - a].div_(self.world)      # (bf16 chunks are scaled by the kernels that read them: grad_scale)
+            self._slices_done.append((a, b))
+            return
+        if bf16:
             if not defer:
                 check(lib().vlt5_cast_f32(ptr(h), ptr(t), b - a, self.grad_scale, stream_ptr()), "vlt5_cast_f32")
-            return
-        dist.all_reduce(t, group=self.group)
-        if self.average:
+        elif self.average:
             t.div_(self.world)
 
+    def _allgather_grads(self, flat):
+        """Second half of rs_ag (and the fall-back of zero1 without a sharded optimizer): every rank receives every chunk."""
+        wire = self._wire(flat)
+        bf16 = wire is not flat
+        ctx = torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else _null()
+        with ctx:
+            for a, b in self._slices_done:
+                ca, cb = self.chunk(a, b)
+                dist.all_gather_into_tensor(wire[a:b], wire[ca:cb], group=self.group)
+                if bf16:
+                    if not (self.defer_cast_back and self.grad_dtype is torch.bfloat16):
+                        from ._lib import check, lib, ptr, stream_ptr
+                        check(lib().vlt5_cast_f32(ptr(wire[a:b]), ptr(flat[a:b]), b - a, self.grad_scale, stream_ptr()), "vlt5_cast_f32")
+        self._slices_done = []
+        self.shards_valid = False
+
     def reduce_range(self, model, events, lo, hi, final=False, mirrored=False):
-        """Issue the all-reduces of buckets [lo, hi) on the comm stream: consecutive buckets are merged up to `bucket_bytes`, each
+        """Issue the collectives of buckets [lo, hi) on the comm stream: consecutive buckets are merged up to `bucket_bytes`, each
         merged slice goes after the event of its last bucket.  `final`: this call completes the gradient buffer."""
         flat = model._flat_grad
         defer = self.defer_cast_back and self.grad_dtype is torch.bfloat16
         with torch.cuda.stream(self.comm_stream):
-            start = lo
-            for b in range(lo, hi):
-                size = (self.bucket_end[b] - self.bucket_start[start]) * 4
-                if size >= self.bucket_bytes or b == hi - 1:
-                    self.comm_stream.wait_event(events[b])
-                    self._allreduce_slice(flat, self.bucket_start[start], self.bucket_end[b], defer=defer, mirrored=mirrored)
-                    start = b + 1
+            for a, b, first, last in self.slices_of(lo, hi):
+                self.comm_stream.wait_event(events[last])
+                self._reduce_slice(flat, a, b, defer=defer, mirrored=mirrored)
         if final:
             self.g16_valid = defer
 
     def finish(self):
+        """End of backward.  allreduce: nothing left; rs_ag (or zero1 without its optimizer): all-gather the reduced chunks;
+        zero1: the chunks stay as they are for the sharded optimizer step."""
+        if self.algo != "allreduce":
+            if self.algo == "zero1" and self.sharded_optimizer:
+                self.shards_valid = True
+            else:
+                self._allgather_grads(self.module._flat_grad)
         torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def reduce_flat(self, flat):
-        """Non-overlapped path (gradient accumulation into a temporary buffer, or CPU/gloo tests)."""
+        """Non-overlapped path (gradient accumulation into a temporary buffer, or CPU/gloo tests): one all-reduce of everything."""
         end = self.bucket_end[-1]
         self.g16_valid = False
-        self._allreduce_slice(flat, 0, end)
+        self.shards_valid = False
+        algo, self.algo = self.algo, "allreduce"
+        try:
+            self._reduce_slice(flat, 0, end)
+        finally:
+            self.algo = algo
+
+    # ---- zero1: parameters after the sharded update ---------------------------------------------------
+    def owned_ranges(self):
+        """This rank's chunk of every slice reduce-scattered by the last backward: [(a, b)] in flat elements."""
+        return [self.chunk(a, b) for a, b in self._slices_done]
+
+    def allgather_updated(self, model, slices, main_event):
+        """After the sharded optimizer updated chunk `rank` of `slices` (list of (a, b)): all-gather the chunks of the bf16 shadow
+        (layer buckets) or of the f32 master + shadow (last bucket) on the comm stream, behind `main_event` (recorded on the
+        optimizer's stream after the update of these slices).  Returns nothing; the caller records the per-bucket events."""
+        last_a = self.bucket_start[-1]
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(main_event)
+            for a, b in slices:
+                ca, cb = self.chunk(a, b)
+                if a >= last_a:      # embeddings / norm weights / visual embedding: the kernels read the f32 master
+                    dist.all_gather_into_tensor(model._flat[a:b], model._flat[ca:cb], group=self.group)
+                dist.all_gather_into_tensor(model._flat_bf16[a:b], model._flat_bf16[ca:cb], group=self.group)
+
+    def materialize_params(self, model=None):
+        """zero1: make the f32 master complete on this rank (all-gather of every rank's chunks); collective -- every rank calls it
+        (state_dict() / flat_params() / checkpointing do)."""
+        if not self.params_sharded:
+            return
+        model = model or self.module
+        model.sync_optimizer()
+        last_a = self.bucket_start[-1]
+        for a, b in self._param_slices:
+            if a >= last_a:
+                continue            # already gathered in f32 every step
+            ca, cb = self.chunk(a, b)
+            dist.all_gather_into_tensor(model._flat[a:b], model._flat[ca:cb], group=self.group)
+        self.params_sharded = False
+        model._bf16_version = model._flat._version     # the shadow already equals bf16(master) everywhere
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

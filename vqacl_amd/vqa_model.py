@@ -40,13 +40,14 @@ class VLT5VQA(VLT5):
             proto_beta=proto_beta,
             return_dict=True,
             scores=batch["scores"],          # fuses the reduction of vqa_model.py:46-54 into the engine
+            _alias_workspace=True,           # no 51 MB copy of the logits per step: only the two small tensors below are handed on
         )
         assert "loss" in output
         B, Lt = lm_labels.size()
         result = {"loss": output["loss_reduced"]}
-        result["encoder_hidden_states"] = output["encoder_hidden_states"]
+        result["encoder_hidden_states"] = output["encoder_hidden_states"].clone()      # owned, like the reference's (vqa_model.py:58)
         result["BL"] = (B, Lt)
-        result["encoder_attention_mask"] = output["encoder_attention_mask"]
+        result["encoder_attention_mask"] = output["encoder_attention_mask"].clone()
         return result
 
     @torch.no_grad()
@@ -54,9 +55,23 @@ class VLT5VQA(VLT5):
         """Greedy decoding (the reference forwards no generation kwargs, so `--num_beams` is ignored: vqa_model.py:112-116).
         The encoder and the prototype retrieval run once; every further token is ONE incremental decoder step over a
         key/value cache (`vlt5_decoder_step`)."""
+        from ._lib import Vlt5Error
+        if getattr(self.cfg, "classifier", False):
+            # vqa_model.py:81-108: a discriminative `answer_head` over the decoder state -- no launch script of the reference
+            # enables it (`--classifier` is never passed) and the engine has no such head
+            raise NotImplementedError("config.classifier=True (answer_head classification) is not part of the engine; "
+                                      "the reference's scripts use the generative path")
+        # the reference forwards **kwargs to HF `generate`; the engine decodes greedily and says so instead of dropping options
+        allowed = {"max_length", "num_beams", "eos_token_id", "use_cache", "do_sample", "early_stopping"}
+        unknown = set(kwargs) - allowed
+        if unknown:
+            raise Vlt5Error(f"test_step: unsupported generation arguments {sorted(unknown)} (greedy decoding only)")
+        if kwargs.get("num_beams") not in (None, 1) or kwargs.get("do_sample"):
+            raise Vlt5Error("test_step: only greedy decoding is implemented (num_beams=1, do_sample=False) -- the reference's "
+                            "Trainer.predict passes no generation arguments either (vqacl.py:594)")
         self.eval()
-        token_ids = self.greedy_generate(batch["input_ids"], _vis_inputs(batch),
-                                         max_length=kwargs.get("max_length", 20))
+        token_ids = self.greedy_generate(batch["input_ids"], _vis_inputs(batch), max_length=kwargs.get("max_length", 20),
+                                         eos_token_id=kwargs.get("eos_token_id", 1), use_cache=kwargs.get("use_cache", True))
         result = {"token_ids": token_ids}
         if self.tokenizer is not None:
             result["pred_ans"] = self.tokenizer.batch_decode(token_ids, skip_special_tokens=True)
