@@ -127,6 +127,28 @@ typedef struct {
 int vlt5_attn_fwd(const vlt5_attn_desc* d, void* stream);
 int vlt5_attn_bwd(const vlt5_attn_desc* d, void* stream);
 
+/* ---- fused encoder self-attention (north star "fused attention kernel") --------------------------------------------
+ * vlt5_qkv_attn_fwd: ONE kernel for the q|k|v projection of LN(x) and the attention core (csrc/enc_attn.hip): a workgroup takes
+ * two samples x two heads (128 rows x 384 projection columns on MFMA, then the four 64x64 cores out of LDS), q/k/v only go to
+ * HBM once for the backward.  Replaces nn.Linear q/k/v + matmul/softmax/dropout/matmul of HF T5Attention.forward for the encoder
+ * (VL-T5/src/modeling_t5_our.py:282-293).  d_kv = 64, H even, S <= 64, d_model % 64 == 0; `core` as for vlt5_attn_fwd with
+ * q/k/v = qkv_bf16 + {0, H*64, 2*H*64}, token stride 3*H*64, sample stride S*3*H*64, Tq = Tk = S.  Bit-identical to
+ * vlt5_gemm_bf16 + vlt5_attn_fwd. */
+int vlt5_qkv_attn_fwd(const void* xn_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model, void* stream);
+/* the whole sublayer: x_out = x + dropout(o(attention(LN(x)))) -- HF T5LayerSelfAttention.forward; norm + fused kernel + output
+ * projection (dropout + residual in its epilogue); xn / rstd / qkv / ctx / lse are left for the backward */
+typedef struct {
+    const float* x; const float* ln_w;               /* f32 [B*S, d_model] residual stream in, norm weight [d_model] */
+    const void* wqkv_bf16; const void* wo_bf16;      /* bf16 [3*H*64, d_model] (q|k|v rows), [d_model, H*64] */
+    float* x_out;                                    /* f32 [B*S, d_model] */
+    void* xn_bf16; float* rstd; void* qkv_bf16; void* ctx_bf16; float* lse;   /* saved: [B*S,d], [B*S], [B*S,3*H*64], [B*S,H*64], [B,H,S] */
+    const float* bias; int bias_q, bias_k;           /* f32 [H,bias_q,bias_k] relative-position bias block, or NULL */
+    const float* key_mask; float mask_value;         /* f32 [B,S] 1 = keep, adds (1-m)*mask_value */
+    int B, S, H, d_model; float eps;
+    float drop_p; uint32_t seed_probs, seed_out;     /* dropout on the probabilities / on the sublayer output */
+} vlt5_enc_attn_desc;
+int vlt5_enc_attn_fwd(const vlt5_enc_attn_desc* d, void* stream);
+
 /* ---- relative position bias: HF T5Attention.compute_bias / _relative_position_bucket ---------
  * The integer bucket table lut[Lq*Lk] is computed on the host (vqacl_amd/buckets.py, bit-exact
  * with the library); the kernel gathers table[lut[i,j], h] into bias[h,i,j]. */

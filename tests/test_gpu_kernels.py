@@ -496,9 +496,28 @@ def test_ffn_layer_vs_hf_golden(dev, case):
         gWi = torch.cat([G[case + "_g__DenseReluDense__wi_0__weight"], G[case + "_g__DenseReluDense__wi_1__weight"]])
     else:
         gWi = G[case + "_g__DenseReluDense__wi__weight"]
-    close_norm(dWi, gWi, 4e-2, 1e-1, f"{case} dWi vs HF")
-    close_norm(dw, G[case + "_g__layer_norm__weight"], 4e-2, 1e-1, f"{case} norm weight grad vs HF")
-    close_norm(dx, G[case + "_gx"].reshape(-1, d), 4e-2, 1e-1, f"{case} input grad vs HF")
+    # ReLU: the gate (pre-activation > 0) is a step function, so a pre-activation inside the bf16 error band of zero may gate
+    # differently than in the f32 module -- an O(1) change of that entry's gradient, visible with only 24 rows to average over.
+    # Such flips must be few and confined to the band; the arithmetic itself is held to the tight tolerance against the f32
+    # gradients recomputed with the kernel's own gate.
+    flips = 0
+    if not gated:
+        x32, w32 = G[case + "_x"].reshape(-1, d), G[case + "_layer_norm__weight"]
+        xn32 = w32 * (x32 * torch.rsqrt(x32.pow(2).mean(-1, keepdim=True) + 1e-6))
+        Wi32, Wo32 = G[case + "_DenseReluDense__wi__weight"], G[case + "_DenseReluDense__wo__weight"]
+        pre = xn32 @ Wi32.t()
+        mine = h.float().cpu() > 0
+        flipped = mine != (pre > 0)
+        flips = int(flipped.sum())
+        assert flips <= 0.01 * pre.numel() and float(pre[flipped].abs().max() if flips else 0.0) < 3e-2 * float(pre.abs().max()), flips
+        gy32 = G[case + "_gy"].reshape(-1, d)
+        dh32 = (gy32 @ Wo32) * mine
+        close_norm(dWi, dh32.t() @ xn32, 4e-2, 1e-1, f"{case} dWi vs f32 with the kernel's gate")
+        close_norm(dxn, dh32 @ Wi32, 4e-2, 1e-1, f"{case} dxn vs f32 with the kernel's gate")
+    fro, mx = (4e-2, 1e-1) if flips == 0 else (1.5e-1, 5e-1)
+    close_norm(dWi, gWi, fro, mx, f"{case} dWi vs HF ({flips} gate flips)")
+    close_norm(dw, G[case + "_g__layer_norm__weight"], fro, mx, f"{case} norm weight grad vs HF ({flips} gate flips)")
+    close_norm(dx, G[case + "_gx"].reshape(-1, d), fro, mx, f"{case} input grad vs HF ({flips} gate flips)")
 
 
 def test_gated_gelu_activation_kernels(dev):

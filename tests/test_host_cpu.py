@@ -33,12 +33,12 @@ def test_struct_sizes_match_the_c_side(built, tmp_path):
     """Compile a tiny C program against the header and compare sizeof() with the ctypes mirrors."""
     import subprocess
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "vlt5_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(vlt5_gemm_desc), '
-                   'sizeof(vlt5_attn_desc), sizeof(vlt5_config), sizeof(vlt5_step));return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include "vlt5_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(vlt5_gemm_desc), '
+                   'sizeof(vlt5_attn_desc), sizeof(vlt5_config), sizeof(vlt5_step), sizeof(vlt5_enc_attn_desc));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert sizes == [C.sizeof(built.GemmDesc), C.sizeof(built.AttnDesc), C.sizeof(built.Config), C.sizeof(built.Step)]
+    assert sizes == [C.sizeof(built.GemmDesc), C.sizeof(built.AttnDesc), C.sizeof(built.Config), C.sizeof(built.Step), C.sizeof(built.EncAttnDesc)]
 
 
 def test_bucket_tables_bit_exact_vs_library_golden():

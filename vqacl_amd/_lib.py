@@ -37,6 +37,13 @@ class AttnDesc(C.Structure):
                 ("dbias", vp)]
 
 
+class EncAttnDesc(C.Structure):
+    _fields_ = [("x", vp), ("ln_w", vp), ("wqkv_bf16", vp), ("wo_bf16", vp), ("x_out", vp), ("xn_bf16", vp), ("rstd", vp),
+                ("qkv_bf16", vp), ("ctx_bf16", vp), ("lse", vp), ("bias", vp), ("bias_q", c_i), ("bias_k", c_i), ("key_mask", vp),
+                ("mask_value", c_f), ("B", c_i), ("S", c_i), ("H", c_i), ("d_model", c_i), ("eps", c_f), ("drop_p", c_f),
+                ("seed_probs", c_u32), ("seed_out", c_u32)]
+
+
 class GemmTimingRec(C.Structure):
     _fields_ = [("M", c_i), ("N", c_i), ("K", c_i), ("batch", c_i), ("tile_m", c_i), ("tile_n", c_i), ("a_kmajor", c_i),
                 ("b_kmajor", c_i), ("splits", c_i), ("workgroups", c_i), ("ms", c_f)]
@@ -79,6 +86,8 @@ PROTOTYPES = {
     "vlt5_colsum_multi": (c_i, [vp, vp, C.POINTER(c_ll), C.POINTER(c_i), c_i, c_i, c_i, vp]),
     "vlt5_layernorm_bwd_blocks": (c_i, [c_i]),
     "vlt5_attn_fwd": (c_i, [C.POINTER(AttnDesc), vp]),
+    "vlt5_qkv_attn_fwd": (c_i, [vp, vp, vp, C.POINTER(AttnDesc), c_i, vp]),
+    "vlt5_enc_attn_fwd": (c_i, [C.POINTER(EncAttnDesc), vp]),
     "vlt5_attn_bwd": (c_i, [C.POINTER(AttnDesc), vp]),
     "vlt5_relbias_build": (c_i, [vp, vp, vp, c_i, c_i, c_i, c_i, vp]),
     "vlt5_relbias_bwd": (c_i, [vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_i, c_i, vp]),

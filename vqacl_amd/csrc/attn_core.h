@@ -1,0 +1,211 @@
+// Device-side building blocks of the T5 attention core (Tq, Tk <= 64, d_kv <= 64), shared by the stand-alone kernels (attn.hip)
+// and the fused encoder attention kernels (enc_attn.hip): natural [64][TS] LDS tiles, swapped-operand score MFMAs, in-register
+// softmax over 4-lane groups, transposed fragments through ds_read_b64_tr_b16.  Layout notes at the top of attn.hip.
+#pragma once
+#include "common.h"
+#include "vlt5_hip.h"
+
+namespace vlt5attn {
+
+constexpr int TS = 72;                 // LDS row stride in elements (64 + 8 pad) -> 144 B, 16-byte aligned rows
+constexpr int TILE_BYTES = 64 * TS * 2;
+
+struct AttnArgs {
+    const bf16_t *q, *k, *v;
+    long long q_sb, q_st, k_sb, k_st, v_sb, v_st;
+    bf16_t* ctx; long long o_sb, o_st;
+    float* lse;
+    const float* bias; int bias_q, bias_k;
+    const float* key_mask; float mask_value;
+    int causal;
+    int B, H, Tq, Tk, dk;
+    uint32_t drop_thr, drop_seed;
+    const bf16_t* d_ctx; long long do_sb, do_st;
+    bf16_t *dq, *dk_, *dv; long long dq_sb, dq_st, dk_sb, dk_st, dv_sb, dv_st;
+    float* dbias;
+};
+
+// stage a [T x dk] bf16 matrix (row stride st) into a natural [64][TS] LDS tile (zero filled outside T x dk)
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, long long st, int T, int dk, bf16_t* nat, int tid) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int c = tid + it * 256;
+        int row = c >> 3, dc = c & 7;
+        uint4 z = make_uint4(0, 0, 0, 0);
+        if (row < T && dc * 8 < dk) z = *reinterpret_cast<const uint4*>(src + (long long)row * st + dc * 8);
+        *reinterpret_cast<uint4*>(nat + row * TS + dc * 8) = z;
+    }
+}
+
+// the same in two halves, so that the loads of ALL tiles of a workgroup are in flight together before the first LDS store waits
+struct TileRegs { uint4 v[2]; };
+__device__ __forceinline__ void tile_load(const bf16_t* __restrict__ src, long long st, int T, int dk, int tid, TileRegs& r) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int c = tid + it * 256;
+        int row = c >> 3, dc = c & 7;
+        uint4 z = make_uint4(0, 0, 0, 0);
+        if (row < T && dc * 8 < dk) z = *reinterpret_cast<const uint4*>(src + (long long)row * st + dc * 8);
+        r.v[it] = z;
+    }
+}
+__device__ __forceinline__ void tile_store(bf16_t* nat, int tid, const TileRegs& r) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int c = tid + it * 256;
+        *reinterpret_cast<uint4*>(nat + (c >> 3) * TS + (c & 7) * 8) = r.v[it];
+    }
+}
+
+__device__ __forceinline__ bf16x8_t lds_frag(const bf16_t* tile, int row, int chunk) {     // 8 consecutive elements of a row
+    return *reinterpret_cast<const bf16x8_t*>(tile + row * TS + chunk * 8);
+}
+// Transposed fragments straight from a NATURAL tile T[k][r] with the gfx950 transpose read (ds_read_b64_tr_b16): within a
+// 16-lane group, lane i points at T[k0 + (i>>2)][r0 + 4*(i&3)] and receives T[k0 .. k0+3][r0 + i].
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ s16x4_t tr4(const bf16_t* tile, int k0, int r0, int lane) {
+    const int i = lane & 15;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(tile + (k0 + (i >> 2)) * TS + r0 + 4 * (i & 3)));
+}
+__device__ __forceinline__ bf16x8_t join8(s16x4_t lo, s16x4_t hi) {
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+// rows r0..r0+15 of T^T, k-slots in the "P slot" pattern of lane group g: {32kk+4g .. +3, 32kk+16+4g .. +3}
+__device__ __forceinline__ bf16x8_t frag_tr_slots(const bf16_t* tile, int r0, int kk, int lane) {
+    const int g = lane >> 4;
+    return join8(tr4(tile, kk * 32 + 4 * g, r0, lane), tr4(tile, kk * 32 + 16 + 4 * g, r0, lane));
+}
+// rows r0..r0+15 of T^T, k = 32*ks + 8g .. +7 (the standard MFMA operand order)
+__device__ __forceinline__ bf16x8_t frag_tr_std(const bf16_t* tile, int r0, int ks, int lane) {
+    const int g = lane >> 4;
+    return join8(tr4(tile, ks * 32 + 8 * g, r0, lane), tr4(tile, ks * 32 + 8 * g + 4, r0, lane));
+}
+__device__ __forceinline__ bf16x8_t pack_slots(const float (&lo)[4], const float (&hi)[4]) {
+    union { uint32_t u[4]; bf16x8_t v; } r;
+    r.u[0] = pack_bf16x2(lo[0], lo[1]); r.u[1] = pack_bf16x2(lo[2], lo[3]);
+    r.u[2] = pack_bf16x2(hi[0], hi[1]); r.u[3] = pack_bf16x2(hi[2], hi[3]);
+    return r.v;
+}
+
+// what is added to the raw scores of this lane's 16 elements: relative-position bias + key mask + causal mask, -inf beyond Tk.
+// Depends on nothing in LDS, so it is requested BEFORE the tiles are staged: its global-memory round trip overlaps the staging
+// loads instead of following the Q.K^T MFMAs (one round trip less on the critical path of a latency-bound kernel).
+__device__ __forceinline__ void score_addend(const AttnArgs& p, int b, int h, int i0, int lane, float (&add)[4][4]) {
+    const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = jb * 16 + g * 4 + r;
+            float v = 0.f;
+            if (j < p.Tk) {
+                if (p.bias && i < p.bias_q && j < p.bias_k) v += p.bias[((size_t)h * p.bias_q + i) * p.bias_k + j];
+                if (p.key_mask) v += (1.0f - p.key_mask[(size_t)b * p.Tk + j]) * p.mask_value;
+                if (p.causal && j > i) v += -10000.0f;
+            } else {
+                v = -INFINITY;
+            }
+            add[jb][r] = v;
+        }
+}
+
+// scores of this wave's 16 query rows against all 64 key slots, + the addend above; s[jb][r] in the swapped layout
+template <bool DK64>
+__device__ __forceinline__ void scores_16x64(const AttnArgs& p, const bf16_t* Qs, const bf16_t* Ks, int b, int h, int i0,
+                                             int lane, const float (&add)[4][4], float (&s)[4][4]) {
+    const int lr = lane & 15, g = lane >> 4;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int nks = DK64 ? 2 : (p.dk > 32 ? 2 : 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        if (ks >= nks) break;
+        bf16x8_t fq = lds_frag(Qs, i0 + lr, ks * 4 + g);
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            bf16x8_t fk = lds_frag(Ks, jb * 16 + lr, ks * 4 + g);
+            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq, acc[jb], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[jb][r] = (add[jb][r] == -INFINITY) ? -INFINITY : acc[jb][r] + add[jb][r];
+}
+
+__device__ __forceinline__ float quad_lane_sum(float v) {     // the 4 lanes sharing a query row: l, l^16, l^32, l^48
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float quad_lane_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+
+// one wave, query rows i0 .. i0+15 of head (b, h): scores -> softmax (+ saved log-sum-exp) -> dropout -> P.V -> ctx rows; Q/K/V are the
+// staged natural tiles of that head, `add` the score addend of these rows (score_addend)
+template <bool DK64>
+__device__ __forceinline__ void attn_fwd_rows(const AttnArgs& p, const bf16_t* Qs, const bf16_t* Ks, const bf16_t* Vs, int b, int h,
+                                              int i0, int lane, const float (&add)[4][4]) {
+    const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
+
+    float s[4][4];
+    scores_16x64<DK64>(p, Qs, Ks, b, h, i0, lane, add, s);
+    float m = -INFINITY;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, s[jb][r]);
+    m = quad_lane_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s[jb][r] = expf(s[jb][r] - m); sum += s[jb][r]; }
+    sum = quad_lane_sum(sum);
+    const float inv = 1.0f / sum;
+    if (g == 0 && i < p.Tq && p.lse) p.lse[((size_t)b * p.H + h) * p.Tq + i] = m + logf(sum);
+    const float dsc = drop_scale(p.drop_thr);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = s[jb][r] * inv;
+            if (p.drop_thr) {
+                const int j = jb * 16 + g * 4 + r;
+                uint32_t idx = (uint32_t)((((size_t)b * p.H + h) * p.Tq + i) * p.Tk + j);
+                v = drop_keep(p.drop_seed, idx, p.drop_thr) ? v * dsc : 0.f;
+            }
+            s[jb][r] = v;
+        }
+    bf16x8_t pf[2] = {pack_slots(s[0], s[1]), pack_slots(s[2], s[3])};
+    const int ndb = DK64 ? 4 : (p.dk + 15) / 16;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        if (db >= ndb) break;
+        f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk * 32 < p.Tk) {
+                bf16x8_t fv = frag_tr_slots(Vs, db * 16, kk, lane);        // V^T[d][j] gathered from the natural V tile
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[kk], o, 0, 0, 0);
+            }
+        }
+        const int d = db * 16 + g * 4;
+        if (i < p.Tq && d < p.dk) {
+            uint2 pk;
+            pk.x = pack_bf16x2(o[0], o[1]);
+            pk.y = pack_bf16x2(o[2], o[3]);
+            *reinterpret_cast<uint2*>(p.ctx + b * p.o_sb + (long long)i * p.o_st + (long long)h * p.dk + d) = pk;
+        }
+    }
+}
+
+}  // namespace vlt5attn

@@ -1,0 +1,248 @@
+// Fused encoder self-attention kernels (gfx950): the q|k|v projection of a (sample pair, head pair) and the attention core
+// of its four (sample, head) problems in ONE workgroup, q/k/v never leaving the chip between the two.
+//
+// Reference op sequence being replaced: VL-T5/src/modeling_t5_our.py:282-293 -> HF T5LayerSelfAttention / T5Attention.forward
+// (q, k, v = Linear(LN(x)); scores = q k^T (no 1/sqrt(d)) + position_bias + mask; softmax in f32; dropout; . v).
+//
+// Why this split: an encoder sample has S = L + V <= 56 tokens, a head 64 columns.  A workgroup needs
+// M >= 128 rows to make a CU's MFMA rate (4 kFLOP/clk) from the 64 B/clk it can pull into LDS, so it takes TWO samples
+// (2 x 64 padded rows); 256 CUs want ~240 workgroups, so it takes TWO heads: 384 weight rows (q|k|v x 2 heads x 64) x d_model.
+//   grid  = ceil(B/2) x H/2 workgroups (B = 80, H = 12: 240), 512 threads = 8 waves as 2 (samples) x 4 (96 columns each)
+//   phase 1  [128 x d] . [384 x d]^T on MFMA 16x16x32 bf16, BK = 64, two LDS stages filled by global_load_lds (the same
+//            interleaved k-step as the 8-wave GEMM: gemm_kernel.h), accumulators 4 x 6 fragments per wave
+//   phase 2  accumulators -> bf16 natural tiles Q/K/V[sample][head] in LDS (over the retired stages); q|k|v rows go out to HBM
+//            once, coalesced, for the backward (attention backward + weight gradient)
+//   phase 3  attention core out of LDS, two waves per (sample, head): scores in registers, softmax over 4-lane groups,
+//            dropout, P.V with V^T gathered by ds_read_b64_tr_b16 (attn_core.h) -> ctx rows, row log-sum-exp
+// The output projection stays a GEMM of its own: fusing it would split its K = H*64 reduction over the H/2 head pairs and
+// trade one 16 us launch for 6 f32 slabs of the residual stream (82 MB written + read per sublayer).
+//
+// Results are bit-identical to vlt5_gemm_bf16 + vlt5_attn_fwd on the same inputs (same k order, same MFMA, same rounding
+// points, same dropout counters): tests/test_gpu_kernels.py::test_fused_qkv_attention_equals_the_unfused_kernels.
+#include "gemm_kernel.h"
+#include "attn_core.h"
+#include <string.h>
+
+namespace {
+
+using vlt5gemm::BK;
+using vlt5gemm::lds_off;
+using vlt5gemm::lds_ptr_t;
+using vlt5attn::AttnArgs;
+using vlt5attn::TILE_BYTES;
+using vlt5attn::TS;
+
+struct QkvAttnArgs {
+    const bf16_t* xn;          // [B*S, d] bf16: LN(x)
+    const bf16_t* wqkv;        // [3*inner, d] bf16: q rows | k rows | v rows, head h at rows h*64 .. h*64+63 of each part
+    bf16_t* qkv;               // [B*S, 3*inner] bf16 out
+    AttnArgs at;               // core: q/k/v strides describe `qkv`; ctx, lse, bias, key_mask, dropout
+    int B, S, H, d;
+};
+
+constexpr int FBM = 128, FBN = 384, FWM = 2, FWN = 4, FNT = 512;
+constexpr int FTM = FBM / FWM, FTN = FBN / FWN;          // 64 x 96 per wave
+constexpr int FFM = FTM / 16, FFN_ = FTN / 16;           // 4 x 6 fragments
+constexpr int A_BYTES = FBM * BK * 2, B_BYTES = FBN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;   // 16 + 48 = 64 KB
+constexpr int PA = FBM * 8 / FNT, PB = FBN * 8 / FNT, LPT = PA + PB;                             // 2 + 6 DMA pieces per wave per k-tile
+constexpr int FUSED_LDS = 2 * STAGE_BYTES;
+static_assert(12 * TILE_BYTES <= FUSED_LDS, "the Q/K/V tiles of 2 samples x 2 heads overlay the retired stages");
+
+__global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / FWN, wn = wave % FWN;
+    const int lrow = lane & 15, lg = lane >> 4;
+    const int HP = p.H >> 1, inner = p.H * 64;
+    // XCD-aware order: workgroup b runs on XCD b % 8; every XCD gets one contiguous run of (sample pair, head pair) tiles, head
+    // pair fastest, so the A rows of a sample pair are fetched into ONE L2 and the 6 weight slices (3.5 MB) stay resident in each
+    const int ntiles = gridDim.x;
+    int tile_id;
+    {
+        const int b = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = b & 7, loc = b >> 3;
+        tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int b0 = (tile_id / HP) * 2, h0 = (tile_id % HP) * 2;
+
+    // per-lane source of each DMA piece at k = 0 (the swizzle of the LDS image is applied to the SOURCE chunk: gemm_kernel.h)
+    const bf16_t* src[LPT];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int c = tid + i * FNT, row = c >> 3, kc = (c & 7) ^ (row & 7);
+        const int bb = min(b0 + (row >> 6), p.B - 1), t = min(row & 63, p.S - 1);        // padding rows repeat a valid row
+        src[i] = p.xn + ((size_t)bb * p.S + t) * p.d + kc * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int c = tid + i * FNT, row = c >> 3, kc = (c & 7) ^ (row & 7);
+        const int grow = (row >> 7) * inner + h0 * 64 + (row & 127);
+        src[PA + i] = p.wqkv + (size_t)grow * p.d + kc * 8;
+    }
+    const int wave_base = tid & ~63;
+    auto piece = [&](int kt, int s, int pc) __attribute__((always_inline)) {
+        char* dst = smem + s * STAGE_BYTES + (pc < PA ? 0 : A_BYTES) + ((pc < PA ? pc : pc - PA) * FNT + wave_base) * 16;
+        __builtin_amdgcn_global_load_lds(src[pc] + (size_t)kt * BK, (lds_ptr_t)dst, 16, 0, 0);
+    };
+    auto ldA = [&](const char* at, int i, int ks) __attribute__((always_inline)) -> bf16x8_t {
+        return *reinterpret_cast<const bf16x8_t*>(at + lds_off(wm * FTM + i * 16 + lrow, ks * 4 + lg));
+    };
+    auto ldB = [&](const char* bt, int j, int ks) __attribute__((always_inline)) -> bf16x8_t {
+        return *reinterpret_cast<const bf16x8_t*>(bt + lds_off(wn * FTN + j * 16 + lrow, ks * 4 + lg));
+    };
+
+    f32x4_t acc[FFM][FFN_];
+#pragma unroll
+    for (int i = 0; i < FFM; ++i)
+#pragma unroll
+        for (int j = 0; j < FFN_; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // ---- phase 1: the interleaved k-step of the 8-wave GEMM (kstep_big in gemm_kernel.h) on a 128 x 384 tile ---------------
+    const int nk = p.d / BK;
+#pragma unroll
+    for (int pc = 0; pc < LPT; ++pc) piece(0, 0, pc);
+    int stage = 0;
+    for (int it = 0; it < nk; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int kt_pf = min(it + 1, nk - 1), s_pf = stage ^ 1;        // the last step re-requests the final k-tile (branch-free)
+        const char* at = smem + stage * STAGE_BYTES;
+        const char* bt = at + A_BYTES;
+        bf16x8_t fa0[FFM], fb0[FFN_], fa1[FFM], fb1[FFN_];
+#pragma unroll
+        for (int i = 0; i < FFM; ++i) fa0[i] = ldA(at, i, 0);
+#pragma unroll
+        for (int j = 0; j < FFN_; ++j) fb0[j] = ldB(bt, j, 0);
+#pragma unroll
+        for (int i = 0; i < FFM; ++i) {
+#pragma unroll
+            for (int j = 0; j < FFN_; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+            fa1[i] = ldA(at, i, 1);
+#pragma unroll
+            for (int j = 0; j < FFN_; ++j)
+                if (j >= vlt5gemm::bfrag_lo<FFM, FFN_>(i) && j < vlt5gemm::bfrag_lo<FFM, FFN_>(i + 1)) fb1[j] = ldB(bt, j, 1);
+#pragma unroll
+            for (int pc = 0; pc < LPT; ++pc)
+                if (vlt5gemm::piece_row<FFM, LPT, true>(pc) == i) piece(kt_pf, s_pf, pc);
+        }
+#pragma unroll
+        for (int i = 0; i < FFM; ++i)
+#pragma unroll
+            for (int j = 0; j < FFN_; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, FFM + FFN_, 0);
+        vlt5gemm::pin_ks0<FFM, FFN_, LPT, 1, 1, true, 0>();
+        vlt5gemm::pin_ks1<FFM, FFN_, LPT, true, 0>();
+        stage ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus prefetch must land before the stages are reused
+    __syncthreads();
+
+    // ---- phase 2: accumulators -> bf16 natural tiles; tile (s, hh, part) at ((s*2 + hh)*3 + part) * TILE_BYTES ---------------
+    auto tile = [&](int s, int hh, int part) __attribute__((always_inline)) -> bf16_t* {
+        return reinterpret_cast<bf16_t*>(smem + ((s * 2 + hh) * 3 + part) * TILE_BYTES);
+    };
+#pragma unroll
+    for (int j = 0; j < FFN_; ++j) {
+        const int n = wn * FTN + j * 16;                       // 16 | 64: a fragment lies inside one (part, head) tile
+        bf16_t* tl = tile(wm, (n >> 6) & 1, n >> 7) + (n & 63) + lg * 4;
+#pragma unroll
+        for (int i = 0; i < FFM; ++i) {
+            uint2 pk;
+            pk.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+            pk.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+            *reinterpret_cast<uint2*>(tl + (i * 16 + lrow) * TS) = pk;
+        }
+    }
+    __syncthreads();
+    // q | k | v rows to HBM (saved for the backward): 12 tiles x S rows x 128 bytes, 16 bytes per lane, whole rows per 8 lanes
+    {
+        const int per_tile = p.S * 8;
+        for (int idx = tid; idx < 12 * per_tile; idx += FNT) {
+            const int ti = idx / per_tile, rem = idx - ti * per_tile, t = rem >> 3, ch = rem & 7;
+            const int s = ti / 6, hh = (ti / 3) & 1, part = ti % 3;
+            if (b0 + s < p.B) {
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + ti * TILE_BYTES + (t * TS + ch * 8) * 2);
+                *reinterpret_cast<uint4*>(p.qkv + ((size_t)(b0 + s) * p.S + t) * (3 * inner) + part * inner + (h0 + hh) * 64 + ch * 8) = v;
+            }
+        }
+    }
+    // ---- phase 3: attention core, two waves per (sample, head), 32 query rows each ------------------------------------------
+    {
+        const int pi = wave >> 1, s = pi >> 1, hh = pi & 1;
+        const int b = b0 + s, h = h0 + hh;
+        if (b >= p.B) return;
+#pragma unroll 1
+        for (int blk = 0; blk < 2; ++blk) {
+            const int i0 = (wave & 1) * 32 + blk * 16;
+            if (i0 >= p.S) break;
+            float add[4][4];
+            vlt5attn::score_addend(p.at, b, h, i0, lane, add);
+            vlt5attn::attn_fwd_rows<true>(p.at, tile(s, hh, 0), tile(s, hh, 1), tile(s, hh, 2), b, h, i0, lane, add);
+        }
+    }
+}
+
+}  // namespace
+
+// q|k|v projection + attention core of one encoder self-attention (the kernel above).  Shapes: d_kv = 64, H even, S <= 64,
+// d_model a multiple of 64; the strides in `core` must describe `qkv` ([B, S, 3*H*64], q | k | v).
+extern "C" int vlt5_qkv_attn_fwd(const void* xn_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model,
+                                 void* stream) {
+    if (!xn_bf16 || !wqkv_bf16 || !qkv_bf16 || !core || !core->ctx) return VLT5_ERR_ARG;
+    if (core->dk != 64 || (core->H & 1) || core->Tq != core->Tk || core->Tq < 1 || core->Tq > 64 || core->B < 1 || d_model < 64) return VLT5_ERR_ARG;
+    if (d_model & 63) return VLT5_ERR_ALIGN;
+    const int inner = core->H * 64, S = core->Tq;
+    const bf16_t* base = (const bf16_t*)qkv_bf16;
+    if (core->q != (const void*)base || core->k != (const void*)(base + inner) || core->v != (const void*)(base + 2 * inner)) return VLT5_ERR_ARG;
+    if (core->q_st != 3 * inner || core->k_st != 3 * inner || core->v_st != 3 * inner) return VLT5_ERR_ARG;
+    if (core->q_sb != (long long)S * 3 * inner || core->k_sb != core->q_sb || core->v_sb != core->q_sb) return VLT5_ERR_ARG;
+    if ((core->o_sb & 3) || (core->o_st & 3)) return VLT5_ERR_ALIGN;
+    QkvAttnArgs a;
+    a.xn = (const bf16_t*)xn_bf16; a.wqkv = (const bf16_t*)wqkv_bf16; a.qkv = (bf16_t*)qkv_bf16;
+    a.B = core->B; a.S = S; a.H = core->H; a.d = d_model;
+    AttnArgs& t = a.at;
+    t.q = base; t.k = base + inner; t.v = base + 2 * inner;
+    t.q_sb = core->q_sb; t.q_st = core->q_st; t.k_sb = core->k_sb; t.k_st = core->k_st; t.v_sb = core->v_sb; t.v_st = core->v_st;
+    t.ctx = (bf16_t*)core->ctx; t.o_sb = core->o_sb; t.o_st = core->o_st; t.lse = core->lse;
+    t.bias = core->bias; t.bias_q = core->bias_q; t.bias_k = core->bias_k;
+    t.key_mask = core->key_mask; t.mask_value = core->mask_value; t.causal = core->causal;
+    t.B = core->B; t.H = core->H; t.Tq = S; t.Tk = S; t.dk = 64;
+    t.drop_thr = core->drop_p > 0.f ? drop_thr16(core->drop_p) : 0u; t.drop_seed = core->drop_seed;
+    t.d_ctx = nullptr; t.do_sb = t.do_st = 0; t.dq = t.dk_ = t.dv = nullptr;
+    t.dq_sb = t.dq_st = t.dk_sb = t.dk_st = t.dv_sb = t.dv_st = 0; t.dbias = nullptr;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS));
+        attr_set = true;
+    }
+    const int grid = ((a.B + 1) / 2) * (a.H / 2);
+    hipLaunchKernelGGL(qkv_attn_fwd_kernel, dim3(grid), dim3(FNT), FUSED_LDS, (hipStream_t)stream, a);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+
+// The whole encoder self-attention sublayer forward (SURVEY 8(b) `vlt5_enc_attn_fwd`; HF T5LayerSelfAttention.forward as called from
+// VL-T5/src/modeling_t5_our.py:282-293):  x_out = x + dropout( o( softmax(q k^T + bias + mask) v ) ),  q|k|v = LN(x) Wqkv^T.
+// Three launches: T5 RMS norm (emits the bf16 operand + rstd), the fused projection + core kernel, the output projection with its
+// dropout + residual epilogue.  Everything the backward needs is left in the caller's buffers.
+extern "C" int vlt5_enc_attn_fwd(const vlt5_enc_attn_desc* d, void* stream) {
+    if (!d || !d->x || !d->ln_w || !d->wqkv_bf16 || !d->wo_bf16 || !d->x_out || !d->xn_bf16 || !d->rstd || !d->qkv_bf16 || !d->ctx_bf16 || !d->lse)
+        return VLT5_ERR_ARG;
+    const int M = d->B * d->S, inner = d->H * 64;
+    int rc = vlt5_layernorm_fwd(d->x, d->ln_w, d->xn_bf16, nullptr, d->rstd, M, d->d_model, d->eps, 0.f, 0, 0, 0, stream);
+    if (rc) return rc;
+    vlt5_attn_desc a;
+    memset(&a, 0, sizeof a);
+    bf16_t* qkv = (bf16_t*)d->qkv_bf16;
+    a.q = qkv; a.k = qkv + inner; a.v = qkv + 2 * inner;
+    a.q_sb = a.k_sb = a.v_sb = (long long)d->S * 3 * inner; a.q_st = a.k_st = a.v_st = 3 * inner;
+    a.ctx = d->ctx_bf16; a.o_sb = (long long)d->S * inner; a.o_st = inner; a.lse = d->lse;
+    a.bias = d->bias; a.bias_q = d->bias_q; a.bias_k = d->bias_k; a.key_mask = d->key_mask; a.mask_value = d->mask_value;
+    a.B = d->B; a.H = d->H; a.Tq = d->S; a.Tk = d->S; a.dk = 64; a.drop_p = d->drop_p; a.drop_seed = d->seed_probs;
+    rc = vlt5_qkv_attn_fwd(d->xn_bf16, d->wqkv_bf16, d->qkv_bf16, &a, d->d_model, stream);
+    if (rc) return rc;
+    vlt5_gemm_desc g;
+    memset(&g, 0, sizeof g);
+    g.A = d->ctx_bf16; g.B = d->wo_bf16; g.C = d->x_out; g.M = M; g.N = d->d_model; g.K = inner; g.lda = inner; g.ldb = inner; g.ldc = d->d_model;
+    g.alpha = 1.f; g.out_f32 = 1; g.resid = d->x; g.ldr = d->d_model; g.drop_p = d->drop_p; g.drop_seed = d->seed_out;
+    return vlt5_gemm_bf16(&g, stream);
+}
