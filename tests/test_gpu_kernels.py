@@ -403,6 +403,47 @@ def test_attention_strided_qkv_and_dropout(dev):
     assert float(c1.float().std()) > 0.01
 
 
+@pytest.mark.parametrize("B,S,H,d,Lb,drop", [(5, 56, 4, 128, 20, 0.0), (80, 56, 12, 768, 20, 0.1), (3, 39, 2, 64, 23, 0.1), (1, 64, 2, 192, 20, 0.0),
+                                              (2, 7, 16, 1024, 5, 0.0)])
+def test_fused_qkv_attention_equals_the_unfused_kernels(dev, B, S, H, d, Lb, drop):
+    """vlt5_qkv_attn_fwd (projection + core in one workgroup per sample pair x head pair) against vlt5_gemm_bf16 + vlt5_attn_fwd on
+    the same inputs: q|k|v rows, context and log-sum-exp bit for bit (same k order, MFMA, rounding points and dropout counters),
+    and the context against an f32 torch reference."""
+    from vqacl_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    inner = H * 64
+    xn = rnd((B * S, d), g).to(BF).to(dev)
+    w = rnd((3 * inner, d), g, d ** -0.5).to(BF).to(dev)
+    bias = rnd((H, Lb, Lb), g).to(dev)
+    km = (torch.rand(B, S, generator=g) > 0.2).float()
+    km[:, Lb:] = 1.0
+    km = km.to(dev)
+    qkv0 = ops.gemm(xn, w, B * S, 3 * inner, d).view(B, S, 3 * inner)
+    ctx0, lse0 = ops.attn_fwd(qkv0[:, :, :inner], qkv0[:, :, inner:2 * inner], qkv0[:, :, 2 * inner:], H, 64, bias=bias, key_mask=km,
+                              mask_value=-10000.0, drop_p=drop, drop_seed=99)
+    qkv1, ctx1, lse1 = ops.qkv_attn_fwd(xn, w, B, S, H, bias=bias, key_mask=km, mask_value=-10000.0, drop_p=drop, drop_seed=99)
+    assert torch.equal(qkv1, qkv0), float((qkv1.float() - qkv0.float()).abs().max())
+    assert torch.equal(lse1, lse0), float((lse1 - lse0).abs().max())
+    assert torch.equal(ctx1, ctx0), float((ctx1.float() - ctx0.float()).abs().max())
+    if drop == 0.0:
+        full = torch.zeros(B, H, S, S, device=dev)
+        full[:, :, :Lb, :Lb] = bias
+        full = full + ((1.0 - km) * -10000.0)[:, None, None, :]
+        q, k, v = (t.float().view(B, S, H, 64).permute(0, 2, 1, 3) for t in (qkv1[:, :, :inner], qkv1[:, :, inner:2 * inner], qkv1[:, :, 2 * inner:]))
+        ref = (torch.softmax(q @ k.transpose(-1, -2) + full, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, S, inner)
+        close(ctx1, ref, 2e-2, 2e-2, "fused context vs f32 reference")
+
+
+def test_fused_qkv_attention_rejects_unsupported_shapes(dev):
+    from vqacl_amd import ops
+    from vqacl_amd._lib import Vlt5Error
+    x = torch.zeros(2 * 8, 64, device=dev, dtype=BF)
+    with pytest.raises(Vlt5Error):
+        ops.qkv_attn_fwd(x, torch.zeros(3 * 3 * 64, 64, device=dev, dtype=BF), 2, 8, 3)         # odd head count
+    with pytest.raises(Vlt5Error):
+        ops.qkv_attn_fwd(torch.zeros(16, 72, device=dev, dtype=BF), torch.zeros(3 * 128, 72, device=dev, dtype=BF), 2, 8, 2)   # d % 64
+
+
 @pytest.mark.parametrize("case", ["ea", "da", "ca"])
 def test_attention_layer_vs_hf_golden(dev, case):
     """Whole T5Attention (q/k/v/o GEMMs + core) against the transformers-5.15 module outputs and gradients."""

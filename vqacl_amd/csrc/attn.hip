@@ -111,21 +111,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
         float dsum = 0.f;
         float pr[4][4], dp[4][4];
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
+        for (int jb = 0; jb < 4; ++jb) {
+            bool kp[4] = {true, true, true, true};
+            if (p.drop_thr)
+                drop_keep4(p.drop_seed, (uint32_t)((((size_t)b * p.H + h) * p.Tq + i) * p.Tk + jb * 16 + g * 4), p.drop_thr, kp);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int j = jb * 16 + g * 4 + r;
-                float pv = (i < p.Tq && j < p.Tk) ? expf(s[jb][r] - lse) : 0.f;
-                float keep = 1.f;
-                if (p.drop_thr) {
-                    uint32_t idx = (uint32_t)((((size_t)b * p.H + h) * p.Tq + i) * p.Tk + j);
-                    keep = drop_keep(p.drop_seed, idx, p.drop_thr) ? dsc : 0.f;
-                }
+                const float pv = (i < p.Tq && j < p.Tk) ? fast_exp(s[jb][r] - lse) : 0.f;
+                const float keep = p.drop_thr ? (kp[r] ? dsc : 0.f) : 1.f;
                 pr[jb][r] = pv;
                 pd[jb][r] = pv * keep;
                 dp[jb][r] = dacc[jb][r] * keep;
                 dsum += dp[jb][r] * pv;
             }
+        }
         dsum = quad_lane_sum(dsum);
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)

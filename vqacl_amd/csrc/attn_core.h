@@ -95,20 +95,32 @@ __device__ __forceinline__ bf16x8_t pack_slots(const float (&lo)[4], const float
 // loads instead of following the Q.K^T MFMAs (one round trip less on the critical path of a latency-bound kernel).
 __device__ __forceinline__ void score_addend(const AttnArgs& p, int b, int h, int i0, int lane, float (&add)[4][4]) {
     const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
+    // branch-free per lane: every load is issued (clamped index) and selected afterwards, so the 32 loads of a block are in flight
+    // together behind ONE wait -- per-element `if (..) v += load` chains serialise into 32 dependent round trips when few waves
+    // share a CU (measured in the fused kernel: 20 k cycles)
+    float bv[4][4], mv[4][4];
+    const bool hb = p.bias != nullptr, hm = p.key_mask != nullptr;            // wave-uniform
+    // (an absent operand reads a dummy word of q instead of branching around its loads: one basic block, one wait)
+    const float* row = hb ? p.bias + ((size_t)h * p.bias_q + min(i, p.bias_q - 1)) * p.bias_k : reinterpret_cast<const float*>(p.q);
+    const float* mrow = hm ? p.key_mask + (size_t)b * p.Tk : reinterpret_cast<const float*>(p.q);
+    const int bk1 = hb ? p.bias_k - 1 : 0, mk1 = hm ? p.Tk - 1 : 0;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bv[jb][r] = row[min(jb * 16 + g * 4 + r, bk1)];
+            mv[jb][r] = mrow[min(jb * 16 + g * 4 + r, mk1)];
+        }
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = jb * 16 + g * 4 + r;
             float v = 0.f;
-            if (j < p.Tk) {
-                if (p.bias && i < p.bias_q && j < p.bias_k) v += p.bias[((size_t)h * p.bias_q + i) * p.bias_k + j];
-                if (p.key_mask) v += (1.0f - p.key_mask[(size_t)b * p.Tk + j]) * p.mask_value;
-                if (p.causal && j > i) v += -10000.0f;
-            } else {
-                v = -INFINITY;
-            }
-            add[jb][r] = v;
+            if (hb && i < p.bias_q && j < p.bias_k) v += bv[jb][r];
+            if (hm) v += (1.0f - mv[jb][r]) * p.mask_value;
+            if (p.causal && j > i) v += -10000.0f;
+            add[jb][r] = (j < p.Tk) ? v : -INFINITY;
         }
 }
 
@@ -168,23 +180,22 @@ __device__ __forceinline__ void attn_fwd_rows(const AttnArgs& p, const bf16_t* Q
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s[jb][r] = expf(s[jb][r] - m); sum += s[jb][r]; }
+        for (int r = 0; r < 4; ++r) { s[jb][r] = fast_exp(s[jb][r] - m); sum += s[jb][r]; }
     sum = quad_lane_sum(sum);
     const float inv = 1.0f / sum;
     if (g == 0 && i < p.Tq && p.lse) p.lse[((size_t)b * p.H + h) * p.Tq + i] = m + logf(sum);
     const float dsc = drop_scale(p.drop_thr);
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
+    for (int jb = 0; jb < 4; ++jb) {
+        bool keep[4] = {true, true, true, true};
+        if (p.drop_thr)
+            drop_keep4(p.drop_seed, (uint32_t)((((size_t)b * p.H + h) * p.Tq + i) * p.Tk + jb * 16 + g * 4), p.drop_thr, keep);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float v = s[jb][r] * inv;
-            if (p.drop_thr) {
-                const int j = jb * 16 + g * 4 + r;
-                uint32_t idx = (uint32_t)((((size_t)b * p.H + h) * p.Tq + i) * p.Tk + j);
-                v = drop_keep(p.drop_seed, idx, p.drop_thr) ? v * dsc : 0.f;
-            }
-            s[jb][r] = v;
+            const float v = s[jb][r] * inv;
+            s[jb][r] = p.drop_thr ? (keep[r] ? v * dsc : 0.f) : v;
         }
+    }
     bf16x8_t pf[2] = {pack_slots(s[0], s[1]), pack_slots(s[2], s[3])};
     const int ndb = DK64 ? 4 : (p.dk + 15) / 16;
 #pragma unroll

@@ -15,16 +15,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;          // one MFMA 
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
-// round-to-nearest-even, NaN kept quiet
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// f32 -> bf16, round to nearest even: the native conversion (clang lowers `(__bf16)x` to v_cvt_pk_bf16_f32 on gfx950, one
+// instruction per PAIR; the integer emulation it replaces cost ~8 VALU instructions per element and dominated every bf16 epilogue)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16_native2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    bf16_native2_t v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 // ---- counter-based dropout mask ---------------------------------------------------------------
 // keep(idx) is a pure function of (seed, idx): forward and backward regenerate the same mask, no
@@ -42,9 +42,23 @@ __host__ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, 
     uint32_t v = (idx & 1u) ? (h >> 16) : (h & 0xffffu);
     return v >= thr16;
 }
+// keep flags of FOUR consecutive elements idx .. idx+3, bit-identical to drop_keep() per element: with an even idx (every call site
+// whose row length is even) the four share two hashes -- half the integer work of the dropout epilogues
+__host__ __device__ __forceinline__ void drop_keep4(uint32_t seed, uint32_t idx, uint32_t thr16, bool (&k)[4]) {
+    if ((idx & 1u) == 0u) {
+        const uint32_t h0 = mix32(((idx >> 1) * 0x9E3779B1u) ^ seed), h1 = mix32((((idx >> 1) + 1u) * 0x9E3779B1u) ^ seed);
+        k[0] = (h0 & 0xffffu) >= thr16; k[1] = (h0 >> 16) >= thr16; k[2] = (h1 & 0xffffu) >= thr16; k[3] = (h1 >> 16) >= thr16;
+    } else {
+        for (int e = 0; e < 4; ++e) k[e] = drop_keep(seed, idx + e, thr16);
+    }
+}
 __host__ __device__ __forceinline__ uint32_t site_seed(uint32_t base, uint32_t site) {
     return mix32(base ^ (site * 0x632BE5ABu + 0x9E3779B9u));
 }
+
+// exp for the softmax paths: v_exp_f32 on x * log2(e) (~1 ulp of the result for the score ranges of a softmax, far below the bf16
+// rounding of the probabilities that follows); expf() expands to ~20 instructions per element and made the attention core VALU-bound
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 
 // ---- wave reductions ----------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

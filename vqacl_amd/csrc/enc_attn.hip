@@ -48,8 +48,13 @@ constexpr int PA = FBM * 8 / FNT, PB = FBN * 8 / FNT, LPT = PA + PB;            
 constexpr int FUSED_LDS = 2 * STAGE_BYTES;
 static_assert(12 * TILE_BYTES <= FUSED_LDS, "the Q/K/V tiles of 2 samples x 2 heads overlay the retired stages");
 
-__global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p) {
+// TL: debug build of the same kernel that records the shader clock of wave 0 at the phase boundaries (vlt5dbg_qkv_attn_timeline)
+template <bool TL>
+__global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsigned long long* tl_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int i) __attribute__((always_inline)) { if (TL && threadIdx.x == 0) tl[i] = __builtin_readcyclecounter(); };
+    stamp(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / FWN, wn = wave % FWN;
     const int lrow = lane & 15, lg = lane >> 4;
@@ -63,6 +68,8 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p) {
         tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     const int b0 = (tile_id / HP) * 2, h0 = (tile_id % HP) * 2;
+    const int pi = wave >> 1, cs = pi >> 1, chh = pi & 1;          // phase 3 roles: two waves per (sample, head)
+    const int cb = min(b0 + cs, p.B - 1), ch = h0 + chh;
 
     // per-lane source of each DMA piece at k = 0 (the swizzle of the LDS image is applied to the SOURCE chunk: gemm_kernel.h)
     const bf16_t* src[LPT];
@@ -101,9 +108,11 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p) {
 #pragma unroll
     for (int pc = 0; pc < LPT; ++pc) piece(0, 0, pc);
     int stage = 0;
+    stamp(1);
     for (int it = 0; it < nk; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (TL && it == 1) stamp(2);
         const int kt_pf = min(it + 1, nk - 1), s_pf = stage ^ 1;        // the last step re-requests the final k-tile (branch-free)
         const char* at = smem + stage * STAGE_BYTES;
         const char* bt = at + A_BYTES;
@@ -134,7 +143,15 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p) {
         stage ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus prefetch must land before the stages are reused
+    stamp(3);
+    // score addends (relative-position bias + key mask) of this wave's two 16-row blocks: requested here (branch-free, all loads in
+    // flight together), their global round trip overlaps the tile hand-over; kept out of the main loop, whose register budget is full
+    float add[2][4][4];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) vlt5attn::score_addend(p.at, cb, ch, (wave & 1) * 32 + blk * 16, lane, add[blk]);
+    stamp(8);
     __syncthreads();
+    stamp(9);
 
     // ---- phase 2: accumulators -> bf16 natural tiles; tile (s, hh, part) at ((s*2 + hh)*3 + part) * TILE_BYTES ---------------
     auto tile = [&](int s, int hh, int part) __attribute__((always_inline)) -> bf16_t* {
@@ -152,34 +169,42 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p) {
             *reinterpret_cast<uint2*>(tl + (i * 16 + lrow) * TS) = pk;
         }
     }
+    stamp(10);
     __syncthreads();
-    // q | k | v rows to HBM (saved for the backward): 12 tiles x S rows x 128 bytes, 16 bytes per lane, whole rows per 8 lanes
+    stamp(4);
+    // q | k | v rows to HBM (saved for the backward): 12 tiles x S rows x 128 bytes; 8 lanes per row, 64 rows per pass
     {
-        const int per_tile = p.S * 8;
-        for (int idx = tid; idx < 12 * per_tile; idx += FNT) {
-            const int ti = idx / per_tile, rem = idx - ti * per_tile, t = rem >> 3, ch = rem & 7;
-            const int s = ti / 6, hh = (ti / 3) & 1, part = ti % 3;
-            if (b0 + s < p.B) {
-                const uint4 v = *reinterpret_cast<const uint4*>(smem + ti * TILE_BYTES + (t * TS + ch * 8) * 2);
-                *reinterpret_cast<uint4*>(p.qkv + ((size_t)(b0 + s) * p.S + t) * (3 * inner) + part * inner + (h0 + hh) * 64 + ch * 8) = v;
+        const int t = tid >> 3, ch8 = (tid & 7) * 8;
+        if (t < p.S) {
+#pragma unroll
+            for (int ti = 0; ti < 12; ++ti) {
+                const int s = ti / 6, hh = (ti / 3) & 1, part = ti % 3;
+                if (b0 + s < p.B) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(smem + ti * TILE_BYTES + (t * TS + ch8) * 2);
+                    *reinterpret_cast<uint4*>(p.qkv + ((size_t)(b0 + s) * p.S + t) * (3 * inner) + part * inner + (h0 + hh) * 64 + ch8) = v;
+                }
             }
         }
     }
-    // ---- phase 3: attention core, two waves per (sample, head), 32 query rows each ------------------------------------------
-    {
-        const int pi = wave >> 1, s = pi >> 1, hh = pi & 1;
-        const int b = b0 + s, h = h0 + hh;
-        if (b >= p.B) return;
-#pragma unroll 1
-        for (int blk = 0; blk < 2; ++blk) {
-            const int i0 = (wave & 1) * 32 + blk * 16;
-            if (i0 >= p.S) break;
-            float add[4][4];
-            vlt5attn::score_addend(p.at, b, h, i0, lane, add);
-            vlt5attn::attn_fwd_rows<true>(p.at, tile(s, hh, 0), tile(s, hh, 1), tile(s, hh, 2), b, h, i0, lane, add);
-        }
+    stamp(5);
+    // ---- phase 3: attention core, two waves per (sample, head), 32 query rows each: the two 16-row blocks are independent
+    // chains in one basic block (rows beyond S compute on padding and store nothing) -------------------------------------------
+    if (b0 + cs < p.B) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+            vlt5attn::attn_fwd_rows<true>(p.at, tile(cs, chh, 0), tile(cs, chh, 1), tile(cs, chh, 2), cb, ch, (wave & 1) * 32 + blk * 16, lane,
+                                          add[blk]);
+    }
+    stamp(6);
+    if (TL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(7);
+        if (threadIdx.x == 0 && tl_out)
+            for (int q = 0; q < 12; ++q) tl_out[(size_t)blockIdx.x * 12 + q] = tl[q];
     }
 }
+
+unsigned long long* g_tl_buf = nullptr;      // vlt5dbg_qkv_attn_timeline: device buffer of 8 x u64 per workgroup, or null
 
 }  // namespace
 
@@ -211,11 +236,13 @@ extern "C" int vlt5_qkv_attn_fwd(const void* xn_bf16, const void* wqkv_bf16, voi
     t.dq_sb = t.dq_st = t.dk_sb = t.dk_st = t.dv_sb = t.dv_st = 0; t.dbias = nullptr;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS));
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS));
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS));
         attr_set = true;
     }
     const int grid = ((a.B + 1) / 2) * (a.H / 2);
-    hipLaunchKernelGGL(qkv_attn_fwd_kernel, dim3(grid), dim3(FNT), FUSED_LDS, (hipStream_t)stream, a);
+    if (g_tl_buf) hipLaunchKernelGGL(qkv_attn_fwd_kernel<true>, dim3(grid), dim3(FNT), FUSED_LDS, (hipStream_t)stream, a, g_tl_buf);
+    else hipLaunchKernelGGL(qkv_attn_fwd_kernel<false>, dim3(grid), dim3(FNT), FUSED_LDS, (hipStream_t)stream, a, (unsigned long long*)nullptr);
     LAUNCH_CHECK();
     return VLT5_OK;
 }
@@ -246,3 +273,8 @@ extern "C" int vlt5_enc_attn_fwd(const vlt5_enc_attn_desc* d, void* stream) {
     g.alpha = 1.f; g.out_f32 = 1; g.resid = d->x; g.ldr = d->d_model; g.drop_p = d->drop_p; g.drop_seed = d->seed_out;
     return vlt5_gemm_bf16(&g, stream);
 }
+
+// debug (not part of the public ABI): while `buf` (device, 8 x u64 per workgroup) is set, vlt5_qkv_attn_fwd launches the
+// instrumented build of its kernel: [0] start, [1] prologue issued, [2] first k-tile landed, [3] main loop done, [4] tiles
+// handed over, [5] q|k|v stores issued, [6] core done, [7] stores drained (shader clocks of wave 0); tools/enc_attn_timeline.py
+extern "C" int vlt5dbg_qkv_attn_timeline(void* buf) { g_tl_buf = (unsigned long long*)buf; return VLT5_OK; }

@@ -428,6 +428,13 @@ int attn_call(const Ctx& k, bool bwd, const bf16_t* q, long long q_sb, long long
     return vlt5_attn_bwd(&a, k.st);
 }
 
+// the fused q|k|v projection + attention core kernel (csrc/enc_attn.hip) covers d_kv = 64, an even number of heads, S <= 64 and
+// d_model % 64 == 0 (every T5 size); VLT5_FUSED_ATTN=0 selects the GEMM + attention-core launches instead (A/B runs, tests)
+bool fused_attn_ok(const Ctx& k) {
+    static const bool off = getenv("VLT5_FUSED_ATTN") && atoi(getenv("VLT5_FUSED_ATTN")) == 0;
+    return !off && k.c.d_kv == 64 && (k.H & 1) == 0 && k.p.S <= 64 && (k.d & 63) == 0;
+}
+
 int encoder_fwd(const Ctx& k) {
     const Plan& p = k.p; const Layout& L = k.lay; const vlt5_config& c = k.c; const vlt5_step& s = k.s;
     const int d = k.d, inner = k.inner, ff = k.ff, M = p.M, S = p.S, Sx = p.Sx, B = s.B;
@@ -457,10 +464,21 @@ int encoder_fwd(const Ctx& k) {
         bf16_t* qkv = k.w<bf16_t>(p.qkv[l]);
         RC(k.ln_fwd_pending(pending, xa, l > 0 ? k.w<float>(p.x[2 * l - 1]) : nullptr, k.pdrop, k.seed(sb - 8 + E_FFN_OUT), E.ln_s,
                             k.w<void>(p.xn_a[l]), nullptr, k.w<float>(p.xr[2 * l]), M, 0.f, 0, 0, 0));
-        RC(k.lin_fwd(k.w<bf16_t>(p.xn_a[l]), k.Pb + E.sqkv, qkv, M, 3 * inner, d, 0));
-        RC(attn_call(k, false, qkv, (long long)S * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)S * 3 * inner,
-                     3 * inner, k.w<bf16_t>(p.ctx[l]), k.w<float>(p.lse[l]), k.w<float>(p.enc_bias), s.L, s.L, k.w<float>(p.mask),
-                     -10000.f, 0, S, S, k.seed(sb + E_PROBS)));
+        if (fused_attn_ok(k)) {
+            vlt5_attn_desc a;
+            memset(&a, 0, sizeof a);
+            a.q = qkv; a.k = qkv + inner; a.v = qkv + 2 * inner;
+            a.q_sb = a.k_sb = a.v_sb = (long long)S * 3 * inner; a.q_st = a.k_st = a.v_st = 3 * inner;
+            a.ctx = k.w<void>(p.ctx[l]); a.o_sb = (long long)S * inner; a.o_st = inner; a.lse = k.w<float>(p.lse[l]);
+            a.bias = k.w<float>(p.enc_bias); a.bias_q = s.L; a.bias_k = s.L; a.key_mask = k.w<float>(p.mask); a.mask_value = -10000.f;
+            a.B = B; a.H = k.H; a.Tq = S; a.Tk = S; a.dk = c.d_kv; a.drop_p = k.pdrop; a.drop_seed = k.seed(sb + E_PROBS);
+            RC(vlt5_qkv_attn_fwd(k.w<void>(p.xn_a[l]), k.Pb + E.sqkv, qkv, &a, d, k.st));
+        } else {
+            RC(k.lin_fwd(k.w<bf16_t>(p.xn_a[l]), k.Pb + E.sqkv, qkv, M, 3 * inner, d, 0));
+            RC(attn_call(k, false, qkv, (long long)S * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)S * 3 * inner,
+                         3 * inner, k.w<bf16_t>(p.ctx[l]), k.w<float>(p.lse[l]), k.w<float>(p.enc_bias), s.L, s.L, k.w<float>(p.mask),
+                         -10000.f, 0, S, S, k.seed(sb + E_PROBS)));
+        }
         RC(k.lin_fwd(k.w<bf16_t>(p.ctx[l]), k.Pb + E.so, xf, M, d, inner, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + E_ATTN_OUT), xa));
         RC(vlt5_layernorm_fwd(xf, k.P + E.ln_f, k.w<void>(p.xn_f[l]), nullptr, k.w<float>(p.xr[2 * l + 1]), M, d, c.eps, 0.f, 0, 0, 0, k.st));
         RC(k.ffn_hidden(k.w<bf16_t>(p.xn_f[l]), E.wi, k.w<bf16_t>(p.u[l]), k.w<bf16_t>(p.h[l]), M, k.pdrop, k.seed(sb + E_FFN_H)));

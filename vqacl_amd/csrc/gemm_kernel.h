@@ -699,9 +699,10 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                 }
                 if constexpr (kDrop) {
                     if (do_drop) {
-                        uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+                        bool kp[4];
+                        drop_keep4(p.drop_seed, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, p.drop_thr, kp);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = drop_keep(p.drop_seed, idx + r, p.drop_thr) ? v[r] * dscale : 0.f;
+                        for (int r = 0; r < 4; ++r) v[r] = kp[r] ? v[r] * dscale : 0.f;
                     }
                 }
                 if constexpr (kAux) { v[0] += aux[ii][j].x; v[1] += aux[ii][j].y; v[2] += aux[ii][j].z; v[3] += aux[ii][j].w; }

@@ -47,11 +47,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 }
                 if (rthr) {
                     const float rsc = drop_scale(rthr);
-                    const uint32_t idx = (uint32_t)row * (uint32_t)d + (uint32_t)c;
-                    xv[k].x = drop_keep(rseed, idx, rthr) ? xv[k].x * rsc : 0.f;
-                    xv[k].y = drop_keep(rseed, idx + 1, rthr) ? xv[k].y * rsc : 0.f;
-                    xv[k].z = drop_keep(rseed, idx + 2, rthr) ? xv[k].z * rsc : 0.f;
-                    xv[k].w = drop_keep(rseed, idx + 3, rthr) ? xv[k].w * rsc : 0.f;
+                    bool kp[4];
+                    drop_keep4(rseed, (uint32_t)row * (uint32_t)d + (uint32_t)c, rthr, kp);
+                    xv[k].x = kp[0] ? xv[k].x * rsc : 0.f;
+                    xv[k].y = kp[1] ? xv[k].y * rsc : 0.f;
+                    xv[k].z = kp[2] ? xv[k].z * rsc : 0.f;
+                    xv[k].w = kp[3] ? xv[k].w * rsc : 0.f;
                 }
                 const float4 r = *reinterpret_cast<const float4*>(resid + (size_t)row * d + c);
                 xv[k].x += r.x; xv[k].y += r.y; xv[k].z += r.z; xv[k].w += r.w;
@@ -73,9 +74,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         float4 g = *reinterpret_cast<const float4*>(w + c);
         float o[4] = {g.x * (v.x * rs), g.y * (v.y * rs), g.z * (v.z * rs), g.w * (v.w * rs)};
         if (thr) {
-            uint32_t idx = (uint32_t)row * (uint32_t)d + (uint32_t)c;
+            bool kp[4];
+            drop_keep4(seed, (uint32_t)row * (uint32_t)d + (uint32_t)c, thr, kp);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = drop_keep(seed, idx + k, thr) ? o[k] * dsc : 0.f;
+            for (int k = 0; k < 4; ++k) o[k] = kp[k] ? o[k] * dsc : 0.f;
         }
         if (yf) *reinterpret_cast<float4*>(yf + (size_t)orow * d + c) = make_float4(o[0], o[1], o[2], o[3]);
         if (yb) {
@@ -161,11 +163,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     }
                 }
                 if (thr) {
-                    uint32_t idx = (uint32_t)row * (uint32_t)d + (uint32_t)c;
-                    t.x = drop_keep(seed, idx, thr) ? t.x * dsc : 0.f;
-                    t.y = drop_keep(seed, idx + 1, thr) ? t.y * dsc : 0.f;
-                    t.z = drop_keep(seed, idx + 2, thr) ? t.z * dsc : 0.f;
-                    t.w = drop_keep(seed, idx + 3, thr) ? t.w * dsc : 0.f;
+                    bool kp[4];
+                    drop_keep4(seed, (uint32_t)row * (uint32_t)d + (uint32_t)c, thr, kp);
+                    t.x = kp[0] ? t.x * dsc : 0.f;
+                    t.y = kp[1] ? t.y * dsc : 0.f;
+                    t.z = kp[2] ? t.z * dsc : 0.f;
+                    t.w = kp[3] ? t.w * dsc : 0.f;
                 }
                 gv[k] = t;
                 s += t.x * wreg[k].x * xv[k].x + t.y * wreg[k].y * xv[k].y + t.z * wreg[k].z * xv[k].z + t.w * wreg[k].w * xv[k].w;
@@ -188,9 +191,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 if (dxb) {                      // bf16(dropout(dx)) = the A operand of the next sublayer's backward GEMMs
                     float q[4] = {o.x, o.y, o.z, o.w};
                     if (thr2) {
-                        uint32_t idx = (uint32_t)row * (uint32_t)d + (uint32_t)c;
+                        bool kp[4];
+                        drop_keep4(seed2, (uint32_t)row * (uint32_t)d + (uint32_t)c, thr2, kp);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) q[e] = drop_keep(seed2, idx + e, thr2) ? q[e] * dsc2 : 0.f;
+                        for (int e = 0; e < 4; ++e) q[e] = kp[e] ? q[e] * dsc2 : 0.f;
                     }
                     uint2 pk;
                     pk.x = pack_bf16x2(q[0], q[1]);

@@ -251,3 +251,18 @@ def glu_bwd(dh, u, ff, drop_p=0.0, drop_seed=0):
     du = torch.empty(rows, 2 * ff, device=u.device, dtype=BF16)
     check(lib().vlt5_glu_bwd(ptr(_need(dh, BF16)), ptr(_need(u, BF16)), ptr(du), rows, ff, drop_p, drop_seed, stream_ptr()), "vlt5_glu_bwd")
     return du
+
+
+def qkv_attn_fwd(xn, wqkv, B, S, H, bias=None, key_mask=None, mask_value=-10000.0, drop_p=0.0, drop_seed=0):
+    """Fused q|k|v projection + attention core (csrc/enc_attn.hip): xn bf16 [B*S, d], wqkv bf16 [3*H*64, d] ->
+    qkv bf16 [B, S, 3*H*64], ctx bf16 [B, S, H*64], lse f32 [B, H, S]."""
+    d = xn.shape[1]
+    inner = H * 64
+    qkv = torch.empty(B, S, 3 * inner, device=xn.device, dtype=BF16)
+    a = _attn_desc(qkv[:, :, :inner], qkv[:, :, inner:2 * inner], qkv[:, :, 2 * inner:], H, 64, bias, key_mask, mask_value, False,
+                   drop_p, drop_seed)
+    ctx = torch.empty(B, S, inner, device=xn.device, dtype=BF16)
+    lse = torch.empty(B, H, S, device=xn.device, dtype=torch.float32)
+    a.ctx, a.o_sb, a.o_st, a.lse = ptr(ctx), ctx.stride(0), ctx.stride(1), ptr(lse)
+    check(lib().vlt5_qkv_attn_fwd(ptr(_need(xn, BF16)), ptr(_need(wqkv, BF16)), ptr(qkv), C.byref(a), d, stream_ptr()), "vlt5_qkv_attn_fwd")
+    return qkv, ctx, lse
