@@ -148,6 +148,17 @@ typedef struct {
     float drop_p; uint32_t seed_probs, seed_out;     /* dropout on the probabilities / on the sublayer output */
 } vlt5_enc_attn_desc;
 int vlt5_enc_attn_fwd(const vlt5_enc_attn_desc* d, void* stream);
+/* backward of the sublayer from what the forward saved (autograd's backward of the same modules, src/vqacl.py:461).  dx may alias dy.
+ * d_scores (optional): f32 [B,H,bias_q,bias_k] per-sample gradient of the bias block (reduce with vlt5_relbias_bwd).
+ * workspace: vlt5_enc_attn_bwd_workspace_bytes(...) bytes of device scratch. */
+typedef struct {
+    const float* dy;                                 /* f32 [B*S, d_model] gradient of x_out */
+    float* dx;                                       /* f32 [B*S, d_model] gradient of x */
+    float* d_wqkv; float* d_wo; float* d_ln_w;       /* f32 [3*H*64, d_model], [d_model, H*64], [d_model] (overwritten) */
+    float* d_scores;
+} vlt5_enc_attn_grads;
+long long vlt5_enc_attn_bwd_workspace_bytes(int B, int S, int H, int d_model);
+int vlt5_enc_attn_bwd(const vlt5_enc_attn_desc* d, const vlt5_enc_attn_grads* g, void* workspace, void* stream);
 
 /* ---- relative position bias: HF T5Attention.compute_bias / _relative_position_bucket ---------
  * The integer bucket table lut[Lq*Lk] is computed on the host (vqacl_amd/buckets.py, bit-exact

@@ -434,6 +434,48 @@ def test_fused_qkv_attention_equals_the_unfused_kernels(dev, B, S, H, d, Lb, dro
         close(ctx1, ref, 2e-2, 2e-2, "fused context vs f32 reference")
 
 
+@pytest.mark.parametrize("B,S,H,d,Lb", [(3, 24, 2, 128, 9), (2, 56, 12, 768, 20)])
+def test_encoder_attention_sublayer_entry_points_vs_oracle(dev, B, S, H, d, Lb):
+    """vlt5_enc_attn_fwd / vlt5_enc_attn_bwd: x + o(attention(LN(x))) and all its gradients against the oracle's
+    restatement of HF T5LayerSelfAttention (oracle/ref_cpu.py t5_layernorm + t5_attention, pinned to the HF modules by G3) in f32."""
+    from oracle import ref_cpu as R
+    from vqacl_amd import ops
+    from vqacl_amd.buckets import bucket_table
+    g = torch.Generator().manual_seed(d + S)
+    cfg = R.Cfg(d_model=d, d_kv=64, num_heads=H, dropout=0.0)
+    inner = H * 64
+    x = rnd((B, S, d), g).requires_grad_(True)
+    lnw = (1.0 + 0.1 * rnd((d,), g)).requires_grad_(True)
+    wq, wk, wv = (rnd((inner, d), g, (d * 64) ** -0.5 if i == 0 else d ** -0.5).requires_grad_(True) for i in range(3))
+    wo = rnd((d, inner), g, inner ** -0.5).requires_grad_(True)
+    table = rnd((32, H), g, 0.5).requires_grad_(True)
+    km = (torch.rand(B, Lb, generator=g) > 0.25).float()
+    km[:, 0] = 1.0
+    mask = torch.cat([km, torch.ones(B, S - Lb)], dim=1)
+    bias = torch.zeros(1, H, S, S)
+    bias = bias + 0.0
+    full = torch.zeros(1, H, S, S)
+    full[:, :, :Lb, :Lb] = R.compute_bias(table, Lb, Lb, True, cfg)
+    full = full + (1.0 - mask)[:, None, None, :] * -10000.0
+    xn = R.t5_layernorm(x, lnw, 1e-6)
+    y = x + R.t5_attention(xn, xn, wq, wk, wv, wo, full, cfg, 0.0, False)
+    gy = rnd((B, S, d), g)
+    y.backward(gy)
+    # engine
+    lut = torch.from_numpy(bucket_table(Lb, Lb, True)).to(dev)
+    bias_blk = ops.relbias_build(table.detach().to(dev), lut, H, Lb, Lb)
+    wqkv = torch.cat([wq, wk, wv]).detach().to(BF).to(dev)
+    out, sv = ops.enc_attn_sublayer(x.detach().reshape(-1, d).to(dev), lnw.detach().to(dev), wqkv, wo.detach().to(BF).to(dev), B, S, H,
+                                    bias=bias_blk, key_mask=mask.to(dev))
+    close_norm(out, y.detach().reshape(-1, d), 2e-2, 5e-2, "sublayer output")
+    dx, dwqkv, dwo, dln, ds = ops.enc_attn_sublayer_bwd(gy.reshape(-1, d).to(dev), sv, want_dscores=True)
+    close_norm(dx, x.grad.reshape(-1, d), 4e-2, 1e-1, "dx")
+    close_norm(dwqkv, torch.cat([wq.grad, wk.grad, wv.grad]), 6e-2, 1.5e-1, "d Wqkv")
+    close_norm(dwo, wo.grad, 4e-2, 1e-1, "d Wo")
+    close_norm(dln, lnw.grad, 4e-2, 1e-1, "d norm weight")
+    close_norm(ops.relbias_bwd(ds, lut, 32), table.grad, 6e-2, 1.5e-1, "d relative-position table")
+
+
 def test_fused_qkv_attention_rejects_unsupported_shapes(dev):
     from vqacl_amd import ops
     from vqacl_amd._lib import Vlt5Error

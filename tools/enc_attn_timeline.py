@@ -44,19 +44,20 @@ print(f"B={B} S={S} H={H} d={d}: fused {timed(lambda: ops.qkv_attn_fwd(xn, w, B,
       f"gemm + attention core {timed(unfused):.1f} us (python-side launches included)")
 L = C.CDLL(lib()._name)
 nwg = ((B + 1) // 2) * (H // 2)
-buf = torch.zeros(nwg * 12, dtype=torch.int64, device=dev)
+buf = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
 L.vlt5dbg_qkv_attn_timeline.argtypes = [C.c_void_p]
 L.vlt5dbg_qkv_attn_timeline(C.c_void_p(buf.data_ptr()))
 for _ in range(3):
     ops.qkv_attn_fwd(xn, w, B, S, H, **kw)
 torch.cuda.synchronize()
 L.vlt5dbg_qkv_attn_timeline(C.c_void_p(0))
-t = buf.view(nwg, 12).cpu().double()
+t = buf.view(nwg, 16).cpu().double()
 # stamp order in the kernel: 0 start, 1 prologue issued, 2 first k-tile landed, 3 main loop done, 8 addends requested, 9 barrier 1,
 # 10 tiles written, 4 barrier 2, 5 q|k|v stores issued, 6 core done, 7 stores drained
-order = [0, 1, 2, 3, 8, 9, 10, 4, 5, 6, 7]
+order = [0, 1, 2, 3, 8, 9, 10, 4, 5, 11, 12, 13, 6, 7]
 names = ["prologue issue", "first k-tile landed", "k-steps 2..n", "addend request", "barrier 1 (incl. load wait)", "tile writes",
-         "barrier 2", "q|k|v store issue", "core", "store drain"]
+         "barrier 2", "q|k|v store issue", "core: addend finish", "core: K/Q reads + score MFMAs", "core: softmax + dropout + pack",
+         "core: V^T reads + P.V + ctx stores", "store drain"]
 print(f"{'phase':34s} {'mean clk':>9s} {'min':>8s} {'max':>8s}")
 for i, nm in enumerate(names):
     dlt = t[:, order[i + 1]] - t[:, order[i]]

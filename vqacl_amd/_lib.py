@@ -44,6 +44,10 @@ class EncAttnDesc(C.Structure):
                 ("seed_probs", c_u32), ("seed_out", c_u32)]
 
 
+class EncAttnGrads(C.Structure):
+    _fields_ = [("dy", vp), ("dx", vp), ("d_wqkv", vp), ("d_wo", vp), ("d_ln_w", vp), ("d_scores", vp)]
+
+
 class GemmTimingRec(C.Structure):
     _fields_ = [("M", c_i), ("N", c_i), ("K", c_i), ("batch", c_i), ("tile_m", c_i), ("tile_n", c_i), ("a_kmajor", c_i),
                 ("b_kmajor", c_i), ("splits", c_i), ("workgroups", c_i), ("ms", c_f)]
@@ -88,6 +92,8 @@ PROTOTYPES = {
     "vlt5_attn_fwd": (c_i, [C.POINTER(AttnDesc), vp]),
     "vlt5_qkv_attn_fwd": (c_i, [vp, vp, vp, C.POINTER(AttnDesc), c_i, vp]),
     "vlt5_enc_attn_fwd": (c_i, [C.POINTER(EncAttnDesc), vp]),
+    "vlt5_enc_attn_bwd_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i]),
+    "vlt5_enc_attn_bwd": (c_i, [C.POINTER(EncAttnDesc), C.POINTER(EncAttnGrads), vp, vp]),
     "vlt5_attn_bwd": (c_i, [C.POINTER(AttnDesc), vp]),
     "vlt5_relbias_build": (c_i, [vp, vp, vp, c_i, c_i, c_i, c_i, vp]),
     "vlt5_relbias_bwd": (c_i, [vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_i, c_i, vp]),

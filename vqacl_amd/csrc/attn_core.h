@@ -93,14 +93,14 @@ __device__ __forceinline__ bf16x8_t pack_slots(const float (&lo)[4], const float
 // what is added to the raw scores of this lane's 16 elements: relative-position bias + key mask + causal mask, -inf beyond Tk.
 // Depends on nothing in LDS, so it is requested BEFORE the tiles are staged: its global-memory round trip overlaps the staging
 // loads instead of following the Q.K^T MFMAs (one round trip less on the critical path of a latency-bound kernel).
-__device__ __forceinline__ void score_addend(const AttnArgs& p, int b, int h, int i0, int lane, float (&add)[4][4]) {
+struct AddendRaw { float bv[4][4], mv[4][4]; };       // the loaded bias / key-mask words of a 16-row block, before they are combined
+// request: every load is issued branch-free per lane (clamped index, selected in score_addend_finish), so the 32 loads of a block are
+// in flight together behind ONE wait -- per-element `if (..) v += load` chains serialise into 32 dependent round trips when few
+// waves share a CU (measured in the fused kernel: 20 k cycles).  An absent operand reads a dummy word of q instead of branching
+// around its loads: one basic block, one wait.
+__device__ __forceinline__ void score_addend_load(const AttnArgs& p, int b, int h, int i0, int lane, AddendRaw& raw) {
     const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
-    // branch-free per lane: every load is issued (clamped index) and selected afterwards, so the 32 loads of a block are in flight
-    // together behind ONE wait -- per-element `if (..) v += load` chains serialise into 32 dependent round trips when few waves
-    // share a CU (measured in the fused kernel: 20 k cycles)
-    float bv[4][4], mv[4][4];
     const bool hb = p.bias != nullptr, hm = p.key_mask != nullptr;            // wave-uniform
-    // (an absent operand reads a dummy word of q instead of branching around its loads: one basic block, one wait)
     const float* row = hb ? p.bias + ((size_t)h * p.bias_q + min(i, p.bias_q - 1)) * p.bias_k : reinterpret_cast<const float*>(p.q);
     const float* mrow = hm ? p.key_mask + (size_t)b * p.Tk : reinterpret_cast<const float*>(p.q);
     const int bk1 = hb ? p.bias_k - 1 : 0, mk1 = hm ? p.Tk - 1 : 0;
@@ -108,20 +108,29 @@ __device__ __forceinline__ void score_addend(const AttnArgs& p, int b, int h, in
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            bv[jb][r] = row[min(jb * 16 + g * 4 + r, bk1)];
-            mv[jb][r] = mrow[min(jb * 16 + g * 4 + r, mk1)];
+            raw.bv[jb][r] = row[min(jb * 16 + g * 4 + r, bk1)];
+            raw.mv[jb][r] = mrow[min(jb * 16 + g * 4 + r, mk1)];
         }
+}
+__device__ __forceinline__ void score_addend_finish(const AttnArgs& p, int i0, int lane, const AddendRaw& raw, float (&add)[4][4]) {
+    const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
+    const bool hb = p.bias != nullptr, hm = p.key_mask != nullptr;
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = jb * 16 + g * 4 + r;
             float v = 0.f;
-            if (hb && i < p.bias_q && j < p.bias_k) v += bv[jb][r];
-            if (hm) v += (1.0f - mv[jb][r]) * p.mask_value;
+            if (hb && i < p.bias_q && j < p.bias_k) v += raw.bv[jb][r];
+            if (hm) v += (1.0f - raw.mv[jb][r]) * p.mask_value;
             if (p.causal && j > i) v += -10000.0f;
             add[jb][r] = (j < p.Tk) ? v : -INFINITY;
         }
+}
+__device__ __forceinline__ void score_addend(const AttnArgs& p, int b, int h, int i0, int lane, float (&add)[4][4]) {
+    AddendRaw raw;
+    score_addend_load(p, b, h, i0, lane, raw);
+    score_addend_finish(p, i0, lane, raw, add);
 }
 
 // scores of this wave's 16 query rows against all 64 key slots, + the addend above; s[jb][r] in the swapped layout
@@ -161,62 +170,115 @@ __device__ __forceinline__ float quad_lane_max(float v) {
 }
 
 
-// one wave, query rows i0 .. i0+15 of head (b, h): scores -> softmax (+ saved log-sum-exp) -> dropout -> P.V -> ctx rows; Q/K/V are the
-// staged natural tiles of that head, `add` the score addend of these rows (score_addend)
-template <bool DK64>
-__device__ __forceinline__ void attn_fwd_rows(const AttnArgs& p, const bf16_t* Qs, const bf16_t* Ks, const bf16_t* Vs, int b, int h,
-                                              int i0, int lane, const float (&add)[4][4]) {
-    const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
-
-    float s[4][4];
-    scores_16x64<DK64>(p, Qs, Ks, b, h, i0, lane, add, s);
-    float m = -INFINITY;
+// one wave, NB consecutive 16-row query blocks (rows i0 .. i0 + 16*NB - 1) of head (b, h): scores -> softmax (+ saved log-sum-exp)
+// -> dropout -> P.V -> ctx rows.  Q/K/V are the staged natural tiles of that head, add[n] the score addend of block n.  The blocks
+// share every K and V^T fragment read and are independent MFMA / VALU chains in one basic block (the fused encoder kernel runs
+// NB = 2: half the LDS reads per row and two chains to interleave); per block the arithmetic and its order are those of NB = 1.
+struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
+template <bool DK64, int NB, class Stamp = NoStamp>
+__device__ __forceinline__ void attn_fwd_blocks(const AttnArgs& p, const bf16_t* Qs, const bf16_t* Ks, const bf16_t* Vs, int b, int h,
+                                                int i0, int lane, const float (&add)[NB][4][4], Stamp stamp = Stamp()) {
+    const int lr = lane & 15, g = lane >> 4;
+    f32x4_t acc[NB][4];
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
+    for (int n = 0; n < NB; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m = fmaxf(m, s[jb][r]);
-    m = quad_lane_max(m);
-    float sum = 0.f;
+        for (int jb = 0; jb < 4; ++jb) acc[n][jb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int nks = DK64 ? 2 : (p.dk > 32 ? 2 : 1);
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
+    for (int ks = 0; ks < 2; ++ks) {
+        if (ks >= nks) break;
+        bf16x8_t fk[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s[jb][r] = fast_exp(s[jb][r] - m); sum += s[jb][r]; }
-    sum = quad_lane_sum(sum);
-    const float inv = 1.0f / sum;
-    if (g == 0 && i < p.Tq && p.lse) p.lse[((size_t)b * p.H + h) * p.Tq + i] = m + logf(sum);
-    const float dsc = drop_scale(p.drop_thr);
+        for (int jb = 0; jb < 4; ++jb) fk[jb] = lds_frag(Ks, jb * 16 + lr, ks * 4 + g);
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-        bool keep[4] = {true, true, true, true};
-        if (p.drop_thr)
-            drop_keep4(p.drop_seed, (uint32_t)((((size_t)b * p.H + h) * p.Tq + i) * p.Tk + jb * 16 + g * 4), p.drop_thr, keep);
+        for (int n = 0; n < NB; ++n) {
+            const bf16x8_t fq = lds_frag(Qs, i0 + n * 16 + lr, ks * 4 + g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = s[jb][r] * inv;
-            s[jb][r] = p.drop_thr ? (keep[r] ? v * dsc : 0.f) : v;
+            for (int jb = 0; jb < 4; ++jb) acc[n][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[jb], fq, acc[n][jb], 0, 0, 0);
         }
     }
-    bf16x8_t pf[2] = {pack_slots(s[0], s[1]), pack_slots(s[2], s[3])};
+    stamp(0);
+    // The softmax of a block is VALU work of all four lanes of a row: kept lean (in the fused encoder kernel it runs with nothing to
+    // hide behind).  exp(s - m) = exp2(fma(s, log2e, -m log2e)); the normaliser and the dropout scale are one factor; a masked slot
+    // (addend -inf: key >= Tk) needs no select since acc is finite (padding rows hold zeros or copies of valid rows).
+    const float dsc = drop_scale(p.drop_thr);          // 1.0 exactly without dropout
+    constexpr float kLog2e = 1.4426950408889634f;
+    bf16x8_t pf[NB][2];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int i = i0 + n * 16 + lr;
+        const uint32_t rowbase = ((uint32_t)(b * p.H + h) * (uint32_t)p.Tq + (uint32_t)i) * (uint32_t)p.Tk + (uint32_t)(g * 4);   // low 32 bits of the element index
+        float s[4][4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[jb][r] = acc[n][jb][r] + add[n][jb][r];
+        // (reductions as trees over the four key blocks: serial 16-long max / add chains leave a wave with two independent
+        // instruction streams waiting on VALU latency)
+        float mj[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) mj[jb] = fmaxf(fmaxf(s[jb][0], s[jb][1]), fmaxf(s[jb][2], s[jb][3]));
+        const float m = quad_lane_max(fmaxf(fmaxf(mj[0], mj[1]), fmaxf(mj[2], mj[3])));
+        const float m2 = m * kLog2e;
+        float sj[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[jb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[jb][r], kLog2e, -m2));
+            sj[jb] = (s[jb][0] + s[jb][1]) + (s[jb][2] + s[jb][3]);
+        }
+        const float sum = quad_lane_sum((sj[0] + sj[1]) + (sj[2] + sj[3]));
+        const float vs = __builtin_amdgcn_rcpf(sum) * dsc;
+        if (g == 0 && i < p.Tq && p.lse) p.lse[((size_t)b * p.H + h) * p.Tq + i] = m + logf(sum);
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            bool keep[4] = {true, true, true, true};
+            if (p.drop_thr) drop_keep4(p.drop_seed, rowbase + jb * 16, p.drop_thr, keep);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[jb][r] = keep[r] ? s[jb][r] * vs : 0.f;
+        }
+        pf[n][0] = pack_slots(s[0], s[1]);
+        pf[n][1] = pack_slots(s[2], s[3]);
+    }
+    stamp(1);
     const int ndb = DK64 ? 4 : (p.dk + 15) / 16;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
         if (db >= ndb) break;
-        f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        f32x4_t o[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) o[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             if (kk * 32 < p.Tk) {
-                bf16x8_t fv = frag_tr_slots(Vs, db * 16, kk, lane);        // V^T[d][j] gathered from the natural V tile
-                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[kk], o, 0, 0, 0);
+                const bf16x8_t fv = frag_tr_slots(Vs, db * 16, kk, lane);        // V^T[d][j] gathered from the natural V tile
+#pragma unroll
+                for (int n = 0; n < NB; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pf[n][kk], o[n], 0, 0, 0);
             }
         }
         const int d = db * 16 + g * 4;
-        if (i < p.Tq && d < p.dk) {
-            uint2 pk;
-            pk.x = pack_bf16x2(o[0], o[1]);
-            pk.y = pack_bf16x2(o[2], o[3]);
-            *reinterpret_cast<uint2*>(p.ctx + b * p.o_sb + (long long)i * p.o_st + (long long)h * p.dk + d) = pk;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int i = i0 + n * 16 + lr;
+            if (i < p.Tq && d < p.dk) {
+                uint2 pk;
+                pk.x = pack_bf16x2(o[n][0], o[n][1]);
+                pk.y = pack_bf16x2(o[n][2], o[n][3]);
+                *reinterpret_cast<uint2*>(p.ctx + b * p.o_sb + (long long)i * p.o_st + (long long)h * p.dk + d) = pk;
+            }
         }
     }
+}
+template <bool DK64>
+__device__ __forceinline__ void attn_fwd_rows(const AttnArgs& p, const bf16_t* Qs, const bf16_t* Ks, const bf16_t* Vs, int b, int h,
+                                              int i0, int lane, const float (&add)[4][4]) {
+    float a1[1][4][4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a1[0][jb][r] = add[jb][r];
+    attn_fwd_blocks<DK64, 1>(p, Qs, Ks, Vs, b, h, i0, lane, a1);
 }
 
 }  // namespace vlt5attn

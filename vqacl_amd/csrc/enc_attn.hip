@@ -52,7 +52,7 @@ static_assert(12 * TILE_BYTES <= FUSED_LDS, "the Q/K/V tiles of 2 samples x 2 he
 template <bool TL>
 __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsigned long long* tl_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tl[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto stamp = [&](int i) __attribute__((always_inline)) { if (TL && threadIdx.x == 0) tl[i] = __builtin_readcyclecounter(); };
     stamp(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -145,10 +145,11 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus prefetch must land before the stages are reused
     stamp(3);
     // score addends (relative-position bias + key mask) of this wave's two 16-row blocks: requested here (branch-free, all loads in
-    // flight together), their global round trip overlaps the tile hand-over; kept out of the main loop, whose register budget is full
-    float add[2][4][4];
+    // flight together) and combined after the hand-over, which hides their global round trip; kept out of the main loop, whose
+    // register budget is full
+    vlt5attn::AddendRaw raw[2];
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) vlt5attn::score_addend(p.at, cb, ch, (wave & 1) * 32 + blk * 16, lane, add[blk]);
+    for (int blk = 0; blk < 2; ++blk) vlt5attn::score_addend_load(p.at, cb, ch, (wave & 1) * 32 + blk * 16, lane, raw[blk]);
     stamp(8);
     __syncthreads();
     stamp(9);
@@ -190,17 +191,21 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
     // ---- phase 3: attention core, two waves per (sample, head), 32 query rows each: the two 16-row blocks are independent
     // chains in one basic block (rows beyond S compute on padding and store nothing) -------------------------------------------
     if (b0 + cs < p.B) {
+        float add[2][4][4];
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-            vlt5attn::attn_fwd_rows<true>(p.at, tile(cs, chh, 0), tile(cs, chh, 1), tile(cs, chh, 2), cb, ch, (wave & 1) * 32 + blk * 16, lane,
-                                          add[blk]);
+        for (int blk = 0; blk < 2; ++blk) vlt5attn::score_addend_finish(p.at, (wave & 1) * 32 + blk * 16, lane, raw[blk], add[blk]);
+        auto cstamp = [&](int i) __attribute__((always_inline)) {
+            if (TL && threadIdx.x == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tl[12 + i] = __builtin_readcyclecounter(); }
+        };
+        stamp(11);
+        vlt5attn::attn_fwd_blocks<true, 2>(p.at, tile(cs, chh, 0), tile(cs, chh, 1), tile(cs, chh, 2), cb, ch, (wave & 1) * 32, lane, add, cstamp);
     }
     stamp(6);
     if (TL) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(7);
         if (threadIdx.x == 0 && tl_out)
-            for (int q = 0; q < 12; ++q) tl_out[(size_t)blockIdx.x * 12 + q] = tl[q];
+            for (int q = 0; q < 16; ++q) tl_out[(size_t)blockIdx.x * 16 + q] = tl[q];
     }
 }
 
@@ -272,6 +277,62 @@ extern "C" int vlt5_enc_attn_fwd(const vlt5_enc_attn_desc* d, void* stream) {
     g.A = d->ctx_bf16; g.B = d->wo_bf16; g.C = d->x_out; g.M = M; g.N = d->d_model; g.K = inner; g.lda = inner; g.ldb = inner; g.ldc = d->d_model;
     g.alpha = 1.f; g.out_f32 = 1; g.resid = d->x; g.ldr = d->d_model; g.drop_p = d->drop_p; g.drop_seed = d->seed_out;
     return vlt5_gemm_bf16(&g, stream);
+}
+
+// Backward of the sublayer (SURVEY 8(b) `vlt5_enc_attn_bwd`; autograd's backward of HF T5LayerSelfAttention as reached from
+// src/vqacl.py:461), from what vlt5_enc_attn_fwd saved:
+//   dyd = bf16(dropout'(dy))                      d ctx = dyd Wo          dWo   = dyd^T ctx
+//   d q|k|v (+ dS for the relative-position table) = attention backward     dWqkv = dqkv^T xn
+//   dxn = dqkv Wqkv                                dx = dy + T5-RMS-norm backward(dxn),  d ln_w
+// Scratch: vlt5_enc_attn_bwd_workspace_bytes(B, S, H, d_model) bytes of device memory owned by the caller.
+extern "C" long long vlt5_enc_attn_bwd_workspace_bytes(int B, int S, int H, int d_model) {
+    if (B < 1 || S < 1 || H < 1 || d_model < 1) return -1;
+    const long long M = (long long)B * S, inner = (long long)H * 64;
+    auto up = [](long long x) { return (x + 255) / 256 * 256; };
+    return up(M * d_model * 2) + up(M * inner * 2) + up(M * 3 * inner * 2) + up(M * d_model * 4) +
+           up((long long)vlt5_layernorm_bwd_blocks((int)M) * d_model * 4);
+}
+extern "C" int vlt5_enc_attn_bwd(const vlt5_enc_attn_desc* d, const vlt5_enc_attn_grads* g, void* workspace, void* stream) {
+    if (!d || !g || !workspace || !d->x || !d->ln_w || !d->wqkv_bf16 || !d->wo_bf16 || !d->xn_bf16 || !d->rstd || !d->qkv_bf16 ||
+        !d->ctx_bf16 || !d->lse || !g->dy || !g->dx || !g->d_wqkv || !g->d_wo || !g->d_ln_w)
+        return VLT5_ERR_ARG;
+    const int M = d->B * d->S, inner = d->H * 64, dm = d->d_model;
+    auto up = [](long long x) { return (x + 255) / 256 * 256; };
+    char* ws = (char*)workspace;
+    bf16_t* dyd = (bf16_t*)ws;              ws += up((long long)M * dm * 2);
+    bf16_t* dctx = (bf16_t*)ws;             ws += up((long long)M * inner * 2);
+    bf16_t* dqkv = (bf16_t*)ws;             ws += up((long long)M * 3 * inner * 2);
+    float* dxn = (float*)ws;                ws += up((long long)M * dm * 4);
+    float* lnpart = (float*)ws;
+    int rc = vlt5_drop_cast(g->dy, dyd, M, dm, d->drop_p, d->seed_out, stream);
+    if (rc) return rc;
+    vlt5_gemm_desc m;
+    auto gemm = [&](const void* A, const void* Bm, void* Cc, int Mm, int Nn, int Kk, int lda, int ldb, int ldc, int akm, int bkm, int f32) {
+        memset(&m, 0, sizeof m);
+        m.A = A; m.B = Bm; m.C = Cc; m.M = Mm; m.N = Nn; m.K = Kk; m.lda = lda; m.ldb = ldb; m.ldc = ldc;
+        m.a_kmajor = akm; m.b_kmajor = bkm; m.alpha = 1.f; m.out_f32 = f32;
+        return vlt5_gemm_bf16(&m, stream);
+    };
+    // d ctx = dyd Wo (Wo [d_model, inner] read k-major);  dWo [d_model, inner] = dyd^T ctx
+    if ((rc = gemm(dyd, d->wo_bf16, dctx, M, inner, dm, dm, inner, inner, 0, 1, 0))) return rc;
+    if ((rc = gemm(dyd, d->ctx_bf16, g->d_wo, dm, inner, M, dm, inner, inner, 1, 1, 1))) return rc;
+    vlt5_attn_desc a;
+    memset(&a, 0, sizeof a);
+    bf16_t* qkv = (bf16_t*)d->qkv_bf16;
+    a.q = qkv; a.k = qkv + inner; a.v = qkv + 2 * inner;
+    a.q_sb = a.k_sb = a.v_sb = (long long)d->S * 3 * inner; a.q_st = a.k_st = a.v_st = 3 * inner;
+    a.lse = d->lse; a.bias = d->bias; a.bias_q = d->bias_q; a.bias_k = d->bias_k; a.key_mask = d->key_mask; a.mask_value = d->mask_value;
+    a.B = d->B; a.H = d->H; a.Tq = d->S; a.Tk = d->S; a.dk = 64; a.drop_p = d->drop_p; a.drop_seed = d->seed_probs;
+    a.d_ctx = dctx; a.do_sb = (long long)d->S * inner; a.do_st = inner;
+    a.dq = dqkv; a.dk_ = dqkv + inner; a.dv = dqkv + 2 * inner;
+    a.dq_sb = a.dk_sb = a.dv_sb = (long long)d->S * 3 * inner; a.dq_st = a.dk_st = a.dv_st = 3 * inner;
+    a.dbias = g->d_scores;
+    if ((rc = vlt5_attn_bwd(&a, stream))) return rc;
+    // dWqkv [3*inner, d_model] = dqkv^T xn;  dxn = dqkv Wqkv (Wqkv [3*inner, d_model] read k-major)
+    if ((rc = gemm(dqkv, d->xn_bf16, g->d_wqkv, 3 * inner, dm, M, 3 * inner, dm, dm, 1, 1, 1))) return rc;
+    if ((rc = gemm(dqkv, d->wqkv_bf16, dxn, M, dm, 3 * inner, 3 * inner, dm, dm, 0, 1, 1))) return rc;
+    if (g->dx != g->dy) HIP_RET(hipMemcpyAsync(g->dx, g->dy, (size_t)M * dm * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return vlt5_layernorm_bwd(dxn, d->x, d->ln_w, d->rstd, g->dx, g->d_ln_w, lnpart, M, dm, 1, 0, 0.f, 0, 0, 0, nullptr, 0.f, 0, stream);
 }
 
 // debug (not part of the public ABI): while `buf` (device, 8 x u64 per workgroup) is set, vlt5_qkv_attn_fwd launches the

@@ -266,3 +266,48 @@ def qkv_attn_fwd(xn, wqkv, B, S, H, bias=None, key_mask=None, mask_value=-10000.
     a.ctx, a.o_sb, a.o_st, a.lse = ptr(ctx), ctx.stride(0), ctx.stride(1), ptr(lse)
     check(lib().vlt5_qkv_attn_fwd(ptr(_need(xn, BF16)), ptr(_need(wqkv, BF16)), ptr(qkv), C.byref(a), d, stream_ptr()), "vlt5_qkv_attn_fwd")
     return qkv, ctx, lse
+
+
+def enc_attn_sublayer(x, ln_w, wqkv, wo, B, S, H, bias=None, key_mask=None, mask_value=-10000.0, eps=1e-6, drop_p=0.0, seeds=(0, 0)):
+    """Forward of the whole encoder self-attention sublayer through `vlt5_enc_attn_fwd` (norm, fused q|k|v projection + core, output
+    projection with dropout + residual).  x f32 [B*S, d]; wqkv bf16 [3*H*64, d]; wo bf16 [d, H*64].  Returns (x_out, saved) where
+    `saved` feeds `enc_attn_sublayer_bwd`."""
+    from ._lib import EncAttnDesc
+    d = x.shape[1]
+    inner = H * 64
+    dev = x.device
+    sv = dict(x=x, ln_w=ln_w, wqkv=wqkv, wo=wo, bias=bias, key_mask=key_mask,
+              xn=torch.empty(B * S, d, device=dev, dtype=BF16), rstd=torch.empty(B * S, device=dev, dtype=torch.float32),
+              qkv=torch.empty(B * S, 3 * inner, device=dev, dtype=BF16), ctx=torch.empty(B * S, inner, device=dev, dtype=BF16),
+              lse=torch.empty(B, H, S, device=dev, dtype=torch.float32))
+    out = torch.empty_like(x)
+    e = EncAttnDesc()
+    e.x, e.ln_w, e.wqkv_bf16, e.wo_bf16, e.x_out = ptr(_need(x, torch.float32)), ptr(ln_w), ptr(_need(wqkv, BF16)), ptr(_need(wo, BF16)), ptr(out)
+    e.xn_bf16, e.rstd, e.qkv_bf16, e.ctx_bf16, e.lse = ptr(sv["xn"]), ptr(sv["rstd"]), ptr(sv["qkv"]), ptr(sv["ctx"]), ptr(sv["lse"])
+    if bias is not None:
+        e.bias, e.bias_q, e.bias_k = ptr(bias), bias.shape[1], bias.shape[2]
+    e.key_mask, e.mask_value = ptr(key_mask), mask_value
+    e.B, e.S, e.H, e.d_model, e.eps = B, S, H, d, eps
+    e.drop_p, e.seed_probs, e.seed_out = drop_p, seeds[0], seeds[1]
+    check(lib().vlt5_enc_attn_fwd(C.byref(e), stream_ptr()), "vlt5_enc_attn_fwd")
+    sv["desc"] = e
+    return out, sv
+
+
+def enc_attn_sublayer_bwd(dy, sv, want_dscores=False):
+    """Backward through `vlt5_enc_attn_bwd`: returns dx, d_wqkv, d_wo, d_ln_w (f32) and, optionally, the per-sample bias-block gradient."""
+    from ._lib import EncAttnGrads
+    e = sv["desc"]
+    dev = dy.device
+    g = EncAttnGrads()
+    dx = torch.empty_like(dy)
+    dwqkv = torch.empty(sv["wqkv"].shape, device=dev, dtype=torch.float32)
+    dwo = torch.empty(sv["wo"].shape, device=dev, dtype=torch.float32)
+    dln = torch.empty(sv["ln_w"].shape, device=dev, dtype=torch.float32)
+    ds = None
+    if want_dscores and sv["bias"] is not None:
+        ds = torch.zeros(e.B, e.H, e.bias_q, e.bias_k, device=dev, dtype=torch.float32)
+    ws = torch.empty(lib().vlt5_enc_attn_bwd_workspace_bytes(e.B, e.S, e.H, e.d_model), device=dev, dtype=torch.uint8)
+    g.dy, g.dx, g.d_wqkv, g.d_wo, g.d_ln_w, g.d_scores = ptr(_need(dy, torch.float32)), ptr(dx), ptr(dwqkv), ptr(dwo), ptr(dln), ptr(ds)
+    check(lib().vlt5_enc_attn_bwd(C.byref(e), C.byref(g), ptr(ws), stream_ptr()), "vlt5_enc_attn_bwd")
+    return dx, dwqkv, dwo, dln, ds
