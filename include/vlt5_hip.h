@@ -44,7 +44,7 @@ typedef struct {
     float drop_p; uint32_t drop_seed;        /* inverted dropout on element index m*N+n */
     int relu, out_f32, accum;                /* accum: C += (f32 only) */
     int split_k; void* workspace;            /* split_k>1: f32 slabs [split_k][M*ldc], plain epilogue, ldc==N */
-    int tile_m, tile_n;                      /* 0 = heuristic; else 64x64, 64x128, 128x64, 128x128 or 256x256 */
+    int tile_m, tile_n;                      /* 0 = heuristic; else 64x64, 64x128, 128x64, 128x128, 256x256 or (row-major A) 224x256, 160x256 */
     int batch;                               /* > 1: batch of equal-shaped GEMMs (grid.z); entry z uses A + z*batch_stride_a, ... */
     long long batch_stride_a, batch_stride_b, batch_stride_c;   /* element strides (may be negative); resid uses batch_stride_c */
     int defer_reduce;                        /* split_k>1: leave the f32 slabs in `workspace` (slab s = partial sum of k-slice s) for

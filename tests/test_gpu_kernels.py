@@ -49,7 +49,7 @@ def close_norm(a, b, rel_fro, rel_max, what=""):
 # ---------------------------------------------------------------------------------------------------------------
 # GEMM
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [(0, 0), (256, 256), (128, 128), (128, 64), (64, 128), (64, 64)])
+@pytest.mark.parametrize("tile", [(0, 0), (256, 256), (224, 256), (160, 256), (128, 128), (128, 64), (64, 128), (64, 64)])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (400, 768, 768), (20, 64, 64), (4480, 768, 768), (136, 2304, 200)])
 def test_gemm_forward_layout(dev, tile, M, N, K):
     from vqacl_amd import ops
@@ -64,7 +64,7 @@ def test_gemm_forward_layout(dev, tile, M, N, K):
     close(outb, ref, 1e-2, 5e-2, "gemm NT bf16")
 
 
-@pytest.mark.parametrize("tile", [(256, 256), (128, 128), (64, 64), (0, 0)])
+@pytest.mark.parametrize("tile", [(256, 256), (224, 256), (160, 256), (128, 128), (64, 64), (0, 0)])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 256), (400, 768, 2304), (4480, 768, 3072), (24, 64, 128)])
 def test_gemm_dgrad_layout(dev, tile, M, N, K):
     """dX[M,N] = dY[M,K] W[K,N]: the weight is read k-major."""
@@ -122,14 +122,14 @@ def test_gemm_epilogues(dev, tile, M, N, K):
 
 
 def test_gemm_randomised_shapes_layouts_and_epilogues(dev):
-    """60 seeded random problems: ragged M (any), N and K multiples of 8 (K tails below 64), every operand layout, every tile,
+    """80 seeded random problems: ragged M (any), N and K multiples of 8 (K tails below 64), every operand layout, every tile,
     padded leading dimensions, split-K, layer batches, and the epilogue combinations the engine issues -- against torch f32."""
     import random as _r
     from vqacl_amd import ops
     rr = _r.Random(2024)
     g = torch.Generator().manual_seed(2024)
-    tiles = [(0, 0), (64, 64), (64, 128), (128, 64), (128, 128), (256, 256)]
-    for case in range(60):
+    tiles = [(0, 0), (64, 64), (64, 128), (128, 64), (128, 128), (256, 256), (224, 256), (160, 256)]
+    for case in range(80):
         M = rr.choice([1, 5, 17, 63, 64, 65, 200, 400, 513, 1000])
         N = 8 * rr.randint(1, 70)
         K = 8 * rr.randint(1, 60)
@@ -137,6 +137,8 @@ def test_gemm_randomised_shapes_layouts_and_epilogues(dev):
         if akm:
             M = max(8, M // 8 * 8)                       # a k-major operand is read in 8-element vectors along its rows
         tile = rr.choice(tiles)
+        if akm and tile[0] in (224, 160):
+            tile = (256, 256)                            # the 224- / 160-row tiles take a row-major A only
         batch = rr.choice([1, 1, 1, 3])
         pad_a, pad_b = 8 * rr.randint(0, 2), 8 * rr.randint(0, 2)
         Af = rnd((batch, K, M + pad_a) if akm else (batch, M, K + pad_a), g)

@@ -8,6 +8,8 @@ vlt5gemm::TimingState vlt5_gemm_timing_state;
 
 namespace vlt5gemm {
 int launch_256x256(const GemmArgs& a, int akm, int bkm, int splits, int batch, hipStream_t st);
+int launch_224x256(const GemmArgs& a, int akm, int bkm, int splits, int batch, hipStream_t st);
+int launch_160x256(const GemmArgs& a, int akm, int bkm, int splits, int batch, hipStream_t st);
 int launch_128x128(const GemmArgs& a, int akm, int bkm, int splits, int batch, hipStream_t st);
 int launch_128x64(const GemmArgs& a, int akm, int bkm, int splits, int batch, hipStream_t st);
 int launch_64x128(const GemmArgs& a, int akm, int bkm, int splits, int batch, hipStream_t st);
@@ -60,7 +62,19 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         // layer-batched FFN weight gradients: 455 us against 385-410 us with 128 x 128)
         // (also for a small output with a very long reduction cut into slices by vlt5_gemm_auto_split: the input gradients
         // of lm_head and of the stacked cross-attention K/V projection)
-        if (!d->a_kmajor && (tiles(256, 256) >= 160 || (d->K >= 8192 && d->split_k > 1 && tiles(256, 256) >= 128))) { bm = 256; bn = 256; }
+        if (!d->a_kmajor && (tiles(256, 256) >= 160 || (d->K >= 8192 && d->split_k > 1 && tiles(256, 256) >= 128))) {
+            // 8-wave kernel; its tile HEIGHT is chosen to fill the 256 CUs: a launch costs about (fixed part + k-steps x height/256)
+            // per round of 256 workgroups, the fixed part (launch, prologue, epilogue) being worth ~9 k-steps of the full tile
+            // (FFN-in forward 4480 x 3072: 216 tiles of 256 rows = 84 % of the CUs -> 240 tiles of 224 rows)
+            bn = 256;
+            const int nks = (d->K + BK - 1) / BK / (d->split_k > 1 ? d->split_k : 1);
+            double best = 1e30;
+            for (int h : {256, 224, 160}) {
+                const long t = tiles(h, 256);
+                const double cost = (double)((t + 255) / 256) * (9.0 + nks * (h / 256.0));
+                if (cost < best - 1e-9) { best = cost; bm = h; }
+            }
+        }
         // (with k-major operands the 64-wide tiles run the deeper fragment pipeline, KM_STEP, and win below this threshold;
         // above it -- the layer-batched weight gradients -- 128 x 128 is still 25 % faster)
         else if (tiles(128, 128) >= 768) { bm = 128; bn = 128; }       // >= 3 workgroups per CU of the big tile
@@ -71,7 +85,8 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         }
         else { bm = 64; bn = 64; }                                     // small-M (decoder) problems: most workgroups
     }
-    if (!(((bm == 128 || bm == 64) && (bn == 128 || bn == 64)) || (bm == 256 && bn == 256))) return VLT5_ERR_ARG;
+    if (!(((bm == 128 || bm == 64) && (bn == 128 || bn == 64)) || ((bm == 256 || bm == 224 || bm == 160) && bn == 256))) return VLT5_ERR_ARG;
+    if ((bm == 224 || bm == 160) && d->a_kmajor) return VLT5_ERR_ARG;
 
     int splits = d->split_k > 1 ? d->split_k : 1;
     const int nk = (d->K + BK - 1) / BK;
@@ -86,6 +101,8 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
     }
     int rc;
     if (bm == 256) rc = launch_256x256(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
+    else if (bm == 224) rc = launch_224x256(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
+    else if (bm == 160) rc = launch_160x256(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
     else if (bm == 128 && bn == 128) rc = launch_128x128(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
     else if (bm == 128 && bn == 64) rc = launch_128x64(a, d->a_kmajor, d->b_kmajor, splits, batch, st);
     else if (bm == 64 && bn == 128) rc = launch_64x128(a, d->a_kmajor, d->b_kmajor, splits, batch, st);

@@ -73,7 +73,7 @@ template <int R, int NT>
 __device__ __forceinline__ void gload_rm(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, int K,
                                          uint4 (&v)[8], int tid) {
 #pragma unroll
-    for (int i = 0; i < R * 8 / NT; ++i) {
+    for (int i = 0; i < (R * 8 + NT - 1) / NT; ++i) {
         int c = tid + i * NT;
         int row = c >> 3, kc = c & 7;
         int gr = row0 + row, gk = k0 + kc * 8;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void gload_rm(const bf16_t* __restrict__ base, int ld
 template <int R, int NT>
 __device__ __forceinline__ void lstore_rm(char* tile, const uint4 (&v)[8], int tid) {
 #pragma unroll
-    for (int i = 0; i < R * 8 / NT; ++i) {
+    for (int i = 0; i < (R * 8 + NT - 1) / NT; ++i) {
         int c = tid + i * NT;
         int row = c >> 3, kc = c & 7;
         *reinterpret_cast<uint4*>(tile + lds_off(row, kc)) = v[i];
@@ -154,7 +154,8 @@ template <int R, int NT>
 __device__ __forceinline__ void glds_rm(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, char* tile, int tid) {
     const int wave_base = (tid & ~63);
 #pragma unroll
-    for (int i = 0; i < R * 8 / NT; ++i) {
+    for (int i = 0; i < (R * 8 + NT - 1) / NT; ++i) {       // (a tile height that is no multiple of NT/8 rows: the last piece also
+                                                             // fetches clamped rows past the tile into the padding of its LDS region)
         const int c = tid + i * NT;
         const int row = c >> 3, kc = (c & 7) ^ (row & 7);
         const int gr = min(row0 + row, rmax - 1);
@@ -230,7 +231,8 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;                 // wave tile
     constexpr int FM = TM / 16, FN = TN / 16;                 // 16x16 fragments per wave
-    constexpr int LPT = (BM + BN) * 8 / NT;                   // LDS-DMA wave-instructions ("pieces") per k-tile per wave
+    constexpr int PA_ = (BM * 8 + NT - 1) / NT, PB_ = (BN * 8 + NT - 1) / NT;
+    constexpr int LPT = PA_ + PB_;                            // LDS-DMA wave-instructions ("pieces") per k-tile per wave
     // k-major operands on the 4-wave tiles up to 64x128: the transpose reads are 8-byte-per-lane LDS reads, which need many
     // reads in flight per wave to approach the LDS rate -- fetch the fragments of BOTH 32-wide halves up front (and spread
     // the DMA pieces between the MFMAs).  Measured -20..-40 % on dgrad / wgrad shapes; the same scheme costs 5-10 % on
@@ -246,7 +248,11 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
 #ifndef GEMM_PINGPONG
 #define GEMM_PINGPONG 0
 #endif
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    // (region sizes in whole pieces: 224 x 64 is 3.5 pieces of 512 lanes -> 4, the tail holds clamped duplicate rows nobody reads)
+    constexpr int A_BYTES = PA_ * NT * 16, B_BYTES = PB_ * NT * 16;
+    static_assert(A_BYTES >= BM * BK * 2 && B_BYTES >= BN * BK * 2, "regions hold the tiles");
+    static_assert((BM * 8) % NT == 0 || (!AKM && WM * WN == 8), "partial pieces: row-major A of the 8-wave kernel only");
+    static_assert((BN * 8) % NT == 0, "B tiles are whole pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;        // stage s: A tile at s*STAGE_BYTES, B tile right after it
     constexpr int NSTAGE = NS;                            // default: 3 stages up to 64x128 (72 KB, 2 workgroups/CU), 2 for 128x128
@@ -309,7 +315,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     auto glds_piece = [&](int kt, int s, int pc) __attribute__((always_inline)) {
         char* at = smem + s * STAGE_BYTES;
         char* bt = at + A_BYTES;
-        constexpr int PA = BM * 8 / NT;
+        constexpr int PA = PA_;
         if (pc < PA) {
             if (AKM) glds_km_piece<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, at, tid, pc); else glds_rm_piece<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, at, tid, pc);
         } else {
@@ -653,6 +659,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
             if constexpr (kAux || kGate) {
 #pragma unroll
                 for (int ii = 0; ii < IC; ++ii) {
+                    if (ib + ii >= FM) continue;
                     const int m = m0 + wm * TM + (ib + ii) * 16 + lrow;
 #pragma unroll
                     for (int j = 0; j < FN; ++j) {
@@ -709,6 +716,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
             };
 #pragma unroll
             for (int ii = 0; ii < IC; ++ii) {
+                if (ib + ii >= FM) continue;
                 const int m = m0 + wm * TM + (ib + ii) * 16 + lrow;
                 if constexpr (kF32) {
                     if (m >= p.M) continue;
@@ -794,7 +802,8 @@ namespace vlt5gemm {
 
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
 int launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
-    constexpr size_t lds = (size_t)NS * (BM + BN) * BK * 2;
+    constexpr int NT_ = WM * WN * 64;
+    constexpr size_t lds = (size_t)NS * ((BM * 8 + NT_ - 1) / NT_ + (BN * 8 + NT_ - 1) / NT_) * NT_ * 16;
     static bool attr_set = false;                           // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
     if (!attr_set) {
         HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WM, WN, AKM, BKM, NS>),
@@ -822,11 +831,15 @@ int launch_tile(const GemmArgs& a, int akm, int bkm, int splits, int batch, hipS
     // ring depth: 3 stages up to 64x128 (72 KB, 2 workgroups/CU); 2 for 128x128 (a 3-stage ring = 96 KB = 1 workgroup/CU
     // measured 13 % slower end to end: occupancy matters more) and for 256x256 (2 x 64 KB, one 8-wave workgroup per CU)
     constexpr int NS = (BM + BN <= 192) ? 3 : 2;
-    constexpr int WM = 2, WN = (BM == 256 && BN == 256) ? 4 : 2;
+    constexpr int WM = 2, WN = (BN == 256) ? 4 : 2;          // 256-wide tiles: the 8-wave kernel
     if (!akm && !bkm) return launch_one<BM, BN, WM, WN, false, false, NS>(a, grid, st);
     if (!akm && bkm) return launch_one<BM, BN, WM, WN, false, true, NS>(a, grid, st);
-    if (akm && bkm) return launch_one<BM, BN, WM, WN, true, true, NS>(a, grid, st);
-    return launch_one<BM, BN, WM, WN, true, false, NS>(a, grid, st);
+    if constexpr ((BM * 8) % (WM * WN * 64) == 0) {          // (224 / 160 rows: row-major A only)
+        if (akm && bkm) return launch_one<BM, BN, WM, WN, true, true, NS>(a, grid, st);
+        return launch_one<BM, BN, WM, WN, true, false, NS>(a, grid, st);
+    } else {
+        return VLT5_ERR_ARG;
+    }
 }
 
 #undef g_timing
