@@ -150,7 +150,10 @@ def insitu_gemm_roofline(step_fn, n_steps):
         gf = 2.0 * r.batch * r.M * r.N * r.K / 1e9
         tot_ms += r.ms
         tot_gflop += gf
-        key = (f"gemm_kernel<{r.tile_m},{r.tile_n},{'km' if r.a_kmajor else 'rm'},{'km' if r.b_kmajor else 'rm'}>")
+        if (r.tile_m, r.tile_n) == (128, 384):      # the fused q|k|v projection + attention core (its 2*M*N*K is the projection alone)
+            key = "qkv_attn_fwd_kernel<128,384> (projection + attention core)"
+        else:
+            key = (f"gemm_kernel<{r.tile_m},{r.tile_n},{'km' if r.a_kmajor else 'rm'},{'km' if r.b_kmajor else 'rm'}>")
         k = by.setdefault(key, [0, 0.0, 0.0])
         k[0] += 1
         k[1] += r.ms
@@ -159,7 +162,7 @@ def insitu_gemm_roofline(step_fn, n_steps):
     achieved = tot_gflop / tot_ms                       # GFLOP/ms == TFLOP/s
     per_kernel = {k: dict(calls_per_step=round(v[0] / n_steps, 1), avg_us=round(v[1] / v[0] * 1e3, 2), ms_per_step=round(v[1] / n_steps, 3),
                           tflops=round(v[2] / v[1], 1)) for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
-    return dict(bound="mfma", kernel="gemm_kernel<BM,BN,AKM,BKM> (all instantiations, in situ)", achieved=round(achieved, 2),
+    return dict(bound="mfma", kernel="gemm_kernel<BM,BN,AKM,BKM> (all instantiations) + qkv_attn_fwd_kernel, in situ", achieved=round(achieved, 2),
                 peak=MFMA_BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), traffic=None,
                 launches_per_step=round(launches, 1), avg_launch_us=round(tot_ms / n * 1e3, 2),
                 gflop_per_launch=round(tot_gflop / n, 3), gemm_ms_per_step=round(tot_ms / n_steps, 3),

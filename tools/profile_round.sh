@@ -15,7 +15,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pf -o r -- python3 $ROO
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pw -o r -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-side-values > $OUT/${TAG}_pw.log 2>&1
 python3 $ROOT/tools/rocpd_pmc.py $(find $OUT/${TAG}_pf -name "*.db" | head -1) $(find $OUT/${TAG}_pw -name "*.db" | head -1) $OUT/${TAG}_pmc_hbm_traffic.json > $OUT/${TAG}_pmc_hbm_traffic.txt
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace -d $OUT/${TAG}_pm -o r -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-side-values > $OUT/${TAG}_pm.log 2>&1
-python3 $ROOT/tools/rocpd_counters.py $(find $OUT/${TAG}_pm -name "*.db" | head -1) --match gemm_kernel > $OUT/${TAG}_pmc_mfma_util.txt
+python3 $ROOT/tools/rocpd_counters.py $(find $OUT/${TAG}_pm -name "*.db" | head -1) --match _kernel > $OUT/${TAG}_pmc_mfma_util.txt
 cd $ROOT && python3 tools/gemm_sweep.py --graph --torch-ref > $OUT/${TAG}_gemm_tile_sweep.txt 2>&1
 # the raw rocpd databases are tens of MB each and gpurun only copies 64 MiB back: keep the summaries, drop the databases
 rm -rf $OUT/${TAG}_kt $OUT/${TAG}_pf $OUT/${TAG}_pw $OUT/${TAG}_pm

@@ -246,8 +246,17 @@ extern "C" int vlt5_qkv_attn_fwd(const void* xn_bf16, const void* wqkv_bf16, voi
         attr_set = true;
     }
     const int grid = ((a.B + 1) / 2) * (a.H / 2);
+    vlt5gemm::TimingState& tm = vlt5_gemm_timing_state;           // bench.py's in-situ roofline covers this MFMA kernel too
     if (g_tl_buf) hipLaunchKernelGGL(qkv_attn_fwd_kernel<true>, dim3(grid), dim3(FNT), FUSED_LDS, (hipStream_t)stream, a, g_tl_buf);
-    else hipLaunchKernelGGL(qkv_attn_fwd_kernel<false>, dim3(grid), dim3(FNT), FUSED_LDS, (hipStream_t)stream, a, (unsigned long long*)nullptr);
+    else if (tm.on && tm.rec.size() < tm.cap) {
+        const size_t i = tm.rec.size();
+        vlt5_gemm_timing_rec r;
+        r.M = a.B * a.S; r.N = 3 * inner; r.K = a.d; r.batch = 1; r.tile_m = FBM; r.tile_n = FBN; r.a_kmajor = 0; r.b_kmajor = 0;
+        r.splits = 1; r.workgroups = grid; r.ms = 0.f;
+        tm.rec.push_back(r);
+        hipExtLaunchKernelGGL(qkv_attn_fwd_kernel<false>, dim3(grid), dim3(FNT), FUSED_LDS, (hipStream_t)stream, tm.ev[2 * i], tm.ev[2 * i + 1],
+                              0, a, (unsigned long long*)nullptr);
+    } else hipLaunchKernelGGL(qkv_attn_fwd_kernel<false>, dim3(grid), dim3(FNT), FUSED_LDS, (hipStream_t)stream, a, (unsigned long long*)nullptr);
     LAUNCH_CHECK();
     return VLT5_OK;
 }
