@@ -14,6 +14,7 @@
 // leaves registers.  The backward recomputes P from the saved row log-sum-exp and regenerates the
 // dropout mask from the counter-based hash.
 #include "attn_core.h"
+#include <cstdlib>
 
 using namespace vlt5attn;
 
@@ -44,6 +45,132 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     __syncthreads();
     if (i0 >= p.Tq) return;
     attn_fwd_rows<DK64>(p, Qs, Ks, Vs, b, h, i0, lane, add);
+}
+
+// ---- backward building blocks (one wave each) -------------------------------------------------------------------------------
+// phase A, query rows i0 .. i0+15: recompute P from the saved log-sum-exp, dP = dO V^T, dS = P (dP - sum_j dP P); leaves
+// Pd = dropout(P) and dS in registers (pd, ds; the swapped score layout), stores the dQ rows and the bias-block gradient
+template <bool DK64>
+__device__ __forceinline__ void attn_bwd_rows(const AttnArgs& p, const bf16_t* Qs, const bf16_t* Ks, const bf16_t* Vs, const bf16_t* dOs,
+                                              int b, int h, int i0, int lane, const float (&add)[4][4], float lse, float (&pd)[4][4],
+                                              float (&ds)[4][4]) {
+    const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
+    const long long hoff = (long long)h * p.dk;
+    const int ndb = DK64 ? 4 : (p.dk + 15) / 16;
+    const int nks = DK64 ? 2 : (p.dk > 32 ? 2 : 1);
+    float s[4][4];
+    scores_16x64<DK64>(p, Qs, Ks, b, h, i0, lane, add, s);
+    // dPd[i][j] = sum_d dO[i][d] V[j][d]  (same swapped layout as the scores)
+    f32x4_t dacc[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) dacc[jb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        if (ks >= nks) break;
+        bf16x8_t fo = lds_frag(dOs, i0 + lr, ks * 4 + g);
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            bf16x8_t fv = lds_frag(Vs, jb * 16 + lr, ks * 4 + g);
+            dacc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fo, dacc[jb], 0, 0, 0);
+        }
+    }
+    const float dsc = drop_scale(p.drop_thr);
+    float dsum = 0.f;
+    float pr[4][4], dp[4][4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        bool kp[4] = {true, true, true, true};
+        if (p.drop_thr)
+            drop_keep4(p.drop_seed, (uint32_t)((((size_t)b * p.H + h) * p.Tq + i) * p.Tk + jb * 16 + g * 4), p.drop_thr, kp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = jb * 16 + g * 4 + r;
+            const float pv = (i < p.Tq && j < p.Tk) ? fast_exp(s[jb][r] - lse) : 0.f;
+            const float keep = p.drop_thr ? (kp[r] ? dsc : 0.f) : 1.f;
+            pr[jb][r] = pv;
+            pd[jb][r] = pv * keep;
+            dp[jb][r] = dacc[jb][r] * keep;
+            dsum += dp[jb][r] * pv;
+        }
+    }
+    dsum = quad_lane_sum(dsum);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ds[jb][r] = pr[jb][r] * (dp[jb][r] - dsum);
+            const int j = jb * 16 + g * 4 + r;
+            if (p.dbias && i < p.bias_q && j < p.bias_k && i < p.Tq && j < p.Tk)
+                p.dbias[(((size_t)b * p.H + h) * p.bias_q + i) * p.bias_k + j] = ds[jb][r];
+        }
+    // dQ[i][d] = sum_j dS[i][j] K[j][d]   (K^T gathered from the natural K tile with transpose reads)
+    bf16x8_t dsf[2] = {pack_slots(ds[0], ds[1]), pack_slots(ds[2], ds[3])};
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        if (db >= ndb) break;
+        f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk * 32 < p.Tk) {
+                bf16x8_t fk = frag_tr_slots(Ks, db * 16, kk, lane);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, dsf[kk], o, 0, 0, 0);
+            }
+        }
+        const int d = db * 16 + g * 4;
+        if (i < p.Tq && d < p.dk) {
+            uint2 pk;
+            pk.x = pack_bf16x2(o[0], o[1]);
+            pk.y = pack_bf16x2(o[2], o[3]);
+            *reinterpret_cast<uint2*>(p.dq + b * p.dq_sb + (long long)i * p.dq_st + hoff + d) = pk;
+        }
+    }
+}
+// Pd / dS of rows i0 .. i0+15 into the natural [i][j] tiles: 4 consecutive j per (lane, jb) -> one 8-byte store each
+__device__ __forceinline__ void attn_bwd_put(bf16_t* Ps, bf16_t* dSs, int i0, int lane, const float (&pd)[4][4], const float (&ds)[4][4]) {
+    const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        uint2 a, c;
+        a.x = pack_bf16x2(pd[jb][0], pd[jb][1]); a.y = pack_bf16x2(pd[jb][2], pd[jb][3]);
+        c.x = pack_bf16x2(ds[jb][0], ds[jb][1]); c.y = pack_bf16x2(ds[jb][2], ds[jb][3]);
+        *reinterpret_cast<uint2*>(Ps + i * TS + jb * 16 + g * 4) = a;
+        *reinterpret_cast<uint2*>(dSs + i * TS + jb * 16 + g * 4) = c;
+    }
+}
+// phase B, key rows j0 .. j0+15:  dV = Pd^T dO,  dK = dS^T Q  (reduction over the queries i); all four operands are transposed
+// views of natural tiles -> ds_read_b64_tr_b16
+template <bool DK64>
+__device__ __forceinline__ void attn_bwd_keys(const AttnArgs& p, const bf16_t* Ps, const bf16_t* dSs, const bf16_t* dOs, const bf16_t* Qs,
+                                              int b, int h, int j0, int lane) {
+    const int lr = lane & 15, g = lane >> 4, j = j0 + lr;
+    const long long hoff = (long long)h * p.dk;
+    const int ndb = DK64 ? 4 : (p.dk + 15) / 16;
+    const int nis = p.Tq > 32 ? 2 : 1;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        if (db >= ndb) break;
+        f32x4_t av = (f32x4_t){0.f, 0.f, 0.f, 0.f}, ak = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks >= nis) break;
+            bf16x8_t fp = frag_tr_std(Ps, j0, ks, lane);          // Pd^T[j][i]
+            bf16x8_t fs = frag_tr_std(dSs, j0, ks, lane);         // dS^T[j][i]
+            bf16x8_t fo = frag_tr_std(dOs, db * 16, ks, lane);    // dO^T[d][i]
+            bf16x8_t fq = frag_tr_std(Qs, db * 16, ks, lane);     // Q^T[d][i]
+            av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo, fp, av, 0, 0, 0);
+            ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, fs, ak, 0, 0, 0);
+        }
+        const int d = db * 16 + g * 4;
+        if (j < p.Tk && d < p.dk) {
+            uint2 pk;
+            pk.x = pack_bf16x2(av[0], av[1]);
+            pk.y = pack_bf16x2(av[2], av[3]);
+            *reinterpret_cast<uint2*>(p.dv + b * p.dv_sb + (long long)j * p.dv_st + hoff + d) = pk;
+            pk.x = pack_bf16x2(ak[0], ak[1]);
+            pk.y = pack_bf16x2(ak[2], ak[3]);
+            *reinterpret_cast<uint2*>(p.dk_ + b * p.dk_sb + (long long)j * p.dk_st + hoff + d) = pk;
+        }
+    }
 }
 
 template <bool DK64>
@@ -77,130 +204,23 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
         tile_store(dOs, tid, ro);
     }
     __syncthreads();
-
     const int i0 = wave * 16;
-    const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
-    const bool active = i0 < p.Tq;              // wave-uniform
     float pd[4][4], ds[4][4];
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pd[jb][r] = 0.f; ds[jb][r] = 0.f; }
-    const int ndb = DK64 ? 4 : (p.dk + 15) / 16;
-    const int nks = DK64 ? 2 : (p.dk > 32 ? 2 : 1);
-
-    if (active) {
-        float s[4][4];
-        scores_16x64<DK64>(p, Qs, Ks, b, h, i0, lane, add, s);
-        const float lse = lse_row;
-        // dPd[i][j] = sum_d dO[i][d] V[j][d]  (same swapped layout as the scores)
-        f32x4_t dacc[4];
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) dacc[jb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (ks >= nks) break;
-            bf16x8_t fo = lds_frag(dOs, i0 + lr, ks * 4 + g);
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb) {
-                bf16x8_t fv = lds_frag(Vs, jb * 16 + lr, ks * 4 + g);
-                dacc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fo, dacc[jb], 0, 0, 0);
-            }
-        }
-        const float dsc = drop_scale(p.drop_thr);
-        float dsum = 0.f;
-        float pr[4][4], dp[4][4];
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-            bool kp[4] = {true, true, true, true};
-            if (p.drop_thr)
-                drop_keep4(p.drop_seed, (uint32_t)((((size_t)b * p.H + h) * p.Tq + i) * p.Tk + jb * 16 + g * 4), p.drop_thr, kp);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = jb * 16 + g * 4 + r;
-                const float pv = (i < p.Tq && j < p.Tk) ? fast_exp(s[jb][r] - lse) : 0.f;
-                const float keep = p.drop_thr ? (kp[r] ? dsc : 0.f) : 1.f;
-                pr[jb][r] = pv;
-                pd[jb][r] = pv * keep;
-                dp[jb][r] = dacc[jb][r] * keep;
-                dsum += dp[jb][r] * pv;
-            }
-        }
-        dsum = quad_lane_sum(dsum);
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ds[jb][r] = pr[jb][r] * (dp[jb][r] - dsum);
-                const int j = jb * 16 + g * 4 + r;
-                if (p.dbias && i < p.bias_q && j < p.bias_k && i < p.Tq && j < p.Tk)
-                    p.dbias[(((size_t)b * p.H + h) * p.bias_q + i) * p.bias_k + j] = ds[jb][r];
-            }
-        // dQ[i][d] = sum_j dS[i][j] K[j][d]   (K^T gathered from the natural K tile with transpose reads)
-        bf16x8_t dsf[2] = {pack_slots(ds[0], ds[1]), pack_slots(ds[2], ds[3])};
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            if (db >= ndb) break;
-            f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                if (kk * 32 < p.Tk) {
-                    bf16x8_t fk = frag_tr_slots(Ks, db * 16, kk, lane);
-                    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, dsf[kk], o, 0, 0, 0);
-                }
-            }
-            const int d = db * 16 + g * 4;
-            if (i < p.Tq && d < p.dk) {
-                uint2 pk;
-                pk.x = pack_bf16x2(o[0], o[1]);
-                pk.y = pack_bf16x2(o[2], o[3]);
-                *reinterpret_cast<uint2*>(p.dq + b * p.dq_sb + (long long)i * p.dq_st + hoff + d) = pk;
-            }
-        }
-    }
+    if (i0 < p.Tq) attn_bwd_rows<DK64>(p, Qs, Ks, Vs, dOs, b, h, i0, lane, add, lse_row, pd, ds);      // wave-uniform
     __syncthreads();                     // every wave is done with the K / V tiles -> reuse them for Pd / dS
-    // natural [i][j] layout: 4 consecutive j per (lane, jb) -> one 8-byte store each
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-        uint2 a, c;
-        a.x = pack_bf16x2(pd[jb][0], pd[jb][1]); a.y = pack_bf16x2(pd[jb][2], pd[jb][3]);
-        c.x = pack_bf16x2(ds[jb][0], ds[jb][1]); c.y = pack_bf16x2(ds[jb][2], ds[jb][3]);
-        *reinterpret_cast<uint2*>(Ps + i * TS + jb * 16 + g * 4) = a;
-        *reinterpret_cast<uint2*>(dSs + i * TS + jb * 16 + g * 4) = c;
-    }
+    attn_bwd_put(Ps, dSs, i0, lane, pd, ds);
     __syncthreads();
-    // phase B: wave w owns key rows 16w..16w+15;  dV = Pd^T dO,  dK = dS^T Q  (reduction over the queries i);
-    // all four operands are transposed views of natural tiles -> ds_read_b64_tr_b16
-    const int j0 = wave * 16;
-    if (j0 >= p.Tk) return;
-    const int j = j0 + lr;
-    const int nis = p.Tq > 32 ? 2 : 1;
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-        if (db >= ndb) break;
-        f32x4_t av = (f32x4_t){0.f, 0.f, 0.f, 0.f}, ak = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (ks >= nis) break;
-            bf16x8_t fp = frag_tr_std(Ps, j0, ks, lane);          // Pd^T[j][i]
-            bf16x8_t fs = frag_tr_std(dSs, j0, ks, lane);         // dS^T[j][i]
-            bf16x8_t fo = frag_tr_std(dOs, db * 16, ks, lane);    // dO^T[d][i]
-            bf16x8_t fq = frag_tr_std(Qs, db * 16, ks, lane);     // Q^T[d][i]
-            av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo, fp, av, 0, 0, 0);
-            ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, fs, ak, 0, 0, 0);
-        }
-        const int d = db * 16 + g * 4;
-        if (j < p.Tk && d < p.dk) {
-            uint2 pk;
-            pk.x = pack_bf16x2(av[0], av[1]);
-            pk.y = pack_bf16x2(av[2], av[3]);
-            *reinterpret_cast<uint2*>(p.dv + b * p.dv_sb + (long long)j * p.dv_st + hoff + d) = pk;
-            pk.x = pack_bf16x2(ak[0], ak[1]);
-            pk.y = pack_bf16x2(ak[2], ak[3]);
-            *reinterpret_cast<uint2*>(p.dk_ + b * p.dk_sb + (long long)j * p.dk_st + hoff + d) = pk;
-        }
-    }
+    if (wave * 16 < p.Tk) attn_bwd_keys<DK64>(p, Ps, dSs, dOs, Qs, b, h, wave * 16, lane);              // wave w owns key rows 16w..
 }
+
+// (Tried and removed, round 2: few-query variants for the decoder (Tq <= 16) in which a WAVE owns a (batch, head), stages its own
+// wave-private tiles and runs these building blocks with no workgroup barrier.  Correct, but slower in situ than the kernels here
+// -- forward 6.3 / 9.3 us against 6.1 / 8.3 (self / cross), backward 10.3 / 16.9 against 8.8 / 14.7: staging a tile with 64 lanes
+// instead of 256 costs more than the three idle waves it removes.)
 
 int fill_args(const vlt5_attn_desc* d, AttnArgs& a, bool bwd) {
     if (!d || !d->q || !d->k || !d->v) return VLT5_ERR_ARG;
