@@ -103,43 +103,59 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
 #pragma unroll
         for (int j = 0; j < FFN_; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // ---- phase 1: the interleaved k-step of the 8-wave GEMM (kstep_big in gemm_kernel.h) on a 128 x 384 tile ---------------
+    // ---- phase 1: [128 x d] . [384 x d]^T, BK = 64, two LDS stages, software-pipelined across the k-steps -------------------
+    // A k-step is two halves (ks = 0 / 1: the two 32-deep MFMA slabs of the 64-deep tile) with the workgroup barrier BETWEEN them:
+    //   ks = 0 half of tile t :  MFMAs on fragments fetched during the previous step; fetch the ks = 1 fragments of tile t
+    //   wait (tile t+1 landed; the ks = 1 fragments returned) + barrier  -> stage of tile t is free, stage of tile t+1 is complete
+    //   ks = 1 half of tile t :  MFMAs; request tile t+2 into the freed stage (LDS-DMA); fetch the ks = 0 fragments of tile t+1
+    // so the matrix pipe never starts a half behind a fragment read (the barrier-at-the-top form of the 8-wave GEMM idles ~450 of
+    // its ~2260 cycles per step there), and a DMA piece has a full step to land.  No extra registers: each half fetches into the
+    // fragment set the other half has just retired.
     const int nk = p.d / BK;
-#pragma unroll
-    for (int pc = 0; pc < LPT; ++pc) piece(0, 0, pc);
-    int stage = 0;
-    stamp(1);
-    for (int it = 0; it < nk; ++it) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (TL && it == 1) stamp(2);
-        const int kt_pf = min(it + 1, nk - 1), s_pf = stage ^ 1;        // the last step re-requests the final k-tile (branch-free)
-        const char* at = smem + stage * STAGE_BYTES;
-        const char* bt = at + A_BYTES;
-        bf16x8_t fa0[FFM], fb0[FFN_], fa1[FFM], fb1[FFN_];
-#pragma unroll
-        for (int i = 0; i < FFM; ++i) fa0[i] = ldA(at, i, 0);
-#pragma unroll
-        for (int j = 0; j < FFN_; ++j) fb0[j] = ldB(bt, j, 0);
+    auto ks_half = [&](bf16x8_t (&fa)[FFM], bf16x8_t (&fb)[FFN_], bf16x8_t (&na)[FFM], bf16x8_t (&nb)[FFN_],
+                       const char* nat, const char* nbt, int nks, int kt_dma, int s_dma, bool dma) __attribute__((always_inline)) {
+        // MFMAs of the half held in (fa, fb); behind fragment row i: the reads of the next half's row i (+ its share of the B fragments)
+        // and, in a DMA half, two pieces of tile kt_dma.  Placement is left to the compiler from here: hard-pinning (all reads
+        // first + one piece behind every third MFMA, or different piece slots for the two waves of a SIMD) measured 9 - 17 % slower
+        // -- a piece blocks its wave ~100+ cycles wherever it stands (64 B/clk LDS-fill path, all eight waves in the same phase).
 #pragma unroll
         for (int i = 0; i < FFM; ++i) {
 #pragma unroll
-            for (int j = 0; j < FFN_; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
-            fa1[i] = ldA(at, i, 1);
+            for (int j = 0; j < FFN_; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            na[i] = ldA(nat, i, nks);
 #pragma unroll
             for (int j = 0; j < FFN_; ++j)
-                if (j >= vlt5gemm::bfrag_lo<FFM, FFN_>(i) && j < vlt5gemm::bfrag_lo<FFM, FFN_>(i + 1)) fb1[j] = ldB(bt, j, 1);
+                if (j >= vlt5gemm::bfrag_lo<FFM, FFN_>(i) && j < vlt5gemm::bfrag_lo<FFM, FFN_>(i + 1)) nb[j] = ldB(nbt, j, nks);
+            if (dma) {
 #pragma unroll
-            for (int pc = 0; pc < LPT; ++pc)
-                if (vlt5gemm::piece_row<FFM, LPT, true>(pc) == i) piece(kt_pf, s_pf, pc);
+                for (int pc = 0; pc < LPT; ++pc)
+                    if (vlt5gemm::piece_row<FFM, LPT, true>(pc) == i) piece(kt_dma, s_dma, pc);
+            }
         }
+    };
 #pragma unroll
-        for (int i = 0; i < FFM; ++i)
+    for (int pc = 0; pc < LPT; ++pc) piece(0, 0, pc);
 #pragma unroll
-            for (int j = 0; j < FFN_; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, FFM + FFN_, 0);
-        vlt5gemm::pin_ks0<FFM, FFN_, LPT, 1, 1, true, 0>();
-        vlt5gemm::pin_ks1<FFM, FFN_, LPT, true, 0>();
+    for (int pc = 0; pc < LPT; ++pc) piece(min(1, nk - 1), 1, pc);
+    stamp(1);
+    bf16x8_t fa0[FFM], fb0[FFN_], fa1[FFM], fb1[FFN_];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");          // tile 0 (the older group) has landed
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < FFM; ++i) fa0[i] = ldA(smem, i, 0);
+#pragma unroll
+    for (int j = 0; j < FFN_; ++j) fb0[j] = ldB(smem + A_BYTES, j, 0);
+    int stage = 0;
+    for (int it = 0; it < nk; ++it) {
+        const char* at = smem + stage * STAGE_BYTES;
+        const char* bt = at + A_BYTES;
+        const char* at2 = smem + (stage ^ 1) * STAGE_BYTES;
+        const char* bt2 = at2 + A_BYTES;
+        ks_half(fa0, fb0, fa1, fb1, at, bt, 1, 0, 0, false);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (TL && it == 0) stamp(2);
+        ks_half(fa1, fb1, fa0, fb0, at2, bt2, 0, min(it + 2, nk - 1), stage, true);   // (past the end: re-request the last tile)
         stage ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus prefetch must land before the stages are reused
