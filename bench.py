@@ -145,11 +145,13 @@ def insitu_gemm_roofline(step_fn, n_steps):
     lib().vlt5_gemm_timing_enable(0)
     assert 0 < n <= cap, n
     by = {}
-    tot_ms = tot_gflop = 0.0
+    tot_ms = tot_gflop = alg_bytes = 0.0
     for r in recs[:n]:
         gf = 2.0 * r.batch * r.M * r.N * r.K / 1e9
         tot_ms += r.ms
         tot_gflop += gf
+        # algorithmic bytes of a launch: both bf16 operands once + the output once (f32 or bf16; split-K slabs count as written)
+        alg_bytes += r.batch * (2.0 * (r.M * r.K + r.N * r.K) + (4 if r.out_f32 else 2) * r.M * r.N * max(r.splits, 1))
         if (r.tile_m, r.tile_n) == (128, 384):      # the fused q|k|v projection + attention core (its 2*M*N*K is the projection alone)
             key = "qkv_attn_fwd_kernel<128,384> (projection + attention core)"
         else:
@@ -166,6 +168,7 @@ def insitu_gemm_roofline(step_fn, n_steps):
                 peak=MFMA_BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), traffic=None,
                 launches_per_step=round(launches, 1), avg_launch_us=round(tot_ms / n * 1e3, 2),
                 gflop_per_launch=round(tot_gflop / n, 3), gemm_ms_per_step=round(tot_ms / n_steps, 3),
+                algorithmic_bytes_per_launch=round(alg_bytes / n),
                 timed_steps=n_steps, ms_per_step_while_timed=round(wall_ms, 3), per_kernel=per_kernel)
 
 
