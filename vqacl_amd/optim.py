@@ -73,6 +73,9 @@ class FusedAdamW(torch.optim.Optimizer):
         dp = getattr(model, "dp", None)
         if dp is not None and dp.grad_dtype is torch.bfloat16 and flat.is_cuda:
             dp.defer_cast_back = True
+        if dp is not None and dp.algo == "zero1" and overlap:
+            raise L.Vlt5Error("FusedAdamW(overlap=True) and the sharded step of DataParallelVLT5(algo='zero1') both order the update "
+                              "against the next forward through the per-bucket events: use one of them")
         if dp is not None and dp.algo == "zero1":
             # ZeRO-1 style step: this rank clips and updates only its chunk of every reduce-scattered slice, then the updated
             # chunks are all-gathered (parallel.py).  The all-gathers are ordered against the next forward by per-bucket events.
