@@ -32,7 +32,8 @@ def _worker(rank, world, port, q):
                         device="cpu")
         before = model.flat_params().clone()
         dp = DataParallelVLT5(model)
-        assert model.proto.dist_enabled and model.proto.dist_group is None, "default group: the statistics must still be reduced"
+        assert model.proto.dist_enabled and model.proto.dist_group is dp.ctrl_group and dp.ctrl_group is not None, \
+            "the statistics are reduced over the wrapper's small-collective group"
         gathered = [torch.zeros_like(before) for _ in range(world)]
         dist.all_gather(gathered, model.flat_params())
         assert torch.equal(gathered[0], gathered[1]), "weights must be identical after construction"

@@ -190,7 +190,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 first = False
             if first:
                 self._total_sq.zero_()
-            dist.all_reduce(self._total_sq, group=dp.group)
+            dist.all_reduce(self._total_sq, group=dp.ctrl_group)
         total = self._total_sq if clip else None
         nb = len(dp.bucket_end)
         if self._z_events is None or len(self._z_events[0]) != len(slices):

@@ -42,7 +42,7 @@ ALGOS = ("auto", "allreduce", "rs_ag", "zero1")
 
 
 class DataParallelVLT5:
-    def __init__(self, model, process_group=None, bucket_mb=128, average=True, grad_dtype=None, algo="auto"):
+    def __init__(self, model, process_group=None, bucket_mb=128, average=True, grad_dtype=None, algo="auto", small_group=True):
         self.module = model
         if grad_dtype is None:
             grad_dtype = torch.bfloat16 if model._flat.is_cuda else torch.float32
@@ -63,8 +63,15 @@ class DataParallelVLT5:
         self.average = average
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         model.dp = self
+        # the latency-critical small collectives (prototype statistics in the middle of the forward, the squared gradient norm of the
+        # sharded step) get a process group -- with RCCL: a communicator and stream -- of their own, so that they do not queue behind
+        # hundreds of MB of reduce-scatter / all-gather traffic issued earlier on the bulk group
+        self.ctrl_group = process_group
+        if self.world > 1 and small_group:
+            ranks = dist.get_process_group_ranks(process_group) if process_group is not None else None
+            self.ctrl_group = dist.new_group(ranks=ranks)
         model.proto.dist_enabled = True
-        model.proto.dist_group = process_group
+        model.proto.dist_group = self.ctrl_group
         # bucket b covers flat elements [start_b, end_b)
         ends = {}
         for name, (off, n, bucket, decay, used) in model._pinfo.items():
