@@ -128,7 +128,8 @@ class FeatureStore:
 
     def slots(self, img_ids):
         """int64 [B] slot indices on the store's device (KeyError for an image that was never put)."""
-        return torch.tensor([self.index[i] for i in img_ids], dtype=torch.long).to(self.device, non_blocking=True)
+        host = torch.tensor([self.index[i] for i in img_ids], dtype=torch.long, pin_memory=self.device.type == "cuda")
+        return host.to(self.device, non_blocking=True)      # pinned (torch's caching host allocator): stream-ordered, no host wait
 
     def ref(self, img_ids):
         return StoreRef(self, self.slots(img_ids))

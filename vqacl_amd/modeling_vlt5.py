@@ -109,6 +109,15 @@ class _Embedding(nn.Embedding):
         raise RuntimeError("sub-modules of the engine-backed VLT5 hold parameters only; call the model itself")
 
 
+def to_device(t, dev, dtype=None):
+    """Host -> device hand-over of a batch tensor.  A tensor in PINNED host memory is copied stream-ordered without a host wait
+    (the host keeps its lead of a whole step over the device: a blocking copy queues behind the previous step's kernels and
+    then leaves the device idle while the first launches of the new step are enqueued); pageable memory blocks as in the
+    reference's `.to(device)`.  The caller must not rewrite a pinned batch tensor before the step that consumes it has run."""
+    nb = t.device.type == "cpu" and t.is_pinned()
+    return t.to(device=dev, dtype=t.dtype if dtype is None else dtype, non_blocking=nb).contiguous()
+
+
 class VLOutput(OrderedDict):
     """ModelOutput-like record (VLSeq2SeqLMOutput, modeling_t5_our.py:774-833): key and attribute access."""
 
@@ -416,8 +425,8 @@ class VLT5(nn.Module):
             if vis_inputs.slots.device != dev or vis_inputs.slots.dtype != torch.long:
                 raise L.Vlt5Error("StoreRef.slots must be an int64 tensor on the model's device")
             return None, None, st.V, vis_inputs
-        feats = vis_inputs[0].to(dev, torch.float32).contiguous()
-        boxes = vis_inputs[1].to(dev, torch.float32).contiguous()
+        feats = to_device(vis_inputs[0], dev, torch.float32)
+        boxes = to_device(vis_inputs[1], dev, torch.float32)
         return feats, boxes, feats.shape[1], None
 
     def sync_optimizer(self):
@@ -451,8 +460,8 @@ class VLT5(nn.Module):
             raise NotImplementedError("decoding without labels is the generate path (vqa_model.test_step)")
         dev = self._device
         feats, boxes, V, ref = self._visual_inputs(vis_inputs)
-        input_ids = input_ids.to(dev).contiguous()
-        labels = labels.to(dev).contiguous()
+        input_ids = to_device(input_ids, dev)
+        labels = to_device(labels, dev)
         B, Lt = input_ids.shape
         T = labels.shape[1]
         S, Sx, d = Lt + V, Lt + V + 2, self.cfg.d_model
@@ -465,7 +474,7 @@ class VLT5(nn.Module):
                   feats=feats, boxes=boxes, feat_ref=ref, input_ids=input_ids, labels=labels,
                   enc_lut=self._lut(Lt, Lt, True), dec_lut=self._lut(T, T, False))
         if scores is not None:
-            st["scores"] = scores.to(dev, torch.float32).contiguous()
+            st["scores"] = to_device(scores, dev, torch.float32)
         c = self.cfg.c_struct()
         cs = self._make_step(st)
         stream = stream_ptr()
@@ -481,8 +490,8 @@ class VLT5(nn.Module):
             # SS/SI prototype head (modeling_t5_our.py:583-615)
             poolQ, poolV = ops.proto_pool(enc_f32, S, self.L)
             if proto_update:
-                ql = ques_labels.to(dev, torch.float32).contiguous()
-                cl = cate_labels.to(dev, torch.float32).contiguous()
+                ql = to_device(ques_labels, dev, torch.float32)
+                cl = to_device(cate_labels, dev, torch.float32)
                 if memory:
                     loss_mem_Q, loss_mem_V = self.proto.memory_loss(poolQ, poolV, ql, cl)
                 self.proto.update(poolQ, poolV, ql, cl, int(current_task_id), float(proto_alpha), float(proto_beta))

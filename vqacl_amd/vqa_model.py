@@ -6,7 +6,7 @@ reference, only the arithmetic runs in the HIP engine.
 """
 import torch
 
-from .modeling_vlt5 import VLT5
+from .modeling_vlt5 import VLT5, to_device
 
 
 def _vis_inputs(batch):
@@ -24,7 +24,7 @@ class VLT5VQA(VLT5):
 
     def train_step(self, batch, current_task_id, proto_alpha, proto_beta, mem_num_Q=0, total_num_Q=1000, memory=False):
         device = self._device
-        lm_labels = batch["target_ids"].to(device)
+        lm_labels = to_device(batch["target_ids"], device)
         output = self(
             input_ids=batch["input_ids"],
             vis_inputs=_vis_inputs(batch),
