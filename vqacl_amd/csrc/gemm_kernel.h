@@ -150,7 +150,28 @@ __device__ __forceinline__ bf16x8_t frag_km(const char* tile, int r0, int ks, in
 // inside the same 128-byte row segment (same cache line, coalescing unchanged).  Only for full k-tiles; rows past the edge
 // are clamped to a valid row (their products land in outputs the epilogue never stores).
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-template <int R, int NT>
+// One wave-instruction of LDS-DMA: 64 lanes x 16 bytes from the per-lane global addresses to `dst_wave` + lane * 16.
+// ASM = true issues it as inline assembly.  Why: the compiler's wait-count pass knows that the builtin writes LDS asynchronously
+// and, for the transpose-read builtin (ds_read_b64_tr_b16, every k-major operand), cannot tell the stage being read from the
+// stage being filled -- it puts an `s_waitcnt vmcnt(0)` in front of the first transpose read that follows a DMA request.  That
+// wait also covers the k-tiles requested one and two steps AHEAD, i.e. it turns the 3-stage ring into "request, then wait for it"
+// and puts the whole global-load latency into every k-step of every dgrad / wgrad GEMM (and four times per step into the
+// interleaved 8-wave k-step).  Plain ds_read_b128 reads do not get that wait.  Through inline assembly the compiler does not
+// model the write; the synchronisation is what the loops spell out anyway (counted `s_waitcnt vmcnt(n)` + `s_barrier` before a
+// stage is read, `vmcnt(0)` before LDS is reused).  M0 carries the wave-uniform LDS address; nothing else in these kernels uses M0.
+#ifndef GEMM_ASM_DMA
+#define GEMM_ASM_DMA 2                  // 0: builtin everywhere, 1: assembly everywhere, 2: assembly in kernels with a k-major operand
+#endif
+template <bool ASM>
+__device__ __forceinline__ void lds_dma16(const bf16_t* src, char* dst_wave) {
+    if constexpr (ASM) {
+        const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)dst_wave);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src));
+    } else {
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst_wave, 16, 0, 0);
+    }
+}
+template <int R, int NT, bool ASM = false>
 __device__ __forceinline__ void glds_rm(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, char* tile, int tid) {
     const int wave_base = (tid & ~63);
 #pragma unroll
@@ -159,10 +180,10 @@ __device__ __forceinline__ void glds_rm(const bf16_t* __restrict__ base, int ld,
         const int c = tid + i * NT;
         const int row = c >> 3, kc = (c & 7) ^ (row & 7);
         const int gr = min(row0 + row, rmax - 1);
-        __builtin_amdgcn_global_load_lds(base + (size_t)gr * ld + k0 + kc * 8, (lds_ptr_t)(tile + (i * NT + wave_base) * 16), 16, 0, 0);
+        lds_dma16<ASM>(base + (size_t)gr * ld + k0 + kc * 8, tile + (i * NT + wave_base) * 16);
     }
 }
-template <int R, int NT>
+template <int R, int NT, bool ASM = false>
 __device__ __forceinline__ void glds_km(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, char* tile, int tid) {
     constexpr int CPR = R / 8;
     const int wave_base = (tid & ~63);
@@ -171,27 +192,27 @@ __device__ __forceinline__ void glds_km(const bf16_t* __restrict__ base, int ld,
         const int c = tid + i * NT;
         const int k = c / CPR, rc = (c % CPR) ^ km_swz<R>(k);
         const int gr = min(row0 + rc * 8, rmax - 8);
-        __builtin_amdgcn_global_load_lds(base + (size_t)(k0 + k) * ld + gr, (lds_ptr_t)(tile + (i * NT + wave_base) * 16), 16, 0, 0);
+        lds_dma16<ASM>(base + (size_t)(k0 + k) * ld + gr, tile + (i * NT + wave_base) * 16);
     }
 }
 
 // piece i (0 .. R*8/NT-1) of a tile = NT consecutive 16-byte slots = one wave-instruction per wave
-template <int R, int NT>
+template <int R, int NT, bool ASM = false>
 __device__ __forceinline__ void glds_rm_piece(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, char* tile, int tid, int i) {
     const int wave_base = (tid & ~63);
     const int c = tid + i * NT;
     const int row = c >> 3, kc = (c & 7) ^ (row & 7);
     const int gr = min(row0 + row, rmax - 1);
-    __builtin_amdgcn_global_load_lds(base + (size_t)gr * ld + k0 + kc * 8, (lds_ptr_t)(tile + (i * NT + wave_base) * 16), 16, 0, 0);
+    lds_dma16<ASM>(base + (size_t)gr * ld + k0 + kc * 8, tile + (i * NT + wave_base) * 16);
 }
-template <int R, int NT>
+template <int R, int NT, bool ASM = false>
 __device__ __forceinline__ void glds_km_piece(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, char* tile, int tid, int i) {
     constexpr int CPR = R / 8;
     const int wave_base = (tid & ~63);
     const int c = tid + i * NT;
     const int k = c / CPR, rc = (c % CPR) ^ km_swz<R>(k);
     const int gr = min(row0 + rc * 8, rmax - 8);
-    __builtin_amdgcn_global_load_lds(base + (size_t)(k0 + k) * ld + gr, (lds_ptr_t)(tile + (i * NT + wave_base) * 16), 16, 0, 0);
+    lds_dma16<ASM>(base + (size_t)(k0 + k) * ld + gr, tile + (i * NT + wave_base) * 16);
 }
 
 // DMA pieces of the interleaved k-step (kstep_big): piece p of LPT is issued after the MFMAs of half-step row
@@ -237,10 +258,14 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     // reads in flight per wave to approach the LDS rate -- fetch the fragments of BOTH 32-wide halves up front (and spread
     // the DMA pieces between the MFMAs).  Measured -20..-40 % on dgrad / wgrad shapes; the same scheme costs 5-10 % on
     // row-major short-K shapes and too many registers at 128x128, so it is applied only here.
-    constexpr bool KM_STEP = (AKM || BKM) && (WM * WN == 4) && (BM + BN <= 192);
+#ifndef GEMM_KM_STEP_MAX
+#define GEMM_KM_STEP_MAX 192
+#endif
+    constexpr bool KM_STEP = (AKM || BKM) && (WM * WN == 4) && (BM + BN <= GEMM_KM_STEP_MAX);
     // the 8-wave 256x256 kernel runs the hand-interleaved k-step (kstep_big).  (Tried for 4-wave 128x128 with both operands
     // k-major, the layer-batched weight gradients: 385 -> 650 us, the fragment double buffer pushes it into AGPR spills.)
     constexpr bool BIG_STEP = (WM * WN == 8);
+    constexpr bool ASM_DMA = (GEMM_ASM_DMA == 1) || (GEMM_ASM_DMA == 2 && (AKM || BKM));     // see lds_dma16()
     // -DGEMM_PINGPONG=1 selects the two-role main loop below instead of the interleaved k-step.  Measured (round 1): correct, but
     // no faster where it compiles without spills (4480x3072x768 with k-major B: 36.6 vs 34.8 us) and the all-row-major / all-k-major
     // instantiations spill (302 / 383 VGPRs) -- four barriers and ~0.6 k cycles of DMA issue per k-step eat what the role split
@@ -308,8 +333,8 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     auto glds = [&](int kt, int s) __attribute__((always_inline)) {                        // asynchronous: completion is awaited with vmcnt(0)
         char* at = smem + s * STAGE_BYTES;
         char* bt = at + A_BYTES;
-        if (AKM) glds_km<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, at, tid); else glds_rm<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, at, tid);
-        if (BKM) glds_km<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid); else glds_rm<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid);
+        if (AKM) glds_km<BM, NT, ASM_DMA>(p.A, p.lda, m0, kt * BK, p.M, at, tid); else glds_rm<BM, NT, ASM_DMA>(p.A, p.lda, m0, kt * BK, p.M, at, tid);
+        if (BKM) glds_km<BN, NT, ASM_DMA>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid); else glds_rm<BN, NT, ASM_DMA>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid);
     };
     const int lrow = lane & 15, lg = lane >> 4;
     auto glds_piece = [&](int kt, int s, int pc) __attribute__((always_inline)) {
@@ -317,10 +342,10 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
         char* bt = at + A_BYTES;
         constexpr int PA = PA_;
         if (pc < PA) {
-            if (AKM) glds_km_piece<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, at, tid, pc); else glds_rm_piece<BM, NT>(p.A, p.lda, m0, kt * BK, p.M, at, tid, pc);
+            if (AKM) glds_km_piece<BM, NT, ASM_DMA>(p.A, p.lda, m0, kt * BK, p.M, at, tid, pc); else glds_rm_piece<BM, NT, ASM_DMA>(p.A, p.lda, m0, kt * BK, p.M, at, tid, pc);
         } else {
-            if (BKM) glds_km_piece<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid, pc - PA);
-            else     glds_rm_piece<BN, NT>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid, pc - PA);
+            if (BKM) glds_km_piece<BN, NT, ASM_DMA>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid, pc - PA);
+            else     glds_rm_piece<BN, NT, ASM_DMA>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid, pc - PA);
         }
     };
     auto ldA = [&](const char* at, int i, int ks) __attribute__((always_inline)) -> bf16x8_t {
@@ -362,7 +387,10 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     // Row-major operands: all FM pieces go into the first half, so the ks = 1 MFMAs cover their latency before the next step's
     // vmcnt(0) (-6 % per launch); with a k-major operand (two transpose reads per fragment) spreading them over both halves
     // measured better.
-    constexpr bool EARLY = !AKM && !BKM;
+#ifndef GEMM_KM_EARLY
+#define GEMM_KM_EARLY 0
+#endif
+    constexpr bool EARLY = (!AKM && !BKM) || GEMM_KM_EARLY;
     auto kstep_big = [&](int stage, int kt_pf, int s_pf) __attribute__((always_inline)) {
         const char* at = smem + stage * STAGE_BYTES;
         const char* bt = at + A_BYTES;
