@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of environment switches: bash tools/ab_env_loop.sh ROUNDS "VAR=a" "VAR=b" ...  -> ms/step of bench.py per setting, interleaved
+# Same-box A/B of environment switches: bash tools/ab_env_loop.sh ROUNDS "VAR=a" "VAR=b VAR2=c" ...  -> ms/step of bench.py per setting, interleaved
 ROUNDS=$1; shift
 for r in $(seq 1 $ROUNDS); do
   for setting in "$@"; do

@@ -62,7 +62,16 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         // layer-batched FFN weight gradients: 455 us against 385-410 us with 128 x 128)
         // (also for a small output with a very long reduction cut into slices by vlt5_gemm_auto_split: the input gradients
         // of lm_head and of the stacked cross-attention K/V projection)
-        if (!d->a_kmajor && (tiles(256, 256) >= 160 || (d->K >= 8192 && d->split_k > 1 && tiles(256, 256) >= 128))) {
+        // Weight gradients (both operands k-major, reduction over the rows of the batch): since the LDS-DMA of the k-major kernels is
+        // issued as assembly (gemm_kernel.h lds_dma16) their prefetch ring works, and the larger tiles win -- in situ, B = 80:
+        // 768x3072x4480 x6 layers 168 -> 151 us and the stacked cross-K/V 18432x768x4640 170 -> 160 us with 256 x 256 (a long
+        // reduction only: at K = 400, the decoder, its prologue / epilogue dominate); 2304x768x4480 x6 159 -> 148 us and
+        // 768x768x400 x12 24 -> 18 us with 128 x 128 instead of 64 x 128.  (experiment knobs: VLT5_GEMM_T128_KMKM, VLT5_GEMM_T256_KM)
+        static const int t128_kmkm = getenv("VLT5_GEMM_T128_KMKM") ? atoi(getenv("VLT5_GEMM_T128_KMKM")) : 100;
+        static const int t256_km = getenv("VLT5_GEMM_T256_KM") ? atoi(getenv("VLT5_GEMM_T256_KM")) : 160;
+        const int t128 = (d->a_kmajor && d->b_kmajor) ? t128_kmkm : 768;
+        if (d->a_kmajor && d->K >= 1024 && tiles(256, 256) >= t256_km) { bm = 256; bn = 256; }
+        else if (!d->a_kmajor && (tiles(256, 256) >= 160 || (d->K >= 8192 && d->split_k > 1 && tiles(256, 256) >= 128))) {
             // 8-wave kernel; its tile HEIGHT is chosen to fill the 256 CUs: a launch costs about (fixed part + k-steps x height/256)
             // per round of 256 workgroups, the fixed part (launch, prologue, epilogue) being worth ~9 k-steps of the full tile
             // (FFN-in forward 4480 x 3072: 216 tiles of 256 rows = 84 % of the CUs -> 240 tiles of 224 rows)
@@ -77,7 +86,7 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         }
         // (with k-major operands the 64-wide tiles run the deeper fragment pipeline, KM_STEP, and win below this threshold;
         // above it -- the layer-batched weight gradients -- 128 x 128 is still 25 % faster)
-        else if (tiles(128, 128) >= 768) { bm = 128; bn = 128; }       // >= 3 workgroups per CU of the big tile
+        else if (tiles(128, 128) >= t128) { bm = 128; bn = 128; }       // >= 3 workgroups per CU of the big tile
         else if (tiles(64, 128) >= 256) {                              // 3-stage ring, 2 workgroups per CU
             // input-gradient layout (row-major dY, k-major W): the tall tile reads the transpose-read operand half as often per
             // flop (sweep r01_f: 26.0 vs 27.5 us on 4480x768x2304, 171.6 vs 182.3 on 4640x768x18432)
