@@ -195,8 +195,9 @@ __global__ void tr_probe_kernel(const uint16_t* in, uint16_t* out, const int* ad
 }
 }  // namespace
 #ifdef GEMM_TIMELINE
+unsigned long long* vlt5_gemm_timeline_buf = nullptr;
 extern "C" int vlt5dbg_set_timeline(void* buf) {
-    HIP_RET(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &buf, sizeof(buf)));
+    vlt5_gemm_timeline_buf = (unsigned long long*)buf;
     return VLT5_OK;
 }
 #endif

@@ -33,7 +33,8 @@
 // Optional per-workgroup timeline (debug builds only, -DGEMM_TIMELINE): wave 0 of every workgroup records the shader
 // clock at fixed points and writes 8 x u64 per workgroup to the buffer registered with vlt5dbg_set_timeline().
 #ifdef GEMM_TIMELINE
-static __device__ unsigned long long* g_timeline = nullptr;
+extern unsigned long long* vlt5_gemm_timeline_buf;      // host side (gemm.hip); travels in GemmArgs (the kernels live in several translation units)
+#define g_timeline p.timeline
 #define TL_DECL unsigned long long tlv[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define TL(i) do { if (threadIdx.x == 0) { tlv[i] = __builtin_readcyclecounter(); if (i == 0) tlv[7] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define TL_FLUSH() do { if (threadIdx.x == 0 && g_timeline) { \
@@ -60,6 +61,9 @@ struct GemmArgs {
     int ktiles_per_split; long long c_split_stride;
     long long batch_a, batch_b, batch_c;          // element strides between batch entries (blockIdx.z)
     bf16_t* C2;                                   // optional bf16 copy of a plain f32 output (same indexing as C), or null
+#ifdef GEMM_TIMELINE
+    unsigned long long* timeline;
+#endif
 };
 
 constexpr int BK = 64;
@@ -838,6 +842,9 @@ int launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+#ifdef GEMM_TIMELINE
+    const_cast<GemmArgs&>(a).timeline = vlt5_gemm_timeline_buf;
+#endif
     if (g_timing.on && g_timing.rec.size() < g_timing.cap) {
         const size_t i = g_timing.rec.size();
         vlt5_gemm_timing_rec r;
@@ -858,7 +865,10 @@ int launch_tile(const GemmArgs& a, int akm, int bkm, int splits, int batch, hipS
     dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM), splits > 1 ? splits : 1, batch > 1 ? batch : 1);
     // ring depth: 3 stages up to 64x128 (72 KB, 2 workgroups/CU); 2 for 128x128 (a 3-stage ring = 96 KB = 1 workgroup/CU
     // measured 13 % slower end to end: occupancy matters more) and for 256x256 (2 x 64 KB, one 8-wave workgroup per CU)
-    constexpr int NS = (BM + BN <= 192) ? 3 : 2;
+#ifndef GEMM_NS_SMALL
+#define GEMM_NS_SMALL 3
+#endif
+    constexpr int NS = (BM + BN <= 192) ? GEMM_NS_SMALL : 2;
     constexpr int WM = 2, WN = (BN == 256) ? 4 : 2;          // 256-wide tiles: the 8-wave kernel
     if (!akm && !bkm) return launch_one<BM, BN, WM, WN, false, false, NS>(a, grid, st);
     if (!akm && bkm) return launch_one<BM, BN, WM, WN, false, true, NS>(a, grid, st);
