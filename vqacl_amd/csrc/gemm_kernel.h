@@ -269,6 +269,12 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     // the 8-wave 256x256 kernel runs the hand-interleaved k-step (kstep_big).  (Tried for 4-wave 128x128 with both operands
     // k-major, the layer-batched weight gradients: 385 -> 650 us, the fragment double buffer pushes it into AGPR spills.)
     constexpr bool BIG_STEP = (WM * WN == 8);
+    // -DGEMM_PIPE: the software-pipelined k-step of the fused encoder kernel (enc_attn.hip) for the 8-wave tiles: 0 off, 1 every
+    // operand layout, 2 only kernels with a k-major operand
+#ifndef GEMM_PIPE
+#define GEMM_PIPE 2
+#endif
+    constexpr bool PIPE_STEP = BIG_STEP && (GEMM_PIPE == 1 || (GEMM_PIPE == 2 && (AKM || BKM)));
     constexpr bool ASM_DMA = (GEMM_ASM_DMA == 1) || (GEMM_ASM_DMA == 2 && (AKM || BKM));     // see lds_dma16()
     // -DGEMM_PINGPONG=1 selects the two-role main loop below instead of the interleaved k-step.  Measured (round 1): correct, but
     // no faster where it compiles without spills (4480x3072x768 with k-major B: 36.6 vs 34.8 us) and the all-row-major / all-k-major
@@ -466,6 +472,8 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
 #pragma unroll
             for (int s0 = 0; s0 < NSTAGE - 1; ++s0) glds(min(kt0 + s0, kt0 + nmain - 1), s0);   // always NSTAGE-1 k-tiles in flight
         }
+    } else if constexpr (PIPE_STEP) {
+        if (nmain > 0) { glds(kt0, 0); glds(min(kt0 + 1, kt0 + nmain - 1), 1); }     // both stages requested
     } else {
 #pragma unroll
         for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
@@ -561,6 +569,55 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // surplus prefetches land before LDS is reused / the wave ends
+        }
+        if (has_tail) __syncthreads();
+    } else if constexpr (PIPE_STEP) {
+        // 8-wave kernel, software-pipelined across the k-steps (the loop of the fused encoder kernel, enc_attn.hip): a k-step is two
+        // halves (the 32-deep MFMA slabs ks = 0 / 1 of the 64-deep tile) with the workgroup barrier BETWEEN them --
+        //   ks = 0 half of tile t: MFMAs on fragments fetched during the previous step; fetch the ks = 1 fragments of tile t
+        //   wait (tile t+1 landed, the ks = 1 fragments returned) + barrier: stage of tile t is free, stage of tile t+1 complete
+        //   ks = 1 half of tile t: MFMAs; request tile t+2 into the freed stage; fetch the ks = 0 fragments of tile t+1
+        // so no half starts behind a fragment read (with k-major operands the up-front fetch of the barrier-at-the-top step is 24
+        // transpose reads, ~700 idle cycles of the matrix pipe per step), and a DMA piece has a whole step to land.
+        static_assert(NSTAGE == 2, "two stages");
+        if (nmain > 0) {
+            bf16x8_t fa0[FM], fb0[FN], fa1[FM], fb1[FN];
+            auto half = [&](bf16x8_t (&fa)[FM], bf16x8_t (&fb)[FN], bf16x8_t (&na)[FM], bf16x8_t (&nb)[FN], const char* nat,
+                            const char* nbt, int nks, int kt_dma, int s_dma, bool dma) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    na[i] = ldA(nat, i, nks);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        if (j >= bfrag_lo<FM, FN>(i) && j < bfrag_lo<FM, FN>(i + 1)) nb[j] = ldB(nbt, j, nks);
+                    if (dma) {
+#pragma unroll
+                        for (int pc = 0; pc < LPT; ++pc)
+                            if (piece_row<FM, LPT, true>(pc) == i) glds_piece(kt_dma, s_dma, pc);
+                    }
+                }
+            };
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");          // tile 0 (the older group) has landed
+            __builtin_amdgcn_s_barrier();
+            TL(2);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa0[i] = ldA(smem, i, 0);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb0[j] = ldB(smem + A_BYTES, j, 0);
+            int stg = 0;
+            for (int i = 0; i < nmain; ++i) {
+                const char* at = smem + stg * STAGE_BYTES;
+                const char* at2 = smem + (stg ^ 1) * STAGE_BYTES;
+                half(fa0, fb0, fa1, fb1, at, at + A_BYTES, 1, 0, 0, false);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                half(fa1, fb1, fa0, fb0, at2, at2 + A_BYTES, 0, min(kt0 + i + 2, kt0 + nmain - 1), stg, true);   // (past the end: the last tile again)
+                stg ^= 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the surplus prefetch / fragments: before LDS is reused or the wave ends
+            stage = 0;
         }
         if (has_tail) __syncthreads();
     } else if constexpr (BIG_STEP) {
