@@ -60,6 +60,38 @@ __host__ __device__ __forceinline__ uint32_t site_seed(uint32_t base, uint32_t s
 // rounding of the probabilities that follows); expf() expands to ~20 instructions per element and made the attention core VALU-bound
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 
+// ---- output stores that another KERNEL reads ------------------------------------------------------
+// Written through the L2 (sc0 sc1) instead of left dirty in it: the 8 XCD-private L2s are not coherent with each other, so whatever
+// a kernel leaves dirty is written back when it ENDS, after its last workgroup -- launch-to-launch time minus workgroup span grew
+// with the output size (~8 us for a 27 MB GEMM output, tools/gemm_timeline.py).  Write-through spreads that traffic over the
+// kernel's life.  (Non-temporal stores measured slower; -DVLT5_WT_STORE=0 restores plain stores for A/B runs.)
+#ifndef VLT5_WT_STORE
+#define VLT5_WT_STORE 1
+#endif
+typedef __attribute__((ext_vector_type(4))) unsigned vlt5_u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned vlt5_u32x2_t;
+__device__ __forceinline__ void store_wt16(void* dst, uint4 v) {
+#if VLT5_WT_STORE
+    const vlt5_u32x4_t q = {v.x, v.y, v.z, v.w};
+    // (s_nop 1: a store of more than 8 bytes reads its data late -- a VALU write to those registers needs two wait states after it;
+    // the compiler pads its own stores, it cannot see into this one)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(q) : "memory");
+#else
+    *reinterpret_cast<uint4*>(dst) = v;
+#endif
+}
+__device__ __forceinline__ void store_wt8(void* dst, uint2 v) {
+#if VLT5_WT_STORE
+    const vlt5_u32x2_t q = {v.x, v.y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(q) : "memory");
+#else
+    *reinterpret_cast<uint2*>(dst) = v;
+#endif
+}
+__device__ __forceinline__ void store_wt16f(float* dst, float4 v) {
+    store_wt16(dst, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
+}
+
 // ---- wave reductions ----------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -72,6 +72,11 @@ __device__ __forceinline__ uint32_t lds_off(int row, int kchunk) {            //
     return (uint32_t)(row * 128 + ((kchunk ^ (row & 7)) << 4));
 }
 
+// Output stores go through the L2 (common.h store_wt16: the dirty lines of a launch would otherwise be written back when the kernel
+// ends, after its last workgroup)
+__device__ __forceinline__ void st16(void* dst, uint4 v) { store_wt16(dst, v); }
+__device__ __forceinline__ void st16f(float* dst, float4 v) { store_wt16f(dst, v); }
+
 // ---- row-major operand: tile [R rows][64 k], 16-byte chunks along k ------------------------------
 template <int R, int NT>
 __device__ __forceinline__ void gload_rm(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rmax, int K,
@@ -677,7 +682,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
         const auto s1 = __builtin_amdgcn_permlane16_swap(p1, q1, false, false);
         const int n = n0 + wn * TN + (j + (lg & 1)) * 16 + (lg >> 1) * 8;
         if (m < p.M && n < p.N)
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(Cbase) + (size_t)m * p.ldc + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            st16(reinterpret_cast<bf16_t*>(Cbase) + (size_t)m * p.ldc + n, make_uint4(s0[0], s1[0], s0[1], s1[1]));
     };
     if (!p.bias && !p.relu && !p.gate && !p.drop_thr && !aux_f32) {
         // plain epilogue (QKV / cross-K/V / lm_head projections, every dgrad without gate, every weight gradient): straight-line
@@ -694,7 +699,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                     if (nb + j * 16 < p.N) {
                         const float4 o = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha,
                                                      acc[i][j][3] * p.alpha);
-                        *reinterpret_cast<float4*>(crow + j * 16) = o;
+                        st16f(crow + j * 16, o);
                         if (C2base) {          // the same values rounded to bf16: a data-parallel bucket's staging copy, no cast pass
                             uint2 pk;
                             pk.x = pack_bf16x2(o.x, o.y);
@@ -816,7 +821,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                         float v[4];
                         finish(ii, j, m, v);
                         float* c = reinterpret_cast<float*>(Cbase) + (size_t)m * p.ldc + n;
-                        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                        st16f(c, make_float4(v[0], v[1], v[2], v[3]));
                     }
                 } else {
 #pragma unroll
