@@ -520,14 +520,19 @@ int decoder_fwd(const Ctx& k) {
         RC(attn_call(k, false, qkv, (long long)T * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)T * 3 * inner,
                      3 * inner, k.w<bf16_t>(p.ctx_s[l]), k.w<float>(p.lse_s[l]), k.w<float>(p.dec_bias), T, T, nullptr, 0.f, 1, T, T,
                      k.seed(sb + D_SPROBS)));
-        RC(k.lin_fwd(k.w<bf16_t>(p.ctx_s[l]), k.Pb + D.so, y1, Md, d, inner, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + D_SOUT), y0));
-        RC(vlt5_layernorm_fwd(y1, k.P + D.ln_c, k.w<void>(p.yn_c[l]), nullptr, k.w<float>(p.yr[3 * l + 1]), Md, d, c.eps, 0.f, 0, 0, 0, k.st));
+        // (the two attention output projections, 84 tiles over K = 768, are cut along K like the FFN output: the norm that follows
+        // sums the slabs while it assembles the row)
+        int pend_s = 0, pend_c = 0;
+        RC(k.lin_fwd_for_norm(k.w<bf16_t>(p.ctx_s[l]), k.Pb + D.so, y1, Md, d, inner, k.pdrop, k.seed(sb + D_SOUT), y0, &pend_s));
+        RC(k.ln_fwd_pending(pend_s, y1, y0, k.pdrop, k.seed(sb + D_SOUT), D.ln_c, k.w<void>(p.yn_c[l]), nullptr,
+                            k.w<float>(p.yr[3 * l + 1]), Md, 0.f, 0, 0, 0));
         RC(k.lin_fwd(k.w<bf16_t>(p.yn_c[l]), k.Pb + D.cq, k.w<void>(p.qc[l]), Md, inner, d, 0));
         RC(attn_call(k, false, k.w<bf16_t>(p.qc[l]), (long long)T * inner, inner, kv, kv + inner, (long long)Sx * kvw, kvw,
                      k.w<bf16_t>(p.ctx_c[l]), k.w<float>(p.lse_c[l]), nullptr, 0, 0, k.w<float>(p.mask_ext), -1e9f, 0, T, Sx,
                      k.seed(sb + D_CPROBS)));
-        RC(k.lin_fwd(k.w<bf16_t>(p.ctx_c[l]), k.Pb + D.co, y2, Md, d, inner, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + D_COUT), y1));
-        RC(vlt5_layernorm_fwd(y2, k.P + D.ln_f, k.w<void>(p.yn_f[l]), nullptr, k.w<float>(p.yr[3 * l + 2]), Md, d, c.eps, 0.f, 0, 0, 0, k.st));
+        RC(k.lin_fwd_for_norm(k.w<bf16_t>(p.ctx_c[l]), k.Pb + D.co, y2, Md, d, inner, k.pdrop, k.seed(sb + D_COUT), y1, &pend_c));
+        RC(k.ln_fwd_pending(pend_c, y2, y1, k.pdrop, k.seed(sb + D_COUT), D.ln_f, k.w<void>(p.yn_f[l]), nullptr,
+                            k.w<float>(p.yr[3 * l + 2]), Md, 0.f, 0, 0, 0));
         RC(k.ffn_hidden(k.w<bf16_t>(p.yn_f[l]), D.wi, k.w<bf16_t>(p.ud[l]), k.w<bf16_t>(p.hd[l]), Md, k.pdrop, k.seed(sb + D_FFN_H)));
         RC(k.lin_fwd_for_norm(k.w<bf16_t>(p.hd[l]), k.Pb + D.wo, y3, Md, d, ff, k.pdrop, k.seed(sb + D_FFN_OUT), y2, &pending));
     }
@@ -660,8 +665,10 @@ int decoder_bwd(const Ctx& k) {
         RC(attn_call(k, true, k.w<bf16_t>(p.qc[l]), (long long)T * inner, inner, kv, kv + inner, (long long)Sx * kvw, kvw, nullptr,
                      k.w<float>(p.lse_c[l]), nullptr, 0, 0, k.w<float>(p.mask_ext), -1e9f, 0, T, Sx, k.seed(sb + D_CPROBS), dctx, dq_c,
                      (long long)T * inner, inner, dkv, dkv + inner, (long long)Sx * kvw, kvw, nullptr));
-        RC(k.lin_dgrad(dq_c, k.Pb + D.cq, tmp, Md, inner, d, 1));
-        RC(k.ln_bwd(tmp, k.w<float>(p.y[3 * l + 1]), D.ln_c, k.w<float>(p.yr[3 * l + 1]), dx, Md, 1, 0.f, 0, 0, 0, dyd_s, k.seed(sb + D_SOUT)));
+        int ns_c = 1;
+        RC(k.lin_dgrad(dq_c, k.Pb + D.cq, tmp, Md, inner, d, 1, 1.f, nullptr, 1.f, &ns_c));
+        RC(k.ln_bwd(tmp, k.w<float>(p.y[3 * l + 1]), D.ln_c, k.w<float>(p.yr[3 * l + 1]), dx, Md, 1, 0.f, 0, 0, 0, dyd_s, k.seed(sb + D_SOUT),
+                    ns_c, (long long)Md * d));
         // causal self-attention sublayer
         RC(k.lin_dgrad(dyd_s, k.Pb + D.so, dctx, Md, d, inner, 0));
         RC(attn_call(k, true, qkv, (long long)T * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)T * 3 * inner,

@@ -167,7 +167,10 @@ extern "C" int vlt5_gemm_auto_split(int M, int N, int Kred, long long slab_bytes
         if (sk > 32) sk = 32;
         if (sk > ksteps / 8) sk = ksteps / 8;
     } else {
-        if (Kred < 1024 || tiles >= 128) return 1;
+        // (K >= 768: the decoder's 400 x 768 x 768 projections whose consumer is a norm -- 84 tiles -> 3 x 84 workgroups of 4 k-steps:
+        // 8.3 -> 4.6 us per launch against +1.8 us in the norm that sums the slabs; VLT5_GEMM_SPLIT_KMIN: experiment knob)
+        static const int kmin = getenv("VLT5_GEMM_SPLIT_KMIN") ? atoi(getenv("VLT5_GEMM_SPLIT_KMIN")) : 768;
+        if (Kred < kmin || tiles >= 128) return 1;
         sk = (int)((512 + tiles / 2) / tiles);
         if (sk > 8) sk = 8;
         if (sk > ksteps / 4) sk = ksteps / 4;
