@@ -52,6 +52,10 @@ typedef struct {
     int split_used;                          /* out: the number of slabs actually written (<= split_k), 1 if not split */
     void* c_bf16_copy;                       /* optional: plain f32 output (no epilogue option, no accum) is ALSO written rounded to bf16
                                                 here, same ldc / batch stride -- the staging copy of a data-parallel gradient bucket */
+    float* sumsq; long long sumsq_batch_stride; /* optional (plain f32 output, no split): sum of squares of every output tile, written to
+                                                sumsq[z * sumsq_batch_stride + t], t < tiles of the launch's tile shape (at most
+                                                ceil(M/64)*ceil(N/64)); fixed reduction order -- the optimizer's gradient norm
+                                                without a second pass over the gradients (vlt5_gnorm_finish) */
 } vlt5_gemm_desc;
 int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream);     /* writes d->split_used */
 long long vlt5_gemm_workspace_bytes(int M, int ldc, int split_k);
@@ -236,6 +240,12 @@ int vlt5_proto_memory_loss(const float* pool, const float* onehot, const float* 
 
 /* ---- optimizer: clip_grad_norm_(5) + HF AdamW (src/vqacl.py:466-487, src/trainer_base.py:187-190) */
 int vlt5_sqnorm(const float* g, long long n, float* partial, float* total_sq, int accum_total, void* stream);
+/* total_sq[0] = sum(partials[0..nslots)) + sum over the `nranges` (<= 4) element ranges [range_off[i], +range_n[i]) of grads of g^2,
+ * all in a fixed order (deterministic).  `scratch`: vlt5_sqnorm_blocks(sum of range_n) + nranges floats.  Completes the
+ * gradient norm whose per-tile shares the weight-gradient GEMMs left in vlt5_step.gnorm_partials (reference: the norm pass of
+ * torch.nn.utils.clip_grad_norm_, src/vqacl.py:466-487). */
+int vlt5_gnorm_finish(const float* partials, long long nslots, const float* grads, const long long* range_off, const long long* range_n,
+                      int nranges, float* scratch, float* total_sq, void* stream);
 int vlt5_sqnorm_blocks(long long n);
 /* p,m,v f32; optional bf16 shadow of p.  clip coefficient = min(1, max_norm / (sqrt(*total_sq) + 1e-6)) when
  * total_sq != NULL.  hf_mode 1: transformers AdamW (eps outside bias correction, decay after the update, on the
@@ -323,7 +333,15 @@ typedef struct {
      * produces, and the relative-position tables, there as well, so a bf16 data-parallel all-reduce of the layer buckets needs no
      * cast pass.  NOT covered (cast them): the last bucket (embeddings, norms, visual embedding). */
     void* grads_bf16;
+    /* optional: vlt5_gnorm_slots(config) floats.  The backward phases zero it (vlt5_decoder_bwd) and every weight-gradient GEMM of the
+     * layer buckets and of the stacked cross-attention K/V projection leaves the sum of squares of its output tiles there
+     * (vlt5_gemm_desc.sumsq; slot = ceil(flat offset / 4096) + tile) -- with vlt5_gnorm_finish over the remaining ranges (last
+     * bucket, relative-position tables) the optimizer's global gradient norm needs no second pass over 0.9 GB of gradients. */
+    float* gnorm_partials;
 } vlt5_step;
+/* number of slots of vlt5_step.gnorm_partials for this configuration, or 0 when it is not supported (a matrix dimension that is
+ * no multiple of 64: the slot ranges of neighbouring tensors would overlap) */
+long long vlt5_gnorm_slots(const vlt5_config* c);
 
 /* ---- batch feed from a resident feature store (replaces the per-item HDF5 read + collate + H2D copy of
  *      src/vqa_data_memory.py:141-189, 291-396) ----

@@ -389,6 +389,45 @@ def test_training_loop_drop_in_with_torch_optimizer_and_fused_optimizer(dev):
         assert torch.allclose(v, finals["fused-overlap"][1][k], rtol=1e-4, atol=1e-5), k
 
 
+@pytest.mark.parametrize("base", [False, True])
+def test_gradient_norm_from_the_weight_gradient_gemms(dev, base):
+    """clip_grad_norm_ (vqacl.py:466-487) without a second pass over the gradients: the weight-gradient GEMMs leave sum(g^2) per output
+    tile, vlt5_gnorm_finish adds the ranges no GEMM writes -- the total must equal the squared norm of the flat gradient buffer, and
+    any later edit of a .grad (or a second backward that accumulates) must send the optimizer back to the full pass."""
+    from oracle import ref_cpu as R
+    from vqacl_amd import FusedAdamW, reference_param_groups
+    if base:
+        ocfg = R.Cfg(dropout=0.0)
+        batch = R.synthetic_batch(ocfg, B=6, L=20, V=36, T=5, seed=3)
+    else:
+        ocfg = R.tiny_cfg()
+        batch = R.synthetic_batch(ocfg, B=8, L=12, V=36, T=4, seed=4)
+    model = make_model(ocfg, R.init_params(ocfg, seed=5), dev)
+    model.train()
+    opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-4, eps=1e-6, max_grad_norm=5.0)
+    for it in range(2):
+        model.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
+        assert model._gnorm is not None and model._gnorm is not False and model._gnorm_version is not None, "the fused path is active"
+        g = model._flat_grad[:opt._used_end].double()
+        want = float((g * g).sum())
+        opt.step()
+        got = float(opt._total_sq)
+        assert abs(got - want) <= 2e-5 * want, (it, got, want)
+        # the tail ranges + the tile shares really partition the buffer: the full pass gives the same number
+        from vqacl_amd._lib import check, lib, ptr, stream_ptr
+        check(lib().vlt5_sqnorm(ptr(model._flat_grad), opt._used_end, ptr(opt._partial), ptr(opt._total_sq), 0, stream_ptr()), "sqnorm")
+        assert abs(float(opt._total_sq) - want) <= 2e-5 * want
+        for p_ in model.parameters():
+            p_.grad = None
+    # an in-place edit of a gradient after backward invalidates the shares (version counter of the flat buffer)
+    model.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
+    dict(model.named_parameters())["encoder.block.0.layer.1.DenseReluDense.wi.weight"].grad.mul_(3.0)
+    g = model._flat_grad[:opt._used_end].double()
+    want = float((g * g).sum())
+    opt.step()
+    assert abs(float(opt._total_sq) - want) <= 2e-5 * want, "fell back to the full pass"
+
+
 def test_gradient_accumulation_path(dev):
     """If the caller does not clear .grad, the second backward accumulates (autograd semantics)."""
     from oracle import ref_cpu as R

@@ -24,7 +24,8 @@ class GemmDesc(C.Structure):
                 ("gate", vp), ("ldg", c_i), ("gate_scale", c_f), ("drop_p", c_f), ("drop_seed", c_u32),
                 ("relu", c_i), ("out_f32", c_i), ("accum", c_i), ("split_k", c_i), ("workspace", vp),
                 ("tile_m", c_i), ("tile_n", c_i), ("batch", c_i), ("batch_stride_a", c_ll), ("batch_stride_b", c_ll),
-                ("batch_stride_c", c_ll), ("defer_reduce", c_i), ("split_used", c_i), ("c_bf16_copy", vp)]
+                ("batch_stride_c", c_ll), ("defer_reduce", c_i), ("split_used", c_i), ("c_bf16_copy", vp),
+                ("sumsq", vp), ("sumsq_batch_stride", c_ll)]
 
 
 class AttnDesc(C.Structure):
@@ -67,7 +68,8 @@ class Step(C.Structure):
                 ("enc_lut", vp), ("dec_lut", vp), ("gout", vp), ("d_loss_tok", vp), ("events", C.POINTER(vp)), ("n_events", c_i),
                 ("wait_events", C.POINTER(vp)), ("n_wait_events", c_i),
                 ("feat_store", vp), ("box_store", vp), ("feat_slots", vp), ("n_slots", c_ll),
-                ("side_stream", vp), ("side_events", C.POINTER(vp)), ("n_side_events", c_i), ("grads_bf16", vp)]
+                ("side_stream", vp), ("side_events", C.POINTER(vp)), ("n_side_events", c_i), ("grads_bf16", vp),
+                ("gnorm_partials", vp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/vlt5_hip.h
@@ -116,6 +118,8 @@ PROTOTYPES = {
     "vlt5_proto_retrieve": (c_i, [vp, vp, vp, vp, c_ll, vp, c_ll, vp, c_i, c_i, c_i, vp]),
     "vlt5_proto_memory_loss": (c_i, [vp, vp, vp, vp, c_i, c_i, c_i, vp]),
     "vlt5_sqnorm": (c_i, [vp, c_ll, vp, vp, c_i, vp]),
+    "vlt5_gnorm_finish": (c_i, [vp, c_ll, vp, C.POINTER(c_ll), C.POINTER(c_ll), c_i, vp, vp, vp]),
+    "vlt5_gnorm_slots": (c_ll, [C.POINTER(Config)]),
     "vlt5_sqnorm_blocks": (c_i, [c_ll]),
     "vlt5_adamw_step": (c_i, [vp, vp, vp, vp, vp, c_ll, c_f, c_f, c_f, c_f, c_f, c_i, vp, c_f, c_i, vp]),
     "vlt5_sqnorm_g16": (c_i, [vp, c_f, c_ll, vp, vp, c_i, vp]),

@@ -337,17 +337,23 @@ struct Ctx {
         return rc;
     }
     // dW[N,K] (+)= alpha * dY[M,N]^T X[M,K]     (both read k-major, reduction over the M rows)
+    // norm_share: the tiles' sums of squares go to the gradient-norm partials (a tensor nothing else adds to afterwards)
     int lin_wgrad(const bf16_t* dY, int ldy, const bf16_t* X, int ldx, float* dW, int M, int N, int K, float alpha = 1.f,
-                  int accum = 0) const {
+                  int accum = 0, bool norm_share = false) const {
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);
         g.A = dY; g.B = X; g.C = dW; g.M = N; g.N = K; g.K = M; g.lda = ldy; g.ldb = ldx; g.ldc = K;
         g.a_kmajor = 1; g.b_kmajor = 1; g.alpha = alpha; g.out_f32 = 1; g.accum = accum;
         if (!accum) g.c_bf16_copy = g16(dW);
-        int sk = pick_split(N, K, M);
+        if (norm_share && !accum) g.sumsq = gsq(dW);
+        int sk = g.sumsq ? 1 : pick_split(N, K, M);           // (the slab reduction has no norm share: such launches are not cut)
         if (sk > 1) { g.split_k = sk; g.workspace = w<void>(p.slab); }
         return vlt5_gemm_bf16(&g, st);
     }
+    // slot of a gradient tensor in the gradient-norm partials (vlt5_step.gnorm_partials): ceil(flat offset / 4096); tensors whose
+    // size is a multiple of 4096 elements (both dimensions multiples of 64) then own disjoint slot ranges of size / 4096
+    bool gnorm_ok() const { return s.gnorm_partials && !(d & 63) && !(inner & 63) && !(ffw() & 63); }
+    float* gsq(const float* dW) const { return gnorm_ok() ? s.gnorm_partials + ((dW - Gr) + 4095) / 4096 : nullptr; }
     // the bf16 mirror of a gradient tensor (vlt5_step.grads_bf16), or null
     void* g16(const float* dW) const {
         return s.grads_bf16 ? (void*)((bf16_t*)s.grads_bf16 + (dW - Gr)) : nullptr;
@@ -390,7 +396,9 @@ struct Ctx {
         g.batch_stride_a = layers > 1 ? ((long long)dy1 - (long long)dy0) / 2 : 0;
         g.batch_stride_b = layers > 1 ? ((long long)x1 - (long long)x0) / 2 : 0;
         g.batch_stride_c = layers > 1 ? (g1 - g0) : 0;
-        if (layers == 1) {
+        g.sumsq = gsq(Gr + g0);                                // every batched weight gradient is a layer matrix: norm share
+        g.sumsq_batch_stride = layers > 1 ? (g1 - g0) / 4096 : 0;
+        if (layers == 1 && !g.sumsq) {
             int sk = pick_split(N, K, M);
             if (sk > 1) { g.split_k = sk; g.workspace = w<void>(p.slab); }
         }
@@ -640,6 +648,7 @@ int decoder_bwd(const Ctx& k) {
     bf16_t* dctx = k.w<bf16_t>(p.dctx);
     bf16_t* dlog = k.w<bf16_t>(p.dlogits);
     const long long* ids = k.w<long long>(p.dec_ids);
+    if (k.gnorm_ok()) HIP_RET(hipMemsetAsync(s.gnorm_partials, 0, (size_t)vlt5_gnorm_slots(&c) * sizeof(float), k.st));
     RC(vlt5_ce_bwd(k.w<float>(p.logits), s.labels, k.w<float>(p.lse_ce), s.d_loss_tok ? s.d_loss_tok : k.w<float>(p.row_w),
                    s.d_loss_tok ? nullptr : s.gout, dlog, Md, c.vocab, k.st));
     // lm_head (tied to shared): dShared = alpha * dlogits^T dec_out ; d dec_out = alpha * dlogits shared
@@ -697,7 +706,7 @@ int decoder_bwd(const Ctx& k) {
         RC(ks.wgrad_batched(p.d_dyd_s[0], p.d_dyd_s[l1], d, p.ctx_s[0], p.ctx_s[l1], inner, L.dec[0].so, L.dec[l1].so, Ld, Md, d, inner));
         RC(ks.wgrad_batched(p.d_dqkv[0], p.d_dqkv[l1], 3 * inner, p.yn_a[0], p.yn_a[l1], d, L.dec[0].sqkv, L.dec[l1].sqkv, Ld, Md, 3 * inner, d));
         // cross-attention K/V projections of all layers at once
-        RC(ks.lin_wgrad(k.w<bf16_t>(p.dkv_all), kvw, k.w<bf16_t>(p.enc_ext), d, k.Gr + L.cross_kv, Mx, kvw, d));
+        RC(ks.lin_wgrad(k.w<bf16_t>(p.dkv_all), kvw, k.w<bf16_t>(p.enc_ext), d, k.Gr + L.cross_kv, Mx, kvw, d, 1.f, 0, true));
         for (int b = 0; b <= Ld; ++b) RC(ks.record(b));     // decoder-side gradient buckets are complete (rel-bias: before the fork)
     }
     RC(vlt5_embed_bwd(ids, dx, (long long)T * d, d, k.Gr + L.shared, B, T, d, c.vocab, k.pdrop, k.seed(SITE_DEC_EMBED), T, 0, k.st));
@@ -839,6 +848,14 @@ extern "C" long long vlt5_layout_total(const vlt5_config* c) {
     Layout L;
     build_layout(*c, L, false);
     return L.total;
+}
+extern "C" long long vlt5_gnorm_slots(const vlt5_config* c) {
+    if (!c) return 0;
+    const int d = c->d_model, inner = c->num_heads * c->d_kv, ffw = c->gated_act ? 2 * c->d_ff : c->d_ff;
+    if ((d & 63) || (inner & 63) || (ffw & 63) || (c->d_ff & 63)) return 0;
+    Layout L;
+    build_layout(*c, L, false);
+    return (L.total + 4095) / 4096 + 1;
 }
 extern "C" int vlt5_layout_buckets(const vlt5_config* c) {
     if (!c) return -1;

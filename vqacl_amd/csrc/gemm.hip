@@ -47,6 +47,11 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         if ((((uintptr_t)d->c_bf16_copy) & 7)) return VLT5_ERR_ALIGN;
         a.C2 = (bf16_t*)d->c_bf16_copy;
     }
+    a.sumsq = nullptr; a.sumsq_zstride = 0;
+    if (d->sumsq) {
+        if (!d->out_f32 || d->accum || d->bias || d->relu || d->gate || d->resid || d->drop_p > 0.f || d->split_k > 1) return VLT5_ERR_ARG;
+        a.sumsq = d->sumsq; a.sumsq_zstride = d->sumsq_batch_stride;
+    }
     a.batch_a = d->batch_stride_a; a.batch_b = d->batch_stride_b; a.batch_c = d->batch_stride_c;
     const int batch = d->batch > 1 ? d->batch : 1;
     if (batch > 1 && (d->split_k > 1 || d->gate)) return VLT5_ERR_ARG;

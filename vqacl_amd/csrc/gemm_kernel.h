@@ -61,6 +61,7 @@ struct GemmArgs {
     int ktiles_per_split; long long c_split_stride;
     long long batch_a, batch_b, batch_c;          // element strides between batch entries (blockIdx.z)
     bf16_t* C2;                                   // optional bf16 copy of a plain f32 output (same indexing as C), or null
+    float* sumsq; long long sumsq_zstride;        // optional: sum of squares of the tile's (plain f32) output -> sumsq[z*zstride + tile]
 #ifdef GEMM_TIMELINE
     unsigned long long* timeline;
 #endif
@@ -689,6 +690,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
         // scale + pack + store; keeps ~100 option-testing instructions per fragment off the tail of ~70 % of the launches
         const int nb = n0 + wn * TN + lg * 4;
         if (p.out_f32) {
+            float ss = 0.f;                       // (sumsq: the gradient-norm share of this tile, see the end of the branch)
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int m = m0 + wm * TM + i * 16 + lrow;
@@ -699,6 +701,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                     if (nb + j * 16 < p.N) {
                         const float4 o = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha,
                                                      acc[i][j][3] * p.alpha);
+                        ss += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
                         st16f(crow + j * 16, o);
                         if (C2base) {          // the same values rounded to bf16: a data-parallel bucket's staging copy, no cast pass
                             uint2 pk;
@@ -707,6 +710,22 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                             *reinterpret_cast<uint2*>(C2base + (size_t)m * p.ldc + nb + j * 16) = pk;
                         }
                     }
+            }
+            // Weight gradients: the clip-by-global-norm of the optimizer needs sum(g^2) over every gradient -- a second pass over
+            // 0.9 GB (0.16 ms per step at the HBM roofline).  The tile's share is reduced here in a fixed order (lanes, then waves) and
+            // written to the tile's own slot; the optimizer sums the slots in a fixed order too (vlt5_gnorm_finish): deterministic.
+            if (p.sumsq && p.ktiles_per_split == 0) {
+                ss = wave_sum(ss);
+                __syncthreads();                                  // every wave has left the main loop: the stages are free
+                float* red = reinterpret_cast<float*>(smem);
+                if (lane == 0) red[wave] = ss;
+                __syncthreads();
+                if (tid == 0) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w8 = 0; w8 < WM * WN; ++w8) t += red[w8];
+                    p.sumsq[(long long)blockIdx.z * p.sumsq_zstride + tile_id] = t;
+                }
             }
         } else {
 #pragma unroll

@@ -164,6 +164,8 @@ class VLT5(nn.Module):
         self._side = None
         self._side_events = None
         self.external_bf16_sync = False      # True once a fused optimizer keeps the bf16 shadow fresh itself
+        self._gnorm = None                   # per-tile sums of squares left by the weight-gradient GEMMs (vlt5_step.gnorm_partials)
+        self._gnorm_version = None           # version of the flat gradient buffer they describe (None: not valid)
         self._opt_events = None              # per-bucket events of an overlapped optimizer update (FusedAdamW(overlap=True))
         self._bf16_version = -1
         self._build(self.cfg, None)
@@ -538,6 +540,18 @@ class VLT5(nn.Module):
                 self._flat_grad_tmp = torch.zeros_like(self._flat_grad)
             target = self._flat_grad_tmp
         cs = self._make_step(st, target)
+        self._gnorm_version = None
+        fused_norm = direct and self.dp is None and os.environ.get("VQACL_FUSED_GNORM", "1") != "0"
+        if fused_norm:
+            # single process, gradients written straight into the flat buffer: the weight-gradient GEMMs leave their share of
+            # sum(g^2) per output tile, so FusedAdamW's clip needs no second pass over the 0.9 GB of gradients
+            if self._gnorm is None:
+                n = lib().vlt5_gnorm_slots(C.byref(c))
+                self._gnorm = torch.zeros(int(n), device=self._device) if n > 0 else False
+            if self._gnorm is not False:
+                cs.gnorm_partials = ptr(self._gnorm)
+            else:
+                fused_norm = False
         gt = g.reshape(-1).to(torch.float32).contiguous()
         if fused:
             cs.gout = ptr(gt)
@@ -596,4 +610,6 @@ class VLT5(nn.Module):
                     p.grad = gv.clone()
                 else:
                     p.grad.add_(gv)
+        if fused_norm:
+            self._gnorm_version = self._flat_grad._version     # any later in-place edit of a .grad view bumps it: the shares go stale
         del keep

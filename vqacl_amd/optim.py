@@ -50,7 +50,19 @@ class FusedAdamW(torch.optim.Optimizer):
             if used:
                 used_end = max(used_end, off + n)
         self._used_end = used_end
-        self._partial = torch.empty(lib().vlt5_sqnorm_blocks(used_end), device=dev, dtype=torch.float32)
+        self._partial = torch.empty(lib().vlt5_sqnorm_blocks(used_end) + 8, device=dev, dtype=torch.float32)
+        # what the weight-gradient GEMMs' norm shares (VLT5._gnorm) do NOT cover: the last bucket (embeddings, norm weights, visual
+        # embedding: scatter-added / column-summed gradients) and the two relative-position tables inside the layer buckets
+        last = max(b for _, (off, n, b, decay, used) in model._pinfo.items() if used)
+        lo = min(off for _, (off, n, b, decay, used) in model._pinfo.items() if used and b == last)
+        rng = [(lo, used_end - lo)]
+        for name, (off, n, b, decay, used) in model._pinfo.items():
+            if used and b != last and name.endswith("relative_attention_bias.weight"):
+                rng.append((off, n))
+        import ctypes as C
+        self._tail_off = (C.c_longlong * len(rng))(*[a for a, _ in rng])
+        self._tail_n = (C.c_longlong * len(rng))(*[b for _, b in rng])
+        self._tail_k = len(rng)
         # contiguous runs of equal hyper-parameters (alignment gaps hold zeros and stay zero under the update)
         spans = []
         for gi, group in enumerate(self.param_groups):
@@ -136,6 +148,13 @@ class FusedAdamW(torch.optim.Optimizer):
 
         def norm(st):
             if self.max_grad_norm is not None and self.max_grad_norm > 0:
+                gn = getattr(model, "_gnorm", None)
+                if (g16 is None and gn is not None and gn is not False and self._tail_k <= 4
+                        and model._gnorm_version is not None and model._gnorm_version == grad._version):
+                    # the weight-gradient GEMMs of this backward left their shares: sum them + the ranges no GEMM writes
+                    check(lib().vlt5_gnorm_finish(ptr(gn), gn.numel(), ptr(grad), self._tail_off, self._tail_n, self._tail_k,
+                                                  ptr(self._partial), ptr(self._total_sq), st), "vlt5_gnorm_finish")
+                    return self._total_sq
                 if g16 is None:
                     check(lib().vlt5_sqnorm(ptr(grad), self._used_end, ptr(self._partial), ptr(self._total_sq), 0, st), "vlt5_sqnorm")
                 else:
