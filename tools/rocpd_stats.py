@@ -20,8 +20,8 @@ def main():
     total = sum(r[2] for r in rows)
     span = list(cur.execute("select min(start), max(end) from rocpd_kernel_dispatch"))[0]
     print(f"# kernels: {sum(r[1] for r in rows)} dispatches, {total / 1e6:.3f} ms busy, span {(span[1] - span[0]) / 1e6:.3f} ms")
-    if steps is None:                                   # one sqnorm_kernel launch per optimizer step
-        steps = next((r[1] for r in rows if "sqnorm_kernel" in r[0] and "final" not in r[0]), None)
+    if steps is None:                                   # one "final" reduction of the gradient norm per optimizer step (either path)
+        steps = sum(r[1] for r in rows if "gnorm_final_kernel" in r[0] or "sqnorm_final_kernel" in r[0]) or None
     if steps:
         print(f"# {steps} optimizer steps in the trace (timed + warm-up + the PCIe-inclusive side loop): "
               f"{total / 1e6 / steps:.3f} ms kernel time per step")

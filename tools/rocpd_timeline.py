@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One optimizer step of a rocprofv3 rocpd kernel trace as a launch-by-launch timeline: start offset, duration, gap to the
 previous kernel, grid.  usage: python tools/rocpd_timeline.py results.db [--step N] > profiles/timeline.txt
-(a step = from one sqnorm_kernel launch to the next; default: the second to last one)"""
+(a step = from one gradient-norm reduction (gnorm_final_kernel / sqnorm_final_kernel) to the next; default: the second to last one)"""
 import re
 import sqlite3
 import sys
@@ -17,14 +17,15 @@ def main():
     gx = "d.grid_size_x, d.workgroup_size_x, d.grid_size_y, d.grid_size_z" if "grid_size_x" in dcols else "0, 1, 1, 1"
     rows = list(cur.execute(f"""select s.{namecol}, d.start, d.end, {gx} from rocpd_kernel_dispatch d
                                 join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start"""))
-    marks = [i for i, r in enumerate(rows) if "sqnorm_kernel" in r[0] and "final" not in r[0]]
+    marks = [i for i, r in enumerate(rows) if "gnorm_final_kernel" in r[0] or "sqnorm_final_kernel" in r[0]]
     a, b = marks[which - 1] if which != 0 else 0, marks[which]
     # a step starts after the optimizer of the previous one: find the last adamw launch after mark a
     j = a
-    while j + 1 < b and ("adamw" in rows[j + 1][0] or "sqnorm" in rows[j + 1][0]):
+    opt = lambda n: "adamw" in n or "sqnorm" in n or "gnorm" in n
+    while j + 1 < b and opt(rows[j + 1][0]):
         j += 1
     seg = rows[j + 1:b + 1]
-    while b + 1 < len(rows) and ("adamw" in rows[b + 1][0] or "sqnorm" in rows[b + 1][0]):
+    while b + 1 < len(rows) and opt(rows[b + 1][0]):
         b += 1
         seg.append(rows[b])
     t0 = seg[0][1]
