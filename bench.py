@@ -488,10 +488,18 @@ def main():
         del model, opt, store
         torch.cuda.empty_cache()
         out["eager_gpu_baseline"] = eager_gpu_baseline(dev, B)
-    if rank == 0:
-        print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()
+    # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio (buffered when stdout is a pipe, it
+    # would otherwise come out at exit, after the line) -- flush the C side first
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -239,6 +239,8 @@ int vlt5_proto_retrieve(const float* protos, const float* pool, long long* idx, 
 int vlt5_proto_memory_loss(const float* pool, const float* onehot, const float* protos, float* out, int B, int C, int d, void* stream);
 
 /* ---- optimizer: clip_grad_norm_(5) + HF AdamW (src/vqacl.py:466-487, src/trainer_base.py:187-190) */
+/* partial: vlt5_sqnorm_blocks(n) floats.  accum_total: 0 total_sq = sum, 1 total_sq += sum, 2 leave only the block partials (no
+ * reduction: several ranges are then summed by one vlt5_gnorm_finish over the concatenated partials) */
 int vlt5_sqnorm(const float* g, long long n, float* partial, float* total_sq, int accum_total, void* stream);
 /* total_sq[0] = sum(partials[0..nslots)) + sum over the `nranges` (<= 4) element ranges [range_off[i], +range_n[i]) of grads of g^2,
  * all in a fixed order (deterministic).  `scratch`: vlt5_sqnorm_blocks(sum of range_n) + nranges floats.  Completes the

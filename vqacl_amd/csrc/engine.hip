@@ -226,6 +226,7 @@ struct Ctx {
     float pdrop;
     int d, inner, ff, H;
     mutable int ln_jobs = 0;
+    mutable void* last_wait = nullptr;
     mutable long long ln_out[64];
     mutable int ln_nblk[64];
     hipStream_t side = nullptr;        // optional second stream of the backward phases (vlt5_step.side_stream)
@@ -406,8 +407,12 @@ struct Ctx {
     }
     // forward side of an overlapped optimizer: wait until parameter bucket b has been updated (no-op without events)
     int wait_bucket(int b) const {
-        if (s.wait_events && b >= 0 && b < s.n_wait_events && s.wait_events[b])
+        if (s.wait_events && b >= 0 && b < s.n_wait_events && s.wait_events[b] && s.wait_events[b] != last_wait) {
+            // (consecutive buckets may share one event -- the all-gather of a merged slice under sharded data parallelism: one wait
+            // per slice; every cross-stream wait is a barrier packet in the chain's queue)
             HIP_RET(hipStreamWaitEvent(st, (hipEvent_t)s.wait_events[b], 0));
+            last_wait = s.wait_events[b];
+        }
         return VLT5_OK;
     }
     int record(int k) const {

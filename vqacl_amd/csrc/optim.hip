@@ -211,13 +211,14 @@ extern "C" int vlt5_sqnorm(const float* g, long long n, float* partial, float* t
     int nblk = grid_for(n, 4);
     hipLaunchKernelGGL(sqnorm_kernel<false>, dim3(nblk), dim3(256), 0, ST, (const void*)g, 1.f, n, partial);
     LAUNCH_CHECK();
+    if (accum_total == 2) return VLT5_OK;           // partials only: the caller sums several ranges with one vlt5_gnorm_finish
     hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(64), 0, ST, partial, nblk, total_sq, accum_total);
     LAUNCH_CHECK();
     return VLT5_OK;
 }
 extern "C" int vlt5_gnorm_finish(const float* partials, long long nslots, const float* grads, const long long* range_off,
                                  const long long* range_n, int nranges, float* scratch, float* total_sq, void* stream) {
-    if (!partials || nslots <= 0 || !grads || !scratch || !total_sq || nranges < 0 || nranges > 4) return VLT5_ERR_ARG;
+    if (!partials || nslots <= 0 || !scratch || !total_sq || nranges < 0 || nranges > 4 || (nranges > 0 && !grads)) return VLT5_ERR_ARG;
     if (((uintptr_t)partials) & 15) return VLT5_ERR_ALIGN;
     long long used = 0;
     for (int i = 0; i < nranges; ++i) {
@@ -240,6 +241,7 @@ extern "C" int vlt5_sqnorm_g16(const void* g_bf16, float g_scale, long long n, f
     int nblk = grid_for(n, 4);
     hipLaunchKernelGGL(sqnorm_kernel<true>, dim3(nblk), dim3(256), 0, ST, g_bf16, g_scale, n, partial);
     LAUNCH_CHECK();
+    if (accum_total == 2) return VLT5_OK;           // partials only (see vlt5_sqnorm)
     hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(64), 0, ST, partial, nblk, total_sq, accum_total);
     LAUNCH_CHECK();
     return VLT5_OK;

@@ -561,7 +561,14 @@ class VLT5(nn.Module):
         events = None
         if self.dp is not None and direct:
             events = self.dp.make_events(self._nbuckets)
-            arr = (L.vp * len(events))(*[L.vp(e.cuda_event) for e in events])
+            # only the events the wrapper waits for (the last bucket of every merged slice) are recorded: a marker in the chain's
+            # queue is not free, and 26 of them per backward bought nothing
+            Ld_, Le_, nb_ = self.cfg.num_decoder_layers, self.cfg.num_layers, self._nbuckets
+            cut_ = Ld_ + 1 + (Le_ - lib().vlt5_encoder_late_layers(Le_)) if Le_ > 1 else Ld_ + 1
+            need = set()
+            for lo_, hi_ in ((0, Ld_ + 1), (Ld_ + 1, cut_), (nb_ - 1, nb_), (cut_, nb_ - 1)):
+                need.update(last for _, _, _, last in self.dp.slices_of(lo_, hi_))
+            arr = (L.vp * len(events))(*[L.vp(e.cuda_event) if i in need else L.vp() for i, e in enumerate(events)])
             cs.events, cs.n_events = arr, len(events)
             keep = keep + (arr,)
         mirrored = False
