@@ -64,6 +64,24 @@ def test_gemm_forward_layout(dev, tile, M, N, K):
     close(outb, ref, 1e-2, 5e-2, "gemm NT bf16")
 
 
+@pytest.mark.parametrize("tile", [(256, 256), (224, 256), (128, 64)])
+def test_gemm_outputs_identical_over_repeated_launches(dev, tile):
+    """The output stores are write-through assembly (common.h store_wt16): a 16-byte store reads its data late and needs two wait
+    states before a VALU write to those registers -- without them ~1 launch in 12 left one stale dword in the 8-wave kernels.  Forty
+    launches per tile and output type must agree bit for bit with the first one (and the first with the reference)."""
+    from vqacl_amd import ops
+    M, N, K = 400, 768, 768
+    g = torch.Generator().manual_seed(5)
+    A = rnd((M, K), g).to(BF).to(dev)
+    B = (rnd((N, K), g) + torch.arange(N)[:, None] * 0.01).to(BF).to(dev)
+    ref = A.float().cpu() @ B.float().cpu().t()
+    for f32 in (False, True):
+        first = ops.gemm(A, B, M, N, K, out_f32=f32, tile=tile).clone()
+        close(first, ref, 1e-2, 5e-2, "first launch")
+        for _ in range(40):
+            assert torch.equal(ops.gemm(A, B, M, N, K, out_f32=f32, tile=tile), first)
+
+
 @pytest.mark.parametrize("tile", [(256, 256), (224, 256), (160, 256), (128, 128), (64, 64), (0, 0)])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 256), (400, 768, 2304), (4480, 768, 3072), (24, 64, 128)])
 def test_gemm_dgrad_layout(dev, tile, M, N, K):
