@@ -133,6 +133,18 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
             }
         }
     };
+    // the fused [3*inner, d] weight operand was last read a pass ago: every workgroup requests a distinct share of it (one word per
+    // 128-byte line) before its own first tile, so the whole panel is on its way into the memory-side cache at once (gemm_kernel.h,
+    // GEMM_TOUCH_B); the destination register stays allocated through the main loop, whose waits cover the load
+    unsigned touch_sink = 0;
+    {
+        const int lpr = p.d >> 6;
+        const long long nlines = 3LL * inner * lpr, i = (long long)blockIdx.x * FNT + tid;
+        if (i < nlines) {
+            const bf16_t* a = p.wqkv + (size_t)(i / lpr) * p.d + (size_t)(i % lpr) * 64;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(touch_sink) : "v"(a));
+        }
+    }
 #pragma unroll
     for (int pc = 0; pc < LPT; ++pc) piece(0, 0, pc);
 #pragma unroll
@@ -159,6 +171,7 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
         stage ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus prefetch must land before the stages are reused
+    asm volatile("" ::"v"(touch_sink));
     stamp(3);
     // score addends (relative-position bias + key mask) of this wave's two 16-row blocks: requested here (branch-free, all loads in
     // flight together) and combined after the hand-over, which hides their global round trip; kept out of the main loop, whose

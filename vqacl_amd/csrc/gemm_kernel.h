@@ -471,6 +471,40 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     // s_waitcnt vmcnt(LPT) at the top of an iteration only waits for the OLDER group, so a whole iteration of MFMAs covers
     // the memory latency.  One raw s_barrier per k-step (it both publishes tile i and retires the reads of tile i-1, whose
     // stage is the one refilled next).  A partial last k-tile (K % 64 != 0) goes through registers with zero fill.
+    // GEMM_TOUCH_B (0 off, 1 weights, 2 weights + gate): the weight-side operand of a forward / dgrad GEMM was last read a pass ago and comes from HBM.
+    // Every workgroup requests a distinct share of it (one word per 128-byte line) before its own first tile, so the whole
+    // panel is on its way into the memory-side cache at once instead of k-tile by k-tile in front of the leading workgroups.
+#ifndef GEMM_TOUCH_B
+#define GEMM_TOUCH_B 2
+#endif
+    unsigned touch_sink2 = 0, touch_sink3 = 0;
+    unsigned touch_sink = 0;                        // destination of the asynchronous touch load: must stay allocated until it has landed
+    if constexpr (GEMM_TOUCH_B && !AKM) {
+        const int rows_b = BKM ? p.K : p.N, lpr = (BKM ? p.N : p.K) >> 6;          // 64 bf16 = 128 bytes per line
+        const long long nlines = (long long)rows_b * lpr;
+        const long long nthreads = (long long)gridDim.x * gridDim.y * NT;
+        const long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * NT + tid;
+        (void)nthreads;
+        if (blockIdx.z == 0 && i < nlines) {       // one line per lane (a panel larger than that is only partly requested)
+            const bf16_t* a = p.B + (size_t)(i / lpr) * p.ldb + (size_t)(i % lpr) * 64;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(touch_sink) : "v"(a));
+        }
+#if GEMM_TOUCH_B >= 2
+        if (p.gate) {                              // the saved activation the epilogue gates by: as cold as the weights, 6x their size
+            const int lprg = p.N >> 6;
+            const long long ng = (long long)p.M * lprg;
+            if (i < ng) {
+                const bf16_t* a = p.gate + (size_t)(i / lprg) * p.ldg + (size_t)(i % lprg) * 64;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(touch_sink2) : "v"(a));
+            }
+            if (i + nthreads < ng) {
+                const long long i2 = i + nthreads;
+                const bf16_t* a = p.gate + (size_t)(i2 / lprg) * p.ldg + (size_t)(i2 % lprg) * 64;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(touch_sink3) : "v"(a));
+            }
+        }
+#endif
+    }
     const bool has_tail = (kt1 == nk_total) && (p.K % BK != 0) && (kt1 > kt0);
     const int nmain = (kt1 - kt0) - (has_tail ? 1 : 0);
     if constexpr (KM_STEP) {
@@ -662,6 +696,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
         compute(stage);
     }
 
+    if constexpr (GEMM_TOUCH_B && !AKM) asm volatile("" ::"v"(touch_sink), "v"(touch_sink2), "v"(touch_sink3));     // (alive through the main loop; its waits have covered the load)
     TL(3);
     // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4 -----------
     // Two phases.  (1) ALL auxiliary operands of the wave's tile (residual / C-for-accumulate, or the gate, and the bias) are
