@@ -32,7 +32,7 @@ int vlt5_abi_version(void);
  * replaces nn.Linear in T5Attention q/k/v/o (HF T5Attention.forward), T5DenseReluDense wi/wo,
  * VisualEmbedding.feat_embedding[0] (src/modeling_t5_our.py:107), lm_head (:671) and, with the
  * k-major flags, their autograd dgrad / wgrad matmuls (src/vqacl.py:461 loss.backward()). */
-typedef struct {
+typedef struct vlt5_gemm_desc_s {
     const void* A; const void* B; void* C;   /* A,B bf16; C bf16 or f32 (out_f32) */
     int M, N, K;
     int lda, ldb, ldc;                       /* leading dimensions in elements */
@@ -52,6 +52,9 @@ typedef struct {
     int split_used;                          /* out: the number of slabs actually written (<= split_k), 1 if not split */
     void* c_bf16_copy;                       /* optional: plain f32 output (no epilogue option, no accum) is ALSO written rounded to bf16
                                                 here, same ldc / batch stride -- the staging copy of a data-parallel gradient bucket */
+    const struct vlt5_gemm_desc_s* grouped_with; /* optional: a SECOND problem launched in the same grid (plain f32 output, same K, batch,
+                                                operand orders, alpha, no split): two weight gradients whose tile counts fill the
+                                                chip only together.  Its own grouped_with / tile fields are ignored */
     float* sumsq; long long sumsq_batch_stride; /* optional (plain f32 output, no split): sum of squares of every output tile, written to
                                                 sumsq[z * sumsq_batch_stride + t], t < tiles of the launch's tile shape (at most
                                                 ceil(M/64)*ceil(N/64)); fixed reduction order -- the optimizer's gradient norm

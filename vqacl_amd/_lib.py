@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
                 ("relu", c_i), ("out_f32", c_i), ("accum", c_i), ("split_k", c_i), ("workspace", vp),
                 ("tile_m", c_i), ("tile_n", c_i), ("batch", c_i), ("batch_stride_a", c_ll), ("batch_stride_b", c_ll),
                 ("batch_stride_c", c_ll), ("defer_reduce", c_i), ("split_used", c_i), ("c_bf16_copy", vp),
-                ("sumsq", vp), ("sumsq_batch_stride", c_ll)]
+                ("grouped_with", vp), ("sumsq", vp), ("sumsq_batch_stride", c_ll)]
 
 
 class AttnDesc(C.Structure):

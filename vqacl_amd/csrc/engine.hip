@@ -387,9 +387,10 @@ struct Ctx {
     // dW_l[N,K] = dY_l[M,N]^T X_l[M,K] for `layers` layers at once; per-layer byte strides of the operand buffers and the
     // element stride of the gradient entries are constant by construction of the plan / layout.
     int wgrad_batched(size_t dy0, size_t dy1, int ldy, size_t x0, size_t x1, int ldx, long long g0, long long g1, int layers,
-                      int M, int N, int K) const {
+                      int M, int N, int K, vlt5_gemm_desc* only_fill = nullptr, const vlt5_gemm_desc* group = nullptr) const {
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);
+        g.grouped_with = group;
         g.A = w<void>(dy0); g.B = w<void>(x0); g.C = Gr + g0; g.M = N; g.N = K; g.K = M; g.lda = ldy; g.ldb = ldx; g.ldc = K;
         g.a_kmajor = 1; g.b_kmajor = 1; g.alpha = 1.f; g.out_f32 = 1;
         g.c_bf16_copy = g16(Gr + g0);
@@ -399,10 +400,11 @@ struct Ctx {
         g.batch_stride_c = layers > 1 ? (g1 - g0) : 0;
         g.sumsq = gsq(Gr + g0);                                // every batched weight gradient is a layer matrix: norm share
         g.sumsq_batch_stride = layers > 1 ? (g1 - g0) / 4096 : 0;
-        if (layers == 1 && !g.sumsq) {
+        if (layers == 1 && !g.sumsq && !group && !only_fill) {
             int sk = pick_split(N, K, M);
             if (sk > 1) { g.split_k = sk; g.workspace = w<void>(p.slab); }
         }
+        if (only_fill) { *only_fill = g; return VLT5_OK; }       // (the second problem of a grouped launch)
         return vlt5_gemm_bf16(&g, st);
     }
     // forward side of an overlapped optimizer: wait until parameter bucket b has been updated (no-op without events)
@@ -735,8 +737,17 @@ int enc_wgrads(const Ctx& k, int lo, int hi) {
     const int l1 = n > 1 ? lo + 1 : lo;
     RC(k.wgrad_batched(p.e_dyd_f[lo], p.e_dyd_f[l1], d, p.h[lo], p.h[l1], ff, L.enc[lo].wo, L.enc[l1].wo, n, M, d, ff));
     RC(k.wgrad_batched(p.e_dh[lo], p.e_dh[l1], k.ffw(), p.xn_f[lo], p.xn_f[l1], d, L.enc[lo].wi, L.enc[l1].wi, n, M, k.ffw(), d));
-    RC(k.wgrad_batched(p.e_dyd_a[lo], p.e_dyd_a[l1], d, p.ctx[lo], p.ctx[l1], inner, L.enc[lo].so, L.enc[l1].so, n, M, d, inner));
-    RC(k.wgrad_batched(p.e_dqkv[lo], p.e_dqkv[l1], 3 * inner, p.xn_a[lo], p.xn_a[l1], d, L.enc[lo].sqkv, L.enc[l1].sqkv, n, M, 3 * inner, d));
+    // the two attention weight gradients share one grid: 162 + 54 tiles of 256 x 256 (six layers) fill the chip only together
+    static const bool grouped = !(getenv("VLT5_WGRAD_GROUPED") && atoi(getenv("VLT5_WGRAD_GROUPED")) == 0);
+    if (grouped) {
+        vlt5_gemm_desc so;
+        RC(k.wgrad_batched(p.e_dyd_a[lo], p.e_dyd_a[l1], d, p.ctx[lo], p.ctx[l1], inner, L.enc[lo].so, L.enc[l1].so, n, M, d, inner, &so));
+        RC(k.wgrad_batched(p.e_dqkv[lo], p.e_dqkv[l1], 3 * inner, p.xn_a[lo], p.xn_a[l1], d, L.enc[lo].sqkv, L.enc[l1].sqkv, n, M, 3 * inner, d,
+                           nullptr, &so));
+    } else {
+        RC(k.wgrad_batched(p.e_dyd_a[lo], p.e_dyd_a[l1], d, p.ctx[lo], p.ctx[l1], inner, L.enc[lo].so, L.enc[l1].so, n, M, d, inner));
+        RC(k.wgrad_batched(p.e_dqkv[lo], p.e_dqkv[l1], 3 * inner, p.xn_a[lo], p.xn_a[l1], d, L.enc[lo].sqkv, L.enc[l1].sqkv, n, M, 3 * inner, d));
+    }
     return VLT5_OK;
 }
 

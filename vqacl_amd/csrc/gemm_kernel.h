@@ -62,6 +62,11 @@ struct GemmArgs {
     long long batch_a, batch_b, batch_c;          // element strides between batch entries (blockIdx.z)
     bf16_t* C2;                                   // optional bf16 copy of a plain f32 output (same indexing as C), or null
     float* sumsq; long long sumsq_zstride;        // optional: sum of squares of the tile's (plain f32) output -> sumsq[z*zstride + tile]
+    // grouped launch: workgroups [grp_tiles, gridDim.x) work on a SECOND problem with the same K, batch and (plain f32) epilogue
+    int grp_tiles;
+    const bf16_t* gA; const bf16_t* gB; void* gC; int gM, gN, glda, gldb, gldc;
+    long long gbatch_a, gbatch_b, gbatch_c;
+    bf16_t* gC2; float* gsumsq; long long gsumsq_zstride;
 #ifdef GEMM_TIMELINE
     unsigned long long* timeline;
 #endif
@@ -305,11 +310,18 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     // XCD-aware tile mapping: the dispatcher places workgroup b on XCD b % 8 (each XCD has a private 4 MB L2), so give
     // every XCD one contiguous run of tiles, n fastest: the tiles that share an A row-panel run on the same L2 back to
     // back, and the weight panel stays L2-resident per XCD.  Bijective for any tile count (speed only, never correctness).
+    int bid = blockIdx.x;
+    if (p.grp_tiles > 0 && bid >= p.grp_tiles) {             // (workgroup-uniform) the second problem of a grouped launch
+        bid -= p.grp_tiles;
+        p.A = p.gA; p.B = p.gB; p.C = p.gC; p.M = p.gM; p.N = p.gN; p.lda = p.glda; p.ldb = p.gldb; p.ldc = p.gldc;
+        p.batch_a = p.gbatch_a; p.batch_b = p.gbatch_b; p.batch_c = p.gbatch_c;
+        p.C2 = p.gC2; p.sumsq = p.gsumsq; p.sumsq_zstride = p.gsumsq_zstride;
+    }
     const int gx = (p.N + BN - 1) / BN, gy = (p.M + BM - 1) / BM;
     const int ntiles = gx * gy;
     int tile_id;
     {
-        const int b = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = b & 7, loc = b >> 3;
+        const int b = bid, q = ntiles >> 3, r = ntiles & 7, xcd = b & 7, loc = b >> 3;
         tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     const int m0 = (tile_id / gx) * BM, n0 = (tile_id % gx) * BN;
@@ -977,8 +989,12 @@ int launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
 }
 
 template <int BM, int BN>
-int launch_tile(const GemmArgs& a, int akm, int bkm, int splits, int batch, hipStream_t st) {
-    dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM), splits > 1 ? splits : 1, batch > 1 ? batch : 1);
+int launch_tile(const GemmArgs& a_in, int akm, int bkm, int splits, int batch, hipStream_t st) {
+    GemmArgs a = a_in;
+    const int t1 = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
+    int t2 = 0;
+    if (a.gA) { t2 = ((a.gN + BN - 1) / BN) * ((a.gM + BM - 1) / BM); a.grp_tiles = t1; }     // grouped launch: the second problem's tiles follow
+    dim3 grid(t1 + t2, splits > 1 ? splits : 1, batch > 1 ? batch : 1);
     // ring depth: 3 stages up to 64x128 (72 KB, 2 workgroups/CU); 2 for 128x128 (a 3-stage ring = 96 KB = 1 workgroup/CU
     // measured 13 % slower end to end: occupancy matters more) and for 256x256 (2 x 64 KB, one 8-wave workgroup per CU)
 #ifndef GEMM_NS_SMALL
