@@ -68,7 +68,8 @@ int vlt5_gemm_auto_split(int M, int N, int Kred, long long slab_bytes);
 /* measurement hook for bench.py's roofline (no counterpart in the reference): while enabled (max_launches > 0; 0 disables and
  * frees), every GEMM kernel dispatch carries its own start/stop HIP events; collect() waits for them and returns one record per
  * dispatch in launch order (the number of records, -1 on error), then resets.  Process-global, not thread-safe. */
-typedef struct { int M, N, K, batch, tile_m, tile_n, a_kmajor, b_kmajor, splits, workgroups, out_f32; float ms; } vlt5_gemm_timing_rec;
+typedef struct { int M, N, K, batch, tile_m, tile_n, a_kmajor, b_kmajor, splits, workgroups, out_f32; float ms;
+                 int M2, N2; /* the second problem of a grouped launch (same K, batch), 0 otherwise */ } vlt5_gemm_timing_rec;
 int vlt5_gemm_timing_enable(int max_launches);
 int vlt5_gemm_timing_collect(vlt5_gemm_timing_rec* out, int cap);
 

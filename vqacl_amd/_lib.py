@@ -51,7 +51,7 @@ class EncAttnGrads(C.Structure):
 
 class GemmTimingRec(C.Structure):
     _fields_ = [("M", c_i), ("N", c_i), ("K", c_i), ("batch", c_i), ("tile_m", c_i), ("tile_n", c_i), ("a_kmajor", c_i),
-                ("b_kmajor", c_i), ("splits", c_i), ("workgroups", c_i), ("out_f32", c_i), ("ms", c_f)]
+                ("b_kmajor", c_i), ("splits", c_i), ("workgroups", c_i), ("out_f32", c_i), ("ms", c_f), ("M2", c_i), ("N2", c_i)]
 
 
 class Config(C.Structure):

@@ -978,6 +978,7 @@ int launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
         vlt5_gemm_timing_rec r;
         r.M = a.M; r.N = a.N; r.K = a.K; r.batch = (int)grid.z; r.tile_m = BM; r.tile_n = BN; r.a_kmajor = AKM; r.b_kmajor = BKM;
         r.splits = (int)grid.y; r.workgroups = (int)(grid.x * grid.y * grid.z); r.out_f32 = a.out_f32; r.ms = 0.f;
+        r.M2 = a.grp_tiles > 0 ? a.gM : 0; r.N2 = a.grp_tiles > 0 ? a.gN : 0;
         g_timing.rec.push_back(r);
         hipExtLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, NS>), grid, dim3(WM * WN * 64), lds, st, g_timing.ev[2 * i],
                               g_timing.ev[2 * i + 1], 0, a);
