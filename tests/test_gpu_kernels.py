@@ -64,6 +64,47 @@ def test_gemm_forward_layout(dev, tile, M, N, K):
     close(outb, ref, 1e-2, 5e-2, "gemm NT bf16")
 
 
+@pytest.mark.parametrize("tile", [(0, 0), (256, 256), (128, 128)])
+def test_grouped_launch_equals_two_launches(dev, tile):
+    """vlt5_gemm_desc.grouped_with: two weight-gradient problems (both operands k-major, same reduction and batch) in ONE grid produce,
+    bit for bit, what the two separate launches produce -- outputs and the per-tile sums of squares of the gradient-norm shares."""
+    import ctypes as C
+    from vqacl_amd import ops
+    from vqacl_amd._lib import check, lib, stream_ptr
+    K, layers = 448, 3
+    g = torch.Generator().manual_seed(9)
+    dims = ((320, 192), (128, 192))                                   # (M, N) of the two problems: dW[M, N] = dY[K, M]^T X[K, N]
+    A = [rnd((layers, K, m), g).to(BF).to(dev) for m, _ in dims]
+    B = [rnd((layers, K, n), g).to(BF).to(dev) for _, n in dims]
+
+    def run(grouped):
+        outs = [torch.zeros(layers, m, n, device=dev) for m, n in dims]
+        sq = [torch.zeros(layers * 64, device=dev) for _ in dims]
+        descs = []
+        for i, (m, n) in enumerate(dims):
+            d, _, keep = ops.gemm_desc(A[i][0], B[i][0], m, n, K, a_kmajor=True, b_kmajor=True, out=outs[i][0], tile=tile, batch=layers,
+                                       batch_strides=(A[i].stride(0), B[i].stride(0), outs[i].stride(0)))
+            d.sumsq, d.sumsq_batch_stride = sq[i].data_ptr(), 64
+            descs.append(d)
+        if grouped:
+            descs[0].grouped_with = C.addressof(descs[1])
+            check(lib().vlt5_gemm_bf16(C.byref(descs[0]), stream_ptr()), "grouped")
+        else:
+            for d in descs:
+                check(lib().vlt5_gemm_bf16(C.byref(d), stream_ptr()), "single")
+        torch.cuda.synchronize()
+        return outs, sq
+
+    o1, s1 = run(False)
+    o2, s2 = run(True)
+    for i, (m, n) in enumerate(dims):
+        ref = torch.einsum("lkm,lkn->lmn", A[i].float(), B[i].float())
+        close(o1[i], ref, 2e-3, 3e-2, "separate launches")
+        assert torch.equal(o1[i], o2[i]), "grouped output differs"
+        assert torch.equal(s1[i], s2[i]), "grouped norm shares differ"
+        assert abs(float(s2[i].double().sum()) - float((o2[i].double() ** 2).sum())) <= 1e-5 * float((o2[i].double() ** 2).sum())
+
+
 @pytest.mark.parametrize("tile", [(256, 256), (224, 256), (128, 64)])
 def test_gemm_outputs_identical_over_repeated_launches(dev, tile):
     """The output stores are write-through assembly (common.h store_wt16): a 16-byte store reads its data late and needs two wait
