@@ -9,10 +9,13 @@ from bench import synthetic_batch
 from vqacl_amd import VLT5VQA, VLT5Config, FusedAdamW, reference_param_groups
 from vqacl_amd._lib import GemmTimingRec, lib
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+large = "--large" in sys.argv                  # VL-T5-large (BASELINE configs[4]): d = 1024, 16 heads, d_ff = 4096, 24 layers, B = 32
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+B = int(args[0]) if args else (32 if large else 80)
 steps = 6
 dev = torch.device("cuda")
-model = VLT5VQA(VLT5Config(dropout_rate=0.1), device=dev)
+kw = dict(d_model=1024, num_heads=16, d_ff=4096, num_layers=24) if large else {}
+model = VLT5VQA(VLT5Config(dropout_rate=0.1, **kw), device=dev)
 model.train()
 opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-4, eps=1e-6, max_grad_norm=5.0)
 batch = {k: v.to(dev) for k, v in synthetic_batch(B, seed=1).items()}

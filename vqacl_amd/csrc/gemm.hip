@@ -94,8 +94,9 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         static const int t128_kmkm = getenv("VLT5_GEMM_T128_KMKM") ? atoi(getenv("VLT5_GEMM_T128_KMKM")) : 100;
         static const int t256_km = getenv("VLT5_GEMM_T256_KM") ? atoi(getenv("VLT5_GEMM_T256_KM")) : 160;
         const int t128 = (d->a_kmajor && d->b_kmajor) ? t128_kmkm : 768;
+        static const int t256_min = getenv("VLT5_GEMM_T256_MIN") ? atoi(getenv("VLT5_GEMM_T256_MIN")) : 100;   // (160 until the t5-large shapes were measured: 1792 x 4096 x 1024 as 192 tiles of 160 x 256, +3 % on that step)
         if (d->a_kmajor && d->K >= 1024 && tiles(256, 256) >= t256_km) { bm = 256; bn = 256; }
-        else if (!d->a_kmajor && (tiles(256, 256) >= 160 || (d->K >= 8192 && d->split_k > 1 && tiles(256, 256) >= 128))) {
+        else if (!d->a_kmajor && (tiles(256, 256) >= t256_min || (d->K >= 8192 && d->split_k > 1 && tiles(256, 256) >= 128))) {
             // 8-wave kernel; its tile HEIGHT is chosen to fill the 256 CUs: a launch costs about (fixed part + k-steps x height/256)
             // per round of 256 workgroups, the fixed part (launch, prologue, epilogue) being worth ~9 k-steps of the full tile
             // (FFN-in forward 4480 x 3072: 216 tiles of 256 rows = 84 % of the CUs -> 240 tiles of 224 rows)
