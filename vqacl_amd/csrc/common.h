@@ -12,6 +12,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;          // one MFMA 
 #define VLT5_ERR_ALIGN 1002        // a contiguous dimension is not a multiple of 8 elements
 
 #define WAVE 64
+#ifndef LNB_MAXBLK
+#define LNB_MAXBLK 320             // workgroups of a norm backward = weight-gradient partials per norm (engine scratch: 64 x LNB_MAXBLK x d)
+#endif
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 

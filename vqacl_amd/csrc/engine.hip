@@ -204,7 +204,7 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     p.slab_bytes = 8 * wmax * 4;
     p.slab = take(p.slab_bytes);
     p.slab2 = take(p.slab_bytes);                            // split-K scratch of the weight-gradient side stream
-    p.ln_partial = take((size_t)64 * 320 * d * 4);          // 64 norm slots x <= 320 workgroup partials
+    p.ln_partial = take((size_t)64 * LNB_MAXBLK * d * 4);          // 64 norm slots x <= 320 workgroup partials
     p.vis_partial = take(((size_t)256 * 10 * d + 2 * (size_t)B * V) * 4);   // <= 256 row splits (vlt5_vis_embed_bwd_blocks)
     size_t rs = 64 * H * (size_t)(L > T ? L : T) * (L > T ? L : T) * 4;
     p.rel_scratch = take(rs);
@@ -370,7 +370,7 @@ struct Ctx {
                float dp, uint32_t dseed, int in_group, int in_group_stride, bf16_t* next_dst, uint32_t next_seed,
                int nslabs = 1, long long slab_stride = 0) const {
         if (ln_jobs >= 64) { int rc = ln_flush(); if (rc) return rc; }     // deep stacks (t5-large: 73 norms per phase)
-        float* part = w<float>(p.ln_partial) + (size_t)ln_jobs * 320 * d;
+        float* part = w<float>(p.ln_partial) + (size_t)ln_jobs * LNB_MAXBLK * d;
         ln_out[ln_jobs] = w_off;
         ln_nblk[ln_jobs] = vlt5_layernorm_bwd_blocks(rows);
         ++ln_jobs;
@@ -380,7 +380,7 @@ struct Ctx {
     }
     int ln_flush() const {
         if (ln_jobs == 0) return VLT5_OK;
-        int rc = vlt5_colsum_multi(w<float>(p.ln_partial), Gr, ln_out, ln_nblk, ln_jobs, 320, d, st);
+        int rc = vlt5_colsum_multi(w<float>(p.ln_partial), Gr, ln_out, ln_nblk, ln_jobs, LNB_MAXBLK, d, st);
         ln_jobs = 0;
         return rc;
     }

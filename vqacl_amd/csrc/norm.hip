@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(const float* __restri
 
 extern "C" int vlt5_layernorm_bwd_blocks(int rows) {
     int b = (rows + 3) / 4;
-    return b < 320 ? (b < 1 ? 1 : b) : 320;
+    return b < LNB_MAXBLK ? (b < 1 ? 1 : b) : LNB_MAXBLK;
 }
 
 extern "C" int vlt5_layernorm_fwd(const float* x, const float* w, void* y_bf16, float* y_f32, float* rstd, int rows, int d,
