@@ -147,12 +147,12 @@ def insitu_gemm_roofline(step_fn, n_steps):
     by = {}
     tot_ms = tot_gflop = alg_bytes = 0.0
     for r in recs[:n]:
-        gf = 2.0 * r.batch * (r.M * r.N + r.M2 * r.N2) * r.K / 1e9          # (a grouped launch carries a second problem)
+        gf = 2.0 * (r.batch * r.M * r.N * r.K + r.batch2 * r.M2 * r.N2 * r.K2) / 1e9          # (a grouped launch carries a second problem)
         tot_ms += r.ms
         tot_gflop += gf
         # algorithmic bytes of a launch: both bf16 operands once + the output once (f32 or bf16; split-K slabs count as written)
         alg_bytes += r.batch * (2.0 * (r.M * r.K + r.N * r.K) + (4 if r.out_f32 else 2) * r.M * r.N * max(r.splits, 1))
-        alg_bytes += r.batch * (2.0 * (r.M2 * r.K + r.N2 * r.K) + 4 * r.M2 * r.N2) if r.M2 else 0.0
+        alg_bytes += r.batch2 * (2.0 * (r.M2 * r.K2 + r.N2 * r.K2) + 4 * r.M2 * r.N2) if r.M2 else 0.0
         if (r.tile_m, r.tile_n) == (128, 384):      # the fused q|k|v projection + attention core (its 2*M*N*K is the projection alone)
             key = "qkv_attn_fwd_kernel<128,384> (projection + attention core)"
         else:

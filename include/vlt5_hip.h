@@ -52,9 +52,10 @@ typedef struct vlt5_gemm_desc_s {
     int split_used;                          /* out: the number of slabs actually written (<= split_k), 1 if not split */
     void* c_bf16_copy;                       /* optional: plain f32 output (no epilogue option, no accum) is ALSO written rounded to bf16
                                                 here, same ldc / batch stride -- the staging copy of a data-parallel gradient bucket */
-    const struct vlt5_gemm_desc_s* grouped_with; /* optional: a SECOND problem launched in the same grid (plain f32 output, same K, batch,
-                                                operand orders, alpha, no split): two weight gradients whose tile counts fill the
-                                                chip only together.  Its own grouped_with / tile fields are ignored */
+    const struct vlt5_gemm_desc_s* grouped_with; /* optional: a SECOND problem launched in the same (flat) grid -- plain f32 output, same
+                                                operand orders and alpha, no split; its own shape, reduction length and batch count:
+                                                weight gradients whose tile counts fill the chip only together, or a short problem
+                                                in the shadow of a long one.  Its own grouped_with / tile fields are ignored */
     float* sumsq; long long sumsq_batch_stride; /* optional (plain f32 output, no split): sum of squares of every output tile, written to
                                                 sumsq[z * sumsq_batch_stride + t], t < tiles of the launch's tile shape (at most
                                                 ceil(M/64)*ceil(N/64)); fixed reduction order -- the optimizer's gradient norm
@@ -69,7 +70,7 @@ int vlt5_gemm_auto_split(int M, int N, int Kred, long long slab_bytes);
  * frees), every GEMM kernel dispatch carries its own start/stop HIP events; collect() waits for them and returns one record per
  * dispatch in launch order (the number of records, -1 on error), then resets.  Process-global, not thread-safe. */
 typedef struct { int M, N, K, batch, tile_m, tile_n, a_kmajor, b_kmajor, splits, workgroups, out_f32; float ms;
-                 int M2, N2; /* the second problem of a grouped launch (same K, batch), 0 otherwise */ } vlt5_gemm_timing_rec;
+                 int M2, N2, K2, batch2; /* the second problem of a grouped launch, 0 otherwise */ } vlt5_gemm_timing_rec;
 int vlt5_gemm_timing_enable(int max_launches);
 int vlt5_gemm_timing_collect(vlt5_gemm_timing_rec* out, int cap);
 
@@ -344,6 +345,10 @@ typedef struct {
      * (vlt5_gemm_desc.sumsq; slot = ceil(flat offset / 4096) + tile) -- with vlt5_gnorm_finish over the remaining ranges (last
      * bucket, relative-position tables) the optimizer's global gradient norm needs no second pass over 0.9 GB of gradients. */
     float* gnorm_partials;
+    /* 1: vlt5_decoder_bwd leaves five of the decoder's six batched weight gradients to vlt5_encoder_bwd, which launches them as the
+     * second problem of its long weight-gradient launches (they run on the CUs those leave idle).  The decoder's weight gradients
+     * are then complete only after vlt5_encoder_bwd; ignored with a side stream / gradient-bucket events (data parallelism). */
+    int defer_decoder_wgrads;
 } vlt5_step;
 /* number of slots of vlt5_step.gnorm_partials for this configuration, or 0 when it is not supported (a matrix dimension that is
  * no multiple of 64: the slot ranges of neighbouring tensors would overlap) */

@@ -71,18 +71,18 @@ def test_grouped_launch_equals_two_launches(dev, tile):
     import ctypes as C
     from vqacl_amd import ops
     from vqacl_amd._lib import check, lib, stream_ptr
-    K, layers = 448, 3
     g = torch.Generator().manual_seed(9)
     dims = ((320, 192), (128, 192))                                   # (M, N) of the two problems: dW[M, N] = dY[K, M]^T X[K, N]
-    A = [rnd((layers, K, m), g).to(BF).to(dev) for m, _ in dims]
-    B = [rnd((layers, K, n), g).to(BF).to(dev) for _, n in dims]
+    Ks, Ls = (1088, 192), (3, 5)                                      # each problem has its own reduction length and batch count
+    A = [rnd((Ls[i], Ks[i], m), g).to(BF).to(dev) for i, (m, _) in enumerate(dims)]
+    B = [rnd((Ls[i], Ks[i], n), g).to(BF).to(dev) for i, (_, n) in enumerate(dims)]
 
     def run(grouped):
-        outs = [torch.zeros(layers, m, n, device=dev) for m, n in dims]
-        sq = [torch.zeros(layers * 64, device=dev) for _ in dims]
+        outs = [torch.zeros(Ls[i], m, n, device=dev) for i, (m, n) in enumerate(dims)]
+        sq = [torch.zeros(Ls[i] * 64, device=dev) for i in range(2)]
         descs = []
         for i, (m, n) in enumerate(dims):
-            d, _, keep = ops.gemm_desc(A[i][0], B[i][0], m, n, K, a_kmajor=True, b_kmajor=True, out=outs[i][0], tile=tile, batch=layers,
+            d, _, keep = ops.gemm_desc(A[i][0], B[i][0], m, n, Ks[i], a_kmajor=True, b_kmajor=True, out=outs[i][0], tile=tile, batch=Ls[i],
                                        batch_strides=(A[i].stride(0), B[i].stride(0), outs[i].stride(0)))
             d.sumsq, d.sumsq_batch_stride = sq[i].data_ptr(), 64
             descs.append(d)

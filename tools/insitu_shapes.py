@@ -42,7 +42,7 @@ n = lib().vlt5_gemm_timing_collect(recs, cap)
 lib().vlt5_gemm_timing_enable(0)
 by = {}
 for r in recs[:n]:
-    key = (r.tile_m, r.tile_n, r.M, r.N, r.K, r.batch, r.a_kmajor, r.b_kmajor, r.splits, r.workgroups, r.out_f32, r.M2, r.N2)
+    key = (r.tile_m, r.tile_n, r.M, r.N, r.K, r.batch, r.a_kmajor, r.b_kmajor, r.splits, r.workgroups, r.out_f32, r.M2, r.N2, r.K2, r.batch2)
     v = by.setdefault(key, [0, 0.0])
     v[0] += 1
     v[1] += r.ms
@@ -50,7 +50,7 @@ tot = sum(v[1] for v in by.values()) / steps
 print(f"# {n / steps:.0f} dispatches per step, {tot:.3f} ms per step in the GEMM family")
 print("tile      M      N      K  batch akm bkm splits   wgs f32  calls/step   avg_us   ms/step   TFLOP/s")
 for key, v in sorted(by.items(), key=lambda kv: -kv[1][1]):
-    tm, tn, M, N, K, bt, akm, bkm, sp, wg, f32, M2, N2 = key
+    tm, tn, M, N, K, bt, akm, bkm, sp, wg, f32, M2, N2, K2, bt2 = key
     us = v[1] / v[0] * 1e3
-    tf = 2.0 * bt * (M * N + M2 * N2) * K / (us * 1e-6) / 1e12            # (M2 x N2: the second problem of a grouped launch)
-    print(f"{tm:3d}x{tn:<3d} {M:6d} {N:6d} {K:6d} {bt:5d} {akm:3d} {bkm:3d} {sp:6d} {wg:5d} {f32:3d} {v[0] / steps:10.1f} {us:9.2f} {v[1] / steps:9.3f} {tf:9.1f}" + (f"   + {M2}x{N2} grouped" if M2 else ""))
+    tf = 2.0 * (bt * M * N * K + bt2 * M2 * N2 * K2) / (us * 1e-6) / 1e12            # (M2 x N2: the second problem of a grouped launch)
+    print(f"{tm:3d}x{tn:<3d} {M:6d} {N:6d} {K:6d} {bt:5d} {akm:3d} {bkm:3d} {sp:6d} {wg:5d} {f32:3d} {v[0] / steps:10.1f} {us:9.2f} {v[1] / steps:9.3f} {tf:9.1f}" + (f"   + {M2}x{N2}x{K2} x{bt2} grouped" if M2 else ""))

@@ -51,7 +51,7 @@ class EncAttnGrads(C.Structure):
 
 class GemmTimingRec(C.Structure):
     _fields_ = [("M", c_i), ("N", c_i), ("K", c_i), ("batch", c_i), ("tile_m", c_i), ("tile_n", c_i), ("a_kmajor", c_i),
-                ("b_kmajor", c_i), ("splits", c_i), ("workgroups", c_i), ("out_f32", c_i), ("ms", c_f), ("M2", c_i), ("N2", c_i)]
+                ("b_kmajor", c_i), ("splits", c_i), ("workgroups", c_i), ("out_f32", c_i), ("ms", c_f), ("M2", c_i), ("N2", c_i), ("K2", c_i), ("batch2", c_i)]
 
 
 class Config(C.Structure):
@@ -69,7 +69,7 @@ class Step(C.Structure):
                 ("wait_events", C.POINTER(vp)), ("n_wait_events", c_i),
                 ("feat_store", vp), ("box_store", vp), ("feat_slots", vp), ("n_slots", c_ll),
                 ("side_stream", vp), ("side_events", C.POINTER(vp)), ("n_side_events", c_i), ("grads_bf16", vp),
-                ("gnorm_partials", vp)]
+                ("gnorm_partials", vp), ("defer_decoder_wgrads", c_i)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/vlt5_hip.h

@@ -281,7 +281,7 @@ extern "C" int vlt5_qkv_attn_fwd(const void* xn_bf16, const void* wqkv_bf16, voi
         const size_t i = tm.rec.size();
         vlt5_gemm_timing_rec r;
         r.M = a.B * a.S; r.N = 3 * inner; r.K = a.d; r.batch = 1; r.tile_m = FBM; r.tile_n = FBN; r.a_kmajor = 0; r.b_kmajor = 0;
-        r.splits = 1; r.workgroups = grid; r.out_f32 = 0; r.ms = 0.f; r.M2 = 0; r.N2 = 0;
+        r.splits = 1; r.workgroups = grid; r.out_f32 = 0; r.ms = 0.f; r.M2 = 0; r.N2 = 0; r.K2 = 0; r.batch2 = 0;
         tm.rec.push_back(r);
         hipExtLaunchKernelGGL(qkv_attn_fwd_kernel<false>, dim3(grid), dim3(FNT), FUSED_LDS, (hipStream_t)stream, tm.ev[2 * i], tm.ev[2 * i + 1],
                               0, a, (unsigned long long*)nullptr);

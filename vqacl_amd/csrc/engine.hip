@@ -340,14 +340,15 @@ struct Ctx {
     // dW[N,K] (+)= alpha * dY[M,N]^T X[M,K]     (both read k-major, reduction over the M rows)
     // norm_share: the tiles' sums of squares go to the gradient-norm partials (a tensor nothing else adds to afterwards)
     int lin_wgrad(const bf16_t* dY, int ldy, const bf16_t* X, int ldx, float* dW, int M, int N, int K, float alpha = 1.f,
-                  int accum = 0, bool norm_share = false) const {
+                  int accum = 0, bool norm_share = false, const vlt5_gemm_desc* group = nullptr) const {
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);
+        g.grouped_with = group;
         g.A = dY; g.B = X; g.C = dW; g.M = N; g.N = K; g.K = M; g.lda = ldy; g.ldb = ldx; g.ldc = K;
         g.a_kmajor = 1; g.b_kmajor = 1; g.alpha = alpha; g.out_f32 = 1; g.accum = accum;
         if (!accum) g.c_bf16_copy = g16(dW);
         if (norm_share && !accum) g.sumsq = gsq(dW);
-        int sk = g.sumsq ? 1 : pick_split(N, K, M);           // (the slab reduction has no norm share: such launches are not cut)
+        int sk = (g.sumsq || group) ? 1 : pick_split(N, K, M);   // (the slab reduction has no norm share: such launches are not cut)
         if (sk > 1) { g.split_k = sk; g.workspace = w<void>(p.slab); }
         return vlt5_gemm_bf16(&g, st);
     }
@@ -424,6 +425,9 @@ struct Ctx {
 };
 
 #define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+int dec_wgrad(const Ctx& k, int which, vlt5_gemm_desc* desc, int lo = 0, int n = 0);
+bool shadow_wgrads(const Ctx& k);
 
 int attn_call(const Ctx& k, bool bwd, const bf16_t* q, long long q_sb, long long q_st, const bf16_t* kk, const bf16_t* v,
               long long kv_sb, long long kv_st, bf16_t* ctx, float* lse, const float* bias, int bq, int bk, const float* kmask,
@@ -706,14 +710,21 @@ int decoder_bwd(const Ctx& k) {
     {
         const Ctx ks = k.on_side();
         const int l1 = Ld > 1 ? 1 : 0;
-        RC(ks.wgrad_batched(p.d_dyd_f[0], p.d_dyd_f[l1], d, p.hd[0], p.hd[l1], ff, L.dec[0].wo, L.dec[l1].wo, Ld, Md, d, ff));
-        RC(ks.wgrad_batched(p.d_dh[0], p.d_dh[l1], k.ffw(), p.yn_f[0], p.yn_f[l1], d, L.dec[0].wi, L.dec[l1].wi, Ld, Md, k.ffw(), d));
-        RC(ks.wgrad_batched(p.d_dyd_c[0], p.d_dyd_c[l1], d, p.ctx_c[0], p.ctx_c[l1], inner, L.dec[0].co, L.dec[l1].co, Ld, Md, d, inner));
-        RC(ks.wgrad_batched(p.d_dq_c[0], p.d_dq_c[l1], inner, p.yn_c[0], p.yn_c[l1], d, L.dec[0].cq, L.dec[l1].cq, Ld, Md, inner, d));
-        RC(ks.wgrad_batched(p.d_dyd_s[0], p.d_dyd_s[l1], d, p.ctx_s[0], p.ctx_s[l1], inner, L.dec[0].so, L.dec[l1].so, Ld, Md, d, inner));
-        RC(ks.wgrad_batched(p.d_dqkv[0], p.d_dqkv[l1], 3 * inner, p.yn_a[0], p.yn_a[l1], d, L.dec[0].sqkv, L.dec[l1].sqkv, Ld, Md, 3 * inner, d));
-        // cross-attention K/V projections of all layers at once
-        RC(ks.lin_wgrad(k.w<bf16_t>(p.dkv_all), kvw, k.w<bf16_t>(p.enc_ext), d, k.Gr + L.cross_kv, Mx, kvw, d, 1.f, 0, true));
+        (void)l1;
+        if (shadow_wgrads(k)) {
+            // self-attention output projection on its own; q|k|v rides with the stacked cross-K/V gradient; the two FFN gradients ride
+            // with the FFN launches of the encoder's upper half, cross o / q with those of its lower half (encoder_bwd).  (Measured
+            // against it: the FFN guests cut in halves of six layers over all four FFN hosts, the 768 x 768 ones on their own -- the
+            // better balance on paper gains half as much.)
+            RC(dec_wgrad(ks, 4, nullptr));
+            vlt5_gemm_desc guest;
+            RC(dec_wgrad(ks, 5, &guest));
+            RC(ks.lin_wgrad(k.w<bf16_t>(p.dkv_all), kvw, k.w<bf16_t>(p.enc_ext), d, k.Gr + L.cross_kv, Mx, kvw, d, 1.f, 0, true, &guest));
+        } else {
+            for (int which = 0; which < 6; ++which) RC(dec_wgrad(ks, which, nullptr));
+            // cross-attention K/V projections of all layers at once
+            RC(ks.lin_wgrad(k.w<bf16_t>(p.dkv_all), kvw, k.w<bf16_t>(p.enc_ext), d, k.Gr + L.cross_kv, Mx, kvw, d, 1.f, 0, true));
+        }
         for (int b = 0; b <= Ld; ++b) RC(ks.record(b));     // decoder-side gradient buckets are complete (rel-bias: before the fork)
     }
     RC(vlt5_embed_bwd(ids, dx, (long long)T * d, d, k.Gr + L.shared, B, T, d, c.vocab, k.pdrop, k.seed(SITE_DEC_EMBED), T, 0, k.st));
@@ -729,14 +740,44 @@ inline int enc_cut(int Le) {
     const int c = env > 0 ? env : Le / 2;
     return c < 1 ? 1 : (c > Le - 1 ? Le - 1 : c);
 }
-// weight gradients of encoder layers [lo, hi): one batched GEMM per weight kind (grid.z = layer)
-int enc_wgrads(const Ctx& k, int lo, int hi) {
+// The six batched weight-gradient problems of the decoder stack (which: 0 FFN wo, 1 FFN wi, 2 cross o, 3 cross q, 4 self o, 5 self q|k|v):
+// launched (desc == nullptr) or only described (for a grouped launch)
+int dec_wgrad(const Ctx& k, int which, vlt5_gemm_desc* desc, int lo, int n) {      // layers [lo, lo + n); n <= 0: all
+    const Plan& p = k.p; const Layout& L = k.lay;
+    const int d = k.d, inner = k.inner, ff = k.ff, Md = p.Md, Ld = k.c.num_decoder_layers;
+    if (n <= 0) { lo = 0; n = Ld; }
+    const int l1 = n > 1 ? lo + 1 : lo;
+    switch (which) {
+    case 0: return k.wgrad_batched(p.d_dyd_f[lo], p.d_dyd_f[l1], d, p.hd[lo], p.hd[l1], ff, L.dec[lo].wo, L.dec[l1].wo, n, Md, d, ff, desc);
+    case 1: return k.wgrad_batched(p.d_dh[lo], p.d_dh[l1], k.ffw(), p.yn_f[lo], p.yn_f[l1], d, L.dec[lo].wi, L.dec[l1].wi, n, Md, k.ffw(), d, desc);
+    case 2: return k.wgrad_batched(p.d_dyd_c[lo], p.d_dyd_c[l1], d, p.ctx_c[lo], p.ctx_c[l1], inner, L.dec[lo].co, L.dec[l1].co, n, Md, d, inner, desc);
+    case 3: return k.wgrad_batched(p.d_dq_c[lo], p.d_dq_c[l1], inner, p.yn_c[lo], p.yn_c[l1], d, L.dec[lo].cq, L.dec[l1].cq, n, Md, inner, d, desc);
+    case 4: return k.wgrad_batched(p.d_dyd_s[lo], p.d_dyd_s[l1], d, p.ctx_s[lo], p.ctx_s[l1], inner, L.dec[lo].so, L.dec[l1].so, n, Md, d, inner, desc);
+    default: return k.wgrad_batched(p.d_dqkv[lo], p.d_dqkv[l1], 3 * inner, p.yn_a[lo], p.yn_a[l1], d, L.dec[lo].sqkv, L.dec[l1].sqkv, n, Md, 3 * inner, d, desc);
+    }
+}
+// vlt5_step.defer_decoder_wgrads: the decoder's weight gradients (400 rows: short reductions, 45-60 us per launch on their own) ride
+// in the shadow of the long 216-tile launches -- the stacked cross-K/V gradient and the encoder's FFN gradients leave 40 of the 256
+// CUs idle for their whole duration; as the second problem of those grouped launches the decoder's tiles run there.
+bool shadow_wgrads(const Ctx& k) {
+    static const bool off = getenv("VLT5_WGRAD_SHADOW") && atoi(getenv("VLT5_WGRAD_SHADOW")) == 0;
+    return !off && k.s.defer_decoder_wgrads && !k.side && k.c.num_layers > 1 && k.c.num_decoder_layers > 0;
+}
+
+// weight gradients of encoder layers [lo, hi): one batched GEMM per weight kind (grid.z = layer); guest_wo / guest_wi >= 0: that
+// decoder problem (dec_wgrad) rides along with the FFN wo / wi launch
+int enc_wgrads(const Ctx& k, int lo, int hi, int guest_wo = -1, int guest_wi = -1, int glo = 0, int gn = 0) {
     const Plan& p = k.p; const Layout& L = k.lay;
     const int n = hi - lo, d = k.d, inner = k.inner, ff = k.ff, M = p.M;
     if (n <= 0) return VLT5_OK;
     const int l1 = n > 1 ? lo + 1 : lo;
-    RC(k.wgrad_batched(p.e_dyd_f[lo], p.e_dyd_f[l1], d, p.h[lo], p.h[l1], ff, L.enc[lo].wo, L.enc[l1].wo, n, M, d, ff));
-    RC(k.wgrad_batched(p.e_dh[lo], p.e_dh[l1], k.ffw(), p.xn_f[lo], p.xn_f[l1], d, L.enc[lo].wi, L.enc[l1].wi, n, M, k.ffw(), d));
+    vlt5_gemm_desc g_wo, g_wi;
+    if (guest_wo >= 0) RC(dec_wgrad(k, guest_wo, &g_wo, glo, gn));
+    if (guest_wi >= 0) RC(dec_wgrad(k, guest_wi, &g_wi, glo, gn));
+    RC(k.wgrad_batched(p.e_dyd_f[lo], p.e_dyd_f[l1], d, p.h[lo], p.h[l1], ff, L.enc[lo].wo, L.enc[l1].wo, n, M, d, ff, nullptr,
+                       guest_wo >= 0 ? &g_wo : nullptr));
+    RC(k.wgrad_batched(p.e_dh[lo], p.e_dh[l1], k.ffw(), p.xn_f[lo], p.xn_f[l1], d, L.enc[lo].wi, L.enc[l1].wi, n, M, k.ffw(), d, nullptr,
+                       guest_wi >= 0 ? &g_wi : nullptr));
     // the two attention weight gradients share one grid: 162 + 54 tiles of 256 x 256 (six layers) fill the chip only together
     static const bool grouped = !(getenv("VLT5_WGRAD_GROUPED") && atoi(getenv("VLT5_WGRAD_GROUPED")) == 0);
     if (grouped) {
@@ -783,7 +824,7 @@ int encoder_bwd(const Ctx& k) {
             // buckets overlaps with the backward of the lower half
             RC(k.fork(1));
             const Ctx ks = k.on_side();                   // beside the lower half's chain when there is a side stream
-            RC(enc_wgrads(ks, enc_cut(Le), Le));
+            RC(enc_wgrads(ks, enc_cut(Le), Le, shadow_wgrads(k) ? 0 : -1, shadow_wgrads(k) ? 1 : -1));   // + decoder FFN wo / wi
             for (int b = Ld + 1; b <= Ld + 1 + (Le - 1 - l); ++b) RC(ks.record(b));
         }
     }
@@ -809,7 +850,7 @@ int encoder_bwd(const Ctx& k) {
     RC(k.fork(2));
     {
         const Ctx ks = k.on_side();
-        RC(enc_wgrads(ks, 0, low_end));                   // lower half of the stack (the upper half was flushed mid-way)
+        RC(enc_wgrads(ks, 0, low_end, shadow_wgrads(k) ? 2 : -1, shadow_wgrads(k) ? 3 : -1));   // lower half (+ decoder cross o / q)
         for (int b = Ld + 1 + (Le - low_end); b <= Ld + Le; ++b) RC(ks.record(b));
     }
     RC(k.join(3));                                        // every gradient is complete on the caller's stream from here on

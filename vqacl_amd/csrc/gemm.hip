@@ -57,13 +57,14 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
     const vlt5_gemm_desc* g2 = d->grouped_with;
     if (g2) {
         // the second problem of a grouped launch: same reduction, batch, operand orders and (plain f32) epilogue
-        if (!g2->A || !g2->B || !g2->C || g2->K != d->K || g2->batch != d->batch || g2->a_kmajor != d->a_kmajor || g2->b_kmajor != d->b_kmajor ||
+        if (!g2->A || !g2->B || !g2->C || g2->K <= 0 || g2->a_kmajor != d->a_kmajor || g2->b_kmajor != d->b_kmajor ||
             g2->alpha != d->alpha || !d->out_f32 || !g2->out_f32 || d->accum || g2->accum || d->split_k > 1 || g2->split_k > 1 || d->bias ||
             g2->bias || d->relu || g2->relu || d->gate || g2->gate || d->resid || g2->resid || d->drop_p > 0.f || g2->drop_p > 0.f)
             return VLT5_ERR_ARG;
         int c2 = g2->a_kmajor ? g2->M : g2->K, b2c = g2->b_kmajor ? g2->N : g2->K;
         if ((c2 & 7) || (b2c & 7) || (g2->N & 7) || (g2->lda & 7) || (g2->ldb & 7) || (g2->ldc & 3)) return VLT5_ERR_ALIGN;
-        a.gA = (const bf16_t*)g2->A; a.gB = (const bf16_t*)g2->B; a.gC = g2->C; a.gM = g2->M; a.gN = g2->N;
+        a.gA = (const bf16_t*)g2->A; a.gB = (const bf16_t*)g2->B; a.gC = g2->C; a.gM = g2->M; a.gN = g2->N; a.gK = g2->K;
+        a.grp_t2 = g2->batch > 1 ? g2->batch : 1;            // (the batch count of the second problem travels here until the tile shape is known)
         a.glda = g2->lda; a.gldb = g2->ldb; a.gldc = g2->ldc;
         a.gbatch_a = g2->batch_stride_a; a.gbatch_b = g2->batch_stride_b; a.gbatch_c = g2->batch_stride_c;
         a.gC2 = (bf16_t*)g2->c_bf16_copy; a.gsumsq = g2->sumsq; a.gsumsq_zstride = g2->sumsq_batch_stride;
@@ -78,8 +79,9 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         const int sk = (d->split_k > 1 ? d->split_k : 1) * batch;
         auto tiles = [&](int tm, int tn) {
             long t = (long)((d->M + tm - 1) / tm) * ((d->N + tn - 1) / tn);
-            if (g2) t += (long)((g2->M + tm - 1) / tm) * ((g2->N + tn - 1) / tn);
-            return t * sk;
+            t *= sk;
+            if (g2) t += (long)((g2->M + tm - 1) / tm) * ((g2->N + tn - 1) / tn) * (g2->batch > 1 ? g2->batch : 1);
+            return t;
         };
         // 256 x 256 (8 waves, one workgroup per CU): half the LDS-fill traffic per flop of 128 x 128 -- wins once its tiles
         // fill most of the 256 CUs (wide-N forward / dgrad GEMMs with row-major A); the k-major A variant does not pay (the

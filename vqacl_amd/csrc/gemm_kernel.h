@@ -62,9 +62,10 @@ struct GemmArgs {
     long long batch_a, batch_b, batch_c;          // element strides between batch entries (blockIdx.z)
     bf16_t* C2;                                   // optional bf16 copy of a plain f32 output (same indexing as C), or null
     float* sumsq; long long sumsq_zstride;        // optional: sum of squares of the tile's (plain f32) output -> sumsq[z*zstride + tile]
-    // grouped launch: workgroups [grp_tiles, gridDim.x) work on a SECOND problem with the same K, batch and (plain f32) epilogue
-    int grp_tiles;
-    const bf16_t* gA; const bf16_t* gB; void* gC; int gM, gN, glda, gldb, gldc;
+    // grouped launch (flat grid: x = every tile of every batch entry of problem 1, then those of problem 2; y = z = 1): workgroups
+    // [grp_tiles, gridDim.x) work on a SECOND problem with its own shape, reduction length and batch count, same (plain f32) epilogue
+    int grp_tiles, grp_t1, grp_t2;                // workgroups of problem 1; tiles per batch entry of problem 1 / 2
+    const bf16_t* gA; const bf16_t* gB; void* gC; int gM, gN, gK, glda, gldb, gldc;
     long long gbatch_a, gbatch_b, gbatch_c;
     bf16_t* gC2; float* gsumsq; long long gsumsq_zstride;
 #ifdef GEMM_TIMELINE
@@ -310,12 +311,18 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     // XCD-aware tile mapping: the dispatcher places workgroup b on XCD b % 8 (each XCD has a private 4 MB L2), so give
     // every XCD one contiguous run of tiles, n fastest: the tiles that share an A row-panel run on the same L2 back to
     // back, and the weight panel stays L2-resident per XCD.  Bijective for any tile count (speed only, never correctness).
-    int bid = blockIdx.x;
-    if (p.grp_tiles > 0 && bid >= p.grp_tiles) {             // (workgroup-uniform) the second problem of a grouped launch
-        bid -= p.grp_tiles;
-        p.A = p.gA; p.B = p.gB; p.C = p.gC; p.M = p.gM; p.N = p.gN; p.lda = p.glda; p.ldb = p.gldb; p.ldc = p.gldc;
-        p.batch_a = p.gbatch_a; p.batch_b = p.gbatch_b; p.batch_c = p.gbatch_c;
-        p.C2 = p.gC2; p.sumsq = p.gsumsq; p.sumsq_zstride = p.gsumsq_zstride;
+    int bid = blockIdx.x, zb = blockIdx.z;                   // tile within the batch entry, batch entry
+    if (p.grp_tiles > 0) {                                   // (workgroup-uniform) grouped launch: a flat grid over both problems
+        int tpb = p.grp_t1;
+        if (bid >= p.grp_tiles) {                            // the second problem
+            bid -= p.grp_tiles;
+            tpb = p.grp_t2;
+            p.A = p.gA; p.B = p.gB; p.C = p.gC; p.M = p.gM; p.N = p.gN; p.K = p.gK; p.lda = p.glda; p.ldb = p.gldb; p.ldc = p.gldc;
+            p.batch_a = p.gbatch_a; p.batch_b = p.gbatch_b; p.batch_c = p.gbatch_c;
+            p.C2 = p.gC2; p.sumsq = p.gsumsq; p.sumsq_zstride = p.gsumsq_zstride;
+        }
+        zb = bid / tpb;
+        bid -= zb * tpb;
     }
     const int gx = (p.N + BN - 1) / BN, gy = (p.M + BM - 1) / BM;
     const int ntiles = gx * gy;
@@ -327,11 +334,11 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     const int m0 = (tile_id / gx) * BM, n0 = (tile_id % gx) * BN;
     const int nk_total = (p.K + BK - 1) / BK;
     int kt0 = 0, kt1 = nk_total;
-    char* Cbase = reinterpret_cast<char*>(p.C) + (long long)blockIdx.z * p.batch_c * (p.out_f32 ? 4 : 2);
-    bf16_t* C2base = p.C2 ? p.C2 + (long long)blockIdx.z * p.batch_c : nullptr;
-    p.A += (long long)blockIdx.z * p.batch_a;
-    p.B += (long long)blockIdx.z * p.batch_b;
-    if (p.resid) p.resid += (long long)blockIdx.z * p.batch_c;
+    char* Cbase = reinterpret_cast<char*>(p.C) + (long long)zb * p.batch_c * (p.out_f32 ? 4 : 2);
+    bf16_t* C2base = p.C2 ? p.C2 + (long long)zb * p.batch_c : nullptr;
+    p.A += (long long)zb * p.batch_a;
+    p.B += (long long)zb * p.batch_b;
+    if (p.resid) p.resid += (long long)zb * p.batch_c;
     if (p.ktiles_per_split > 0) {
         kt0 = blockIdx.y * p.ktiles_per_split;
         kt1 = min(nk_total, kt0 + p.ktiles_per_split);
@@ -771,7 +778,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                     float t = 0.f;
 #pragma unroll
                     for (int w8 = 0; w8 < WM * WN; ++w8) t += red[w8];
-                    p.sumsq[(long long)blockIdx.z * p.sumsq_zstride + tile_id] = t;
+                    p.sumsq[(long long)zb * p.sumsq_zstride + tile_id] = t;
                 }
             }
         } else {
@@ -979,6 +986,8 @@ int launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
         r.M = a.M; r.N = a.N; r.K = a.K; r.batch = (int)grid.z; r.tile_m = BM; r.tile_n = BN; r.a_kmajor = AKM; r.b_kmajor = BKM;
         r.splits = (int)grid.y; r.workgroups = (int)(grid.x * grid.y * grid.z); r.out_f32 = a.out_f32; r.ms = 0.f;
         r.M2 = a.grp_tiles > 0 ? a.gM : 0; r.N2 = a.grp_tiles > 0 ? a.gN : 0;
+        r.K2 = a.grp_tiles > 0 ? a.gK : 0; r.batch2 = a.grp_tiles > 0 ? (int)((grid.x - a.grp_tiles) / (a.grp_t2 > 0 ? a.grp_t2 : 1)) : 0;
+        if (a.grp_tiles > 0) r.batch = a.grp_tiles / (a.grp_t1 > 0 ? a.grp_t1 : 1);
         g_timing.rec.push_back(r);
         hipExtLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, NS>), grid, dim3(WM * WN * 64), lds, st, g_timing.ev[2 * i],
                               g_timing.ev[2 * i + 1], 0, a);
@@ -993,9 +1002,12 @@ template <int BM, int BN>
 int launch_tile(const GemmArgs& a_in, int akm, int bkm, int splits, int batch, hipStream_t st) {
     GemmArgs a = a_in;
     const int t1 = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
-    int t2 = 0;
-    if (a.gA) { t2 = ((a.gN + BN - 1) / BN) * ((a.gM + BM - 1) / BM); a.grp_tiles = t1; }     // grouped launch: the second problem's tiles follow
-    dim3 grid(t1 + t2, splits > 1 ? splits : 1, batch > 1 ? batch : 1);
+    dim3 grid(t1, splits > 1 ? splits : 1, batch > 1 ? batch : 1);
+    if (a.gA) {       // grouped launch: flat grid, every tile of every batch entry of problem 1, then those of problem 2
+        const int t2 = ((a.gN + BN - 1) / BN) * ((a.gM + BM - 1) / BM), b1 = batch > 1 ? batch : 1, b2 = a.grp_t2 > 1 ? a.grp_t2 : 1;
+        a.grp_tiles = t1 * b1; a.grp_t1 = t1; a.grp_t2 = t2;
+        grid = dim3(t1 * b1 + t2 * b2, 1, 1);
+    }
     // ring depth: 3 stages up to 64x128 (72 KB, 2 workgroups/CU); 2 for 128x128 (a 3-stage ring = 96 KB = 1 workgroup/CU
     // measured 13 % slower end to end: occupancy matters more) and for 256x256 (2 x 64 KB, one 8-wave workgroup per CU)
 #ifndef GEMM_NS_SMALL

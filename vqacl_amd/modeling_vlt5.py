@@ -552,6 +552,7 @@ class VLT5(nn.Module):
                 cs.gnorm_partials = ptr(self._gnorm)
             else:
                 fused_norm = False
+        cs.defer_decoder_wgrads = int(self.dp is None)      # (single process: the decoder's short weight gradients ride with the encoder's)
         gt = g.reshape(-1).to(torch.float32).contiguous()
         if fused:
             cs.gout = ptr(gt)
