@@ -84,10 +84,10 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
             return t;
         };
         // 256 x 256 (8 waves, one workgroup per CU): half the LDS-fill traffic per flop of 128 x 128 -- wins once its tiles
-        // fill most of the 256 CUs (wide-N forward / dgrad GEMMs with row-major A); the k-major A variant does not pay (the
-        // layer-batched FFN weight gradients: 455 us against 385-410 us with 128 x 128)
-        // (also for a small output with a very long reduction cut into slices by vlt5_gemm_auto_split: the input gradients
-        // of lm_head and of the stacked cross-attention K/V projection)
+        // fill most of the 256 CUs (wide-N forward / dgrad GEMMs with row-major A; also a small output with a very long reduction
+        // cut into slices by vlt5_gemm_auto_split: the input gradients of lm_head and of the stacked cross-attention K/V projection).
+        // (Round 1 found the k-major A variant slower than 128 x 128 for the weight gradients -- 455 against 385-410 us; that was the
+        // compiler's wait in front of every transpose read, see below.)
         // Weight gradients (both operands k-major, reduction over the rows of the batch): since the LDS-DMA of the k-major kernels is
         // issued as assembly (gemm_kernel.h lds_dma16) their prefetch ring works, and the larger tiles win -- in situ, B = 80:
         // 768x3072x4480 x6 layers 168 -> 151 us and the stacked cross-K/V 18432x768x4640 170 -> 160 us with 256 x 256 (a long
