@@ -12,11 +12,11 @@
 //   dgrad    dx = dy W   : A = dy [M,N] row-major,  B = W  read k-major (k runs over W's rows)
 //   wgrad    dW = dy^T x : A = dy read k-major,     B = x  read k-major (k runs over the M rows)
 //
-// Structure: 256 threads = 4 waves in a 2x2 grid over a BM x BN tile, BK = 64 per step, two LDS
-// stages, global -> registers -> LDS staging (the load of step t+1 is issued before the MFMAs of
-// step t).  Row-major operands sit in LDS as [row][64 k] with k contiguous, 16-byte slots XOR-swizzled by
-// (row & 7) so the ds_read_b128 fragment reads are bank-conflict free; k-major operands stay [64 k][row] in LDS and are
-// gathered into fragments with the hardware transpose read ds_read_b64_tr_b16 (no register transposes).
+// Structure: 4 waves (2x2) over tiles up to 128x128, 8 waves (2x4) over the 256-wide tiles; BK = 64 per step; a ring of 2-3 LDS
+// stages filled by LDS-DMA (global_load_lds_dwordx4: as assembly in the kernels with a k-major operand, see lds_dma16) while earlier
+// tiles are computed; registers only stage a partial last k-tile.  Row-major operands sit in LDS as [row][64 k] with k contiguous,
+// 16-byte slots XOR-swizzled by (row & 7) so the ds_read_b128 fragment reads are bank-conflict free; k-major operands stay
+// [64 k][row] in LDS and are gathered into fragments with the hardware transpose read ds_read_b64_tr_b16 (no register transposes).
 // MFMA: v_mfma_f32_16x16x32_bf16 with the operands swapped (weight fragment as A, activation
 // fragment as B) so each lane ends up with 4 consecutive n of one row m -> 8/16-byte stores.
 //
