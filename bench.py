@@ -244,8 +244,11 @@ def parity_vs_oracle(model, dev, B):
         model.train(was_training)
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle (CPU restatement of the reference path) timed on the host: fwd + bwd + clip + AdamW, dropout on."""
+def cpu_baseline(budget_s=30.0):
+    """The oracle (CPU restatement of the reference path) timed on the host, SURVEY 8(d) protocol: fwd + bwd + clip + AdamW, dropout
+    on, fp32 torch-CPU ops, at the two batch sizes the survey names -- B = 4 (BASELINE configs[0], the reference's own CPU-runnable
+    case) and B = 80 (the benched configuration) -- warm-up steps first, then the MEDIAN of the timed steps.  The step counts are
+    what a bounded sample allows (the survey's 3 + 10 steps at B = 80 would be a minute of CPU work): stated in `sample`."""
     from oracle import ref_cpu as R
     try:
         usable = len(os.sched_getaffinity(0))
@@ -254,26 +257,57 @@ def cpu_baseline(seconds_budget=25.0):
     cores = max(1, min(usable, 16))           # torch intra-op threads actually used: 16 was the fastest on the 256-core box
     torch.set_num_threads(cores)
     cfg = R.Cfg(dropout=0.1)
-    Bc = 16
-    model = R.OracleModel(cfg, seed=0)
-    opt = R.HFAdamW(model.used, lr=1e-4, eps=1e-6, weight_decay=0.01)
-    batch = synthetic_batch(Bc, seed=66666)
-    times = []
-    t_start = time.time()
-    while True:                                   # a bounded sample: >= 3 steps and ~12 s of CPU work, never beyond the budget
-        t0 = time.time()
-        model.zero_grad()
-        out = model.train_step(batch, 0, 0.5, 0.3, training=True)
-        out["loss"].backward()
-        R.clip_grad_norm(list(model.used.values()), 5.0)
-        opt.step()
-        times.append(time.time() - t0)
-        spent = time.time() - t_start
-        if spent > seconds_budget or (len(times) >= 3 and spent > 12.0):
-            break
-    t = min(times[1:]) if len(times) > 1 else times[0]
-    return dict(value=round(Bc / t, 3), unit="samples/s", cores=cores, kind="port",
-                sample=f"{len(times)} train steps of batch {Bc} ({sum(times):.0f} s; L=20,V=36,T=5, dropout on, fp32 torch-CPU oracle), best of steps 2+")
+    res, t_all = {}, time.time()
+    for Bc, warm, timed in ((4, 2, 7), (80, 1, 3)):
+        model = R.OracleModel(cfg, seed=0)
+        opt = R.HFAdamW(model.used, lr=1e-4, eps=1e-6, weight_decay=0.01)
+        batch = synthetic_batch(Bc, seed=66666)
+        times = []
+        for i in range(warm + timed):
+            t0 = time.time()
+            model.zero_grad()
+            out = model.train_step(batch, 0, 0.5, 0.3, training=True)
+            out["loss"].backward()
+            R.clip_grad_norm(list(model.used.values()), 5.0)
+            opt.step()
+            if i >= warm:
+                times.append(time.time() - t0)
+            if time.time() - t_all > budget_s and len(times) >= 1:
+                break                                   # (a slow host: keep the sample bounded, report what was timed)
+        times.sort()
+        res[Bc] = (Bc / times[len(times) // 2], len(times), warm)
+        del model, opt
+    return dict(value=round(res[80][0], 3), unit="samples/s", cores=cores, kind="port", value_b4=round(res[4][0], 3),
+                sample=(f"median step of the fp32 torch-CPU oracle (L=20,V=36,T=5, dropout on, fwd+bwd+clip+AdamW): B=80 "
+                        f"{res[80][1]} timed steps after {res[80][2]} warm-up -> value; B=4 {res[4][1]} timed after {res[4][2]} warm-up -> value_b4; "
+                        f"{time.time() - t_all:.0f} s of CPU work in all"))
+
+
+def trace_roofline(gflop_per_step):
+    """`frac` recomputed from the committed rocprofv3 kernel trace of this round's build (profiles/r03*_kernel_stats_bench_b80.txt, the
+    same bench command under --kernel-trace): time of the GEMM family per optimizer step from the trace, FLOPs per step from the
+    in-situ records of this run (same launches).  The event-timed `frac` perturbs the step it measures; this one does not."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03*_kernel_stats_bench_b80.txt")))
+    if not files:
+        return None
+    steps, fam_ms = None, 0.0
+    for line in open(files[-1]):
+        m = re.match(r"# (\d+) optimizer steps in the trace", line)
+        if m:
+            steps = int(m.group(1))
+        if line.startswith("#") or line.startswith("kernel "):
+            continue
+        if any(k in line for k in ("gemm_kernel<", "qkv_attn_fwd_kernel", "skinny_kernel<", "dec_attn_fwd_kernel")):
+            f = line.split()
+            nums = [x for x in f if re.fullmatch(r"[0-9.]+", x)]
+            fam_ms += float(nums[-5])                   # columns: calls total_ms avg_us min_us max_us %
+    if not steps or fam_ms <= 0:
+        return None
+    ms = fam_ms / steps
+    return dict(frac_trace=round(gflop_per_step / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), gemm_ms_per_step_trace=round(ms, 3),
+                trace_source=f"profiles/{os.path.basename(files[-1])}")
 
 
 def eager_gpu_baseline(dev, B=80, steps=5):
@@ -431,9 +465,13 @@ def main():
         # in-situ roofline of the dominant kernel family: real steps, every GEMM dispatch timed
         out["roofline"] = insitu_gemm_roofline(lambda i: step_store(n_total + i), 8)
         import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_hbm_traffic.json")))
+        tr = trace_roofline(out["roofline"]["gflop_per_launch"] * out["roofline"]["launches_per_step"])
+        if tr:
+            out["roofline"].update(tr)
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03*_pmc_hbm_traffic.json"))) or \
+            sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_hbm_traffic.json")))
         if pmcs:          # HBM bytes per GEMM launch from the committed PMC passes of THIS round's build (tagged; not measured in this run)
-            g = [r for r in json.load(open(pmcs[-1])) if "gemm_kernel" in r["kernel"]]
+            g = [r for r in json.load(open(pmcs[-1])) if any(k in r["kernel"] for k in ("gemm_kernel", "skinny_kernel", "qkv_attn_fwd_kernel", "dec_attn_fwd_kernel"))]
             if g:
                 out["roofline"]["traffic"] = round(sum(r["calls"] * r["hbm_mb"] for r in g) / sum(r["calls"] for r in g) * 1e6)
                 out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(pmcs[-1])} (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"

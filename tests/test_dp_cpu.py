@@ -58,7 +58,23 @@ def _worker(rank, world, port, q):
 
         # reduce-scatter + all-gather of merged slices == all-reduce (algo "rs_ag" / the gradient half of "zero1"); chunks tile a slice
         dp2 = DataParallelVLT5(model, algo="rs_ag", bucket_mb=0.05)
-        assert dp2.algo == "rs_ag" and DataParallelVLT5(model).algo == "zero1", "auto picks the sharded path when world | 64"
+        dflt = DataParallelVLT5(model)
+        assert dp2.algo == "rs_ag" and dflt.algo == "zero1" and dflt.gather_master, "auto picks the sharded path when world | 8"
+        # the slice plan (and with it the chunk a rank owns under zero1) is a function of the model alone: a step that did not come
+        # out of the overlapped backward (gradient accumulation) updates the very same chunks
+        plan = dflt.slice_plan()
+        assert sorted(plan) == sorted((a, b) for lo, hi in dflt.release_ranges for a, b, _, _ in dflt.slices_of(lo, hi))
+        assert sum(b - a for a, b in plan) == dflt.bucket_end[-1] and len(set(plan)) == len(plan)
+        assert all((dflt.chunk(a, b)[1] - dflt.chunk(a, b)[0]) % 8 == 0 for a, b in plan), "chunks stay 16-byte aligned in bf16"
+        # reading parameters is local in the default mode and refuses (instead of starting a collective) with a sharded master
+        dflt.params_sharded = True
+        from vqacl_amd._lib import Vlt5Error
+        with pytest.raises(Vlt5Error):
+            model.state_dict()
+        dflt.params_sharded = False
+        assert "shared.weight" in model.state_dict()
+        for w in (3, 5, 16, 64):
+            assert 8 % w != 0           # world sizes "auto" must not shard for (chunks would lose their alignment)
         model.dp = dp
         nbk = len(dp2.bucket_end)
         sl = dp2.slices_of(0, nbk)

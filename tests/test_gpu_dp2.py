@@ -36,6 +36,8 @@ def _model(ocfg, params, dev):
 
 
 def _worker(rank, world, port, q, grad_dtype, algo="allreduce", backend="gloo"):
+    lazy = algo == "zero1-lazy"             # zero1 with gather_master=False: the f32 master stays sharded until consolidate()
+    algo = "zero1" if lazy else algo
     try:
         sys.path.insert(0, ROOT)
         import torch.distributed as dist
@@ -61,7 +63,7 @@ def _worker(rank, world, port, q, grad_dtype, algo="allreduce", backend="gloo"):
         model = _model(ocfg, wrong, dev)
         model.train()
         dp = DataParallelVLT5(model, bucket_mb=0.05,          # tiny buckets: several collectives interleaved with backward
-                              grad_dtype=getattr(torch, grad_dtype), algo=algo)
+                              grad_dtype=getattr(torch, grad_dtype), algo=algo, gather_master=not lazy)
         assert dp.algo == algo
         opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-3, eps=1e-6, max_grad_norm=5.0)
         losses, grads0 = [], None
@@ -69,17 +71,40 @@ def _worker(rank, world, port, q, grad_dtype, algo="allreduce", backend="gloo"):
         for it in range(3):
             res = dp.train_step(mine, 0, 0.5, 0.3)
             res["loss"].backward()
+            assert dp.shards_valid == (algo == "zero1")
             if it == 0:
                 torch.cuda.synchronize()
-                grads0 = model.flat_grads().clone()       # (zero1: all-gathers the reduced chunks; this step then updates unsharded)
-            else:
+                grads0 = model.flat_grads().clone()       # (zero1: all-gathers the reduced chunks -- collective; the step below is still the sharded one)
                 assert dp.shards_valid == (algo == "zero1")
             opt.step()
-            assert dp.params_sharded == (algo == "zero1" and it > 0)
+            assert dp.params_sharded == (lazy and world > 1)
             for p in model.parameters():
                 p.grad = None
             losses.append(float(res["loss"]))
+        # a fourth step with gradient accumulation over two half batches (the non-overlapped reduction path): under zero1 it must
+        # still be the sharded update -- the Adam moments of the chunks a rank does not own are stale since its first sharded step
+        for half in (slice(0, b // 2), slice(b // 2, b)):
+            part = {k: (v[half] if torch.is_tensor(v) else v) for k, v in mine.items()}
+            dp.train_step(part, 0, 0.5, 0.3)["loss"].backward()
+        opt.step()
+        for p in model.parameters():
+            p.grad = None
         torch.cuda.synchronize()
+        if lazy:
+            # the master is sharded: reading parameters must fail loudly, not start a collective behind the caller's back
+            from vqacl_amd._lib import Vlt5Error
+            for fn in (model.state_dict, model.flat_params):
+                try:
+                    fn()
+                    raise AssertionError("a sharded master must not be readable before consolidate()")
+                except Vlt5Error:
+                    pass
+            dp.consolidate()
+        elif rank == 0:
+            # the reference checkpoints on rank 0 ONLY (vqacl.py:413-414) while the other ranks walk on: state_dict() must be a
+            # local call in the default mode (a collective here would hang this test into its timeout)
+            sd = model.state_dict()
+            assert torch.isfinite(sd["decoder.block.0.layer.0.SelfAttention.q.weight"]).all()
         flat = model.flat_params().clone()
         protoQ = model.Q_prototype.clone()
 
@@ -107,6 +132,13 @@ def _worker(rank, world, port, q, grad_dtype, algo="allreduce", backend="gloo"):
                 for p in ref.parameters():
                     p.grad = None
                 rl.append(float(r["loss"]))
+            for lo in (0, b // 2):        # the accumulation step: micro-batch = the same halves of every rank's samples
+                sel = torch.cat([torch.arange(r_ * b + lo, r_ * b + lo + b // 2) for r_ in range(world)])
+                part = {k: (v[sel] if torch.is_tensor(v) else v) for k, v in full.items()}
+                ref.train_step(part, 0, 0.5, 0.3)["loss"].backward()
+            ropt.step()
+            for p in ref.parameters():
+                p.grad = None
             torch.cuda.synchronize()
 
             def cosine(a, c):
@@ -114,7 +146,7 @@ def _worker(rank, world, port, q, grad_dtype, algo="allreduce", backend="gloo"):
             assert cosine(grads0, rg0) > 0.9995, cosine(grads0, rg0)                  # mean of rank gradients == full-batch gradient
             assert abs(float(grads0.norm() / rg0.norm()) - 1.0) < 1e-2
             assert cosine(flat, ref.flat_params()) > 0.999999
-            assert float((flat - ref.flat_params()).abs().max()) < 5e-3               # lr 1e-3 x 3 steps bounds any difference
+            assert float((flat - ref.flat_params()).abs().max()) < 7e-3               # lr 1e-3 x 4 steps bounds any difference
             assert torch.allclose(protoQ, ref.Q_prototype, atol=2e-2), float((protoQ - ref.Q_prototype).abs().max())
             # the rank-local loss is the mean over b, the reference's over N*b: rank 0's differs, the mean over ranks matches
         lt = torch.tensor(losses, device=dev)
@@ -150,7 +182,7 @@ def _run_two(grad_dtype, algo, backend):
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("grad_dtype,algo", [("float32", "allreduce"), ("bfloat16", "allreduce"), ("float32", "rs_ag"),
-                                             ("bfloat16", "zero1")])
+                                             ("bfloat16", "zero1"), ("float32", "zero1"), ("bfloat16", "zero1-lazy")])
 def test_two_ranks_on_one_gpu_equal_one_process_on_the_concatenated_batch(grad_dtype, algo):
     assert torch.cuda.is_available()
     _run_two(grad_dtype, algo, "gloo")

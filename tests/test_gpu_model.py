@@ -4,7 +4,7 @@ the CPU oracle and the committed golden fixture, through the drop-in boundary th
 Tolerances (bf16 compute with fp32 accumulation against an fp32 oracle):
   logits ....... max |err| <= 3e-2 * max |logits|  (BASELINE north_star: "answer-token logits within stated fp tol")
   loss ......... 2e-2 absolute
-  gradients .... cosine similarity >= 0.98 per tensor and norm ratio within 10 %
+  gradients .... cosine similarity >= 0.99 per tensor and norm ratio within 3 % (measured worst cases: profiles/rNN_parity.txt)
   integer prototype indices: bit-exact whenever the oracle's top-2 cosine margin exceeds 1e-2
 """
 import copy
@@ -121,7 +121,7 @@ def check_greedy_tokens(tok, ref_tok, margins, tol, eos=1, pad=0, what=""):
     return checked, cut
 
 
-def check_grads(model, oracle_grads, min_cos=0.98, skip=()):
+def check_grads(model, oracle_grads, min_cos=0.99, skip=(), norm_tol=0.03):
     worst = (1.0, None)
     for k, g in oracle_grads.items():
         if k in skip or g is None:
@@ -138,7 +138,7 @@ def check_grads(model, oracle_grads, min_cos=0.98, skip=()):
         if c < worst[0]:
             worst = (c, k)
         assert c >= min_cos, f"gradient of {k}: cosine {c:.4f}"
-        assert 0.9 < ratio < 1.1, f"gradient of {k}: norm ratio {ratio:.3f}"
+        assert 1 - norm_tol < ratio < 1 + norm_tol, f"gradient of {k}: norm ratio {ratio:.3f}"
     return worst
 
 
@@ -222,7 +222,7 @@ def test_base_model_forward_backward_vs_oracle(dev):
     assert e < 3e-2
     assert abs(float(res["loss"]) - float(o["loss"])) < 2e-2
     assert rel_max_err(res["encoder_hidden_states"], o["encoder_hidden_states"]) < 3e-2
-    worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()}, min_cos=0.97)
+    worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()})
     parity_log(f"base B=4: logits rel max err {e:.4g}, loss err {abs(float(res['loss']) - float(o['loss'])):.3g}, "
                f"worst gradient cosine {worst[0]:.5f} ({worst[1]})")
     assert check_proto_indices(model, oracle, o, "base B=4") > 0
@@ -252,7 +252,7 @@ def test_gated_gelu_model_vs_oracle(dev):
     logits = model._ws_view(model.cfg.c_struct(), (B, 13, 36, T), 2, torch.float32, (B, T, ocfg.vocab_size))
     e = rel_max_err(logits, o["logits"])
     assert e < 3e-2 and abs(float(res["loss"]) - float(o["loss"])) < 2e-2
-    worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()}, min_cos=0.97)
+    worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()})
     parity_log(f"gated-gelu tiny: logits rel max err {e:.4g}, loss err {abs(float(res['loss']) - float(o['loss'])):.3g}, "
                f"worst gradient cosine {worst[0]:.5f} ({worst[1]})")
     # dropout on: seeded, finite, and the step runs through the fused optimizer
@@ -744,7 +744,7 @@ def test_other_baseline_configs_vs_oracle(dev, name, kw, B, L, V, T):
     print(name, "logits rel max err", e, "loss", float(res["loss"]), float(o["loss"]))
     assert e < 4e-2
     assert abs(float(res["loss"]) - float(o["loss"])) < 3e-2
-    worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()}, min_cos=0.95)
+    worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()})
     parity_log(f"{name}: logits rel max err {e:.4g}, loss err {abs(float(res['loss']) - float(o['loss'])):.3g}, "
                f"worst gradient cosine {worst[0]:.5f} ({worst[1]})")
     check_proto_indices(model, oracle, o, name)
@@ -796,6 +796,155 @@ def test_loss_curve_tracks_oracle_over_a_dual_level_schedule(dev):
         assert fro < 8e-2, fro
 
 
+def test_base_model_trajectory_tracks_oracle_over_20_optimizer_steps(dev):
+    """VL-T5-base at B = 4 (BASELINE configs[0] shape), 20 optimizer steps of the Trainer's inner loop (vqacl.py:364-373, 461-487):
+    current-task batch and rehearsal batch alternating, clip_grad_norm_(5) + HF AdamW (FusedAdamW against the oracle's
+    restatement), dropout off.  The engine's loss curve and prototype state must track the fp32 CPU oracle's at real dimensions
+    -- the in-repo proxy for the north star's accuracy target (no dataset to measure accuracy itself on)."""
+    from oracle import ref_cpu as R
+    from vqacl_amd import FusedAdamW, reference_param_groups
+    torch.set_num_threads(16)
+    ocfg = R.Cfg(dropout=0.0)
+    params = R.init_params(ocfg, seed=77)
+    oracle = R.OracleModel(ocfg, params)
+    model = make_model(ocfg, params, dev)
+    model.train()
+    cur0 = R.synthetic_batch(ocfg, B=4, L=20, V=36, T=5, seed=299, task_id=0)
+    cur = R.synthetic_batch(ocfg, B=4, L=20, V=36, T=5, seed=300, task_id=1)
+    mem = R.synthetic_batch(ocfg, B=4, L=17, V=36, T=4, seed=301, task_id=0)
+    oopt = R.HFAdamW(oracle.used, lr=1e-4, eps=1e-6, weight_decay=0.01)
+    opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-4, eps=1e-6, max_grad_norm=5.0)
+    ref, got = [], []
+    for it in range(20):
+        # task 0 for four steps (it opens the prototype state), then task 1: its batch and a rehearsal batch of task 0 alternating
+        batch, task = (cur0, 0) if it < 4 else ((cur, 1) if it % 2 == 0 else (mem, 1))
+        oracle.zero_grad()
+        o = oracle.train_step(batch, task, 0.5, 0.3)
+        o["loss"].backward()
+        R.clip_grad_norm(list(oracle.used.values()), 5.0)
+        oopt.step()
+        ref.append(float(o["loss"]))
+        res = model.train_step(batch, task, 0.5, 0.3)
+        res["loss"].backward()
+        opt.step()
+        for p in model.parameters():
+            p.grad = None
+        got.append(float(res["loss"].detach()))
+    print("oracle", [round(x, 3) for x in ref])
+    print("engine", [round(x, 3) for x in got])
+    worst = max(abs(a - b) for a, b in zip(got, ref))
+    assert worst < 5e-2, (got, ref)
+    assert got[3] < got[0] and got[-2] < got[4] and got[-1] < got[5], "every batch is being fitted"
+    drift = {}
+    for tag, mine, ref_p in (("Q", model.Q_prototype, oracle.state.Q_prototype), ("V", model.V_prototype, oracle.state.V_prototype)):
+        used = ref_p.abs().sum(1) > 0
+        drift[tag] = float((mine.cpu()[used] - ref_p[used]).norm() / ref_p[used].norm())
+        assert drift[tag] < 8e-2, (tag, drift[tag])       # (same bound as the tiny-model curve: the prototypes are EMAs of bf16-accurate encoder outputs)
+    # the weights themselves after 20 steps: a matrix from each stack and the tied table
+    ucos = {}
+    for k in ("encoder.block.5.layer.1.DenseReluDense.wi.weight", "decoder.block.11.layer.1.EncDecAttention.q.weight", "shared.weight"):
+        w = dict(model.named_parameters())[k].detach().float().cpu()
+        # the UPDATE (20 lr-sized Adam steps), not the weight: direction and size (element-wise an Adam step flips with the sign of a
+        # near-zero gradient, so no element-wise bound)
+        upd, ref_upd = w - params[k], oracle.P[k].detach() - params[k]
+        ucos[k] = cos(upd, ref_upd)
+        assert ucos[k] > 0.97 and abs(float(upd.norm() / ref_upd.norm()) - 1) < 0.03, (k, ucos[k])
+    parity_log(f"base B=4 trajectory (20 optimizer steps, current + rehearsal batch): max |loss - oracle| {worst:.4f}, "
+               f"prototype drift Q {drift['Q']:.4f} V {drift['V']:.4f}, weight-update cosine min {min(ucos.values()):.4f}")
+
+
+def test_benched_shape_b80_against_the_oracle(dev):
+    """BASELINE configs[1] launch shapes (VL-T5-base, B = 80, L = 20, V = 36, T = 5 -- what bench.py times): forward of the whole
+    batch on the engine, 4 of the 80 samples against the fp32 CPU oracle (the path is per-sample independent bit for bit:
+    test_full_size_batch_properties), margin-gated prototype indices of those samples, and the gradients of a B = 4 step of
+    the same weights.  A parity regression at the benched shape turns this test red, not only the bench line's `parity` field."""
+    from oracle import ref_cpu as R
+    torch.set_num_threads(16)
+    ocfg = R.Cfg(dropout=0.0)
+    params = R.init_params(ocfg, seed=4242)
+    model = make_model(ocfg, params, dev)
+    model.train()
+    B = 80
+    batch = R.synthetic_batch(ocfg, B=B, L=20, V=36, T=5, seed=424242, task_id=0)
+    pick = [0, 1, B // 2, B - 1]
+    sub = {k: v[pick] for k, v in batch.items()}
+    g = torch.Generator().manual_seed(9)
+    model.Q_prototype = torch.randn(ocfg.n_ques, ocfg.d_model, generator=g)
+    model.V_prototype = torch.randn(ocfg.n_cate, ocfg.d_model, generator=g)
+    out = model(input_ids=batch["input_ids"], vis_inputs=(batch["vis_feats"], batch["boxes"]), labels=batch["target_ids"], proto_update=False)
+    logits = out["logits"][pick].float().cpu()
+    loss_tok = out["loss"].detach().view(B, -1)[pick].float().cpu()
+    idx = (out["max_idx_Q"].cpu()[pick], out["max_idx_V"].cpu()[pick])
+    oracle = R.OracleModel(ocfg, params)
+    g = torch.Generator().manual_seed(9)
+    Qp, Vp = torch.randn(ocfg.n_ques, ocfg.d_model, generator=g), torch.randn(ocfg.n_cate, ocfg.d_model, generator=g)
+    oracle.state.Q_prototype, oracle.state.V_prototype = Qp.clone(), Vp.clone()      # (retrieval only: both sides see the same prototypes)
+    o = R.vlt5_forward(oracle.P, oracle.state, ocfg, input_ids=sub["input_ids"], vis_feats=sub["vis_feats"], boxes=sub["boxes"],
+                       labels=sub["target_ids"], proto_update=False, training=False)
+    e = rel_max_err(logits, o["logits"].detach())
+    le = float((loss_tok.flatten() - o["loss"].detach()).abs().max())
+    assert e < 3e-2 and le < 3e-2, (e, le)
+    assert rel_max_err(out["encoder_hidden_states"][pick], o["encoder_hidden_states"].detach()) < 3e-2
+    h = o["encoder_hidden_states"].detach()
+    gated = exact = 0
+    for protos, pooled, mine, ref in ((oracle.state.Q_prototype, h[:, :20].mean(1), idx[0], o["max_idx_Q"]),
+                                      (oracle.state.V_prototype, h[:, 20:].mean(1), idx[1], o["max_idx_V"])):
+        ok = margin_ok(protos, pooled)
+        gated += int(ok.sum())
+        exact += int((mine[ok] == ref[ok]).sum())
+    assert exact == gated
+    res = model(input_ids=sub["input_ids"], vis_inputs=(sub["vis_feats"], sub["boxes"]), labels=sub["target_ids"], proto_update=False,
+                scores=sub["scores"])
+    res["loss_reduced"].backward()
+    lo = R.train_step_loss(o["loss"], sub["target_ids"], sub["scores"])
+    lo.backward()
+    assert abs(float(res["loss_reduced"]) - float(lo)) < 2e-2
+    worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()})
+    parity_log(f"base B=80 (benched shape, samples {pick}): logits rel max err {e:.4g}, per-token loss err {le:.3g}, prototype indices "
+               f"{exact} of {gated} margin-gated equal; B=4 gradients worst cosine {worst[0]:.5f} ({worst[1]})")
+
+
+def test_full_size_large_model_properties(dev):
+    """BASELINE configs[4] size (VL-T5-large: d = 1024, 16 heads, d_ff = 4096, 24 + 24 layers; B = 32 per GPU), where one oracle step
+    takes minutes: the size-independent properties of test_full_size_batch_properties at the large model's launch shapes --
+    determinism, per-sample independence under a batch permutation (bit for bit), linearity of the backward in the upstream
+    gradient (exact for a power of two), run-to-run identical gradients, finite values everywhere."""
+    from oracle import ref_cpu as R
+    from vqacl_amd import VLT5VQA, VLT5Config
+    torch.manual_seed(5)
+    model = VLT5VQA(VLT5Config(d_model=1024, num_heads=16, d_ff=4096, num_layers=24, num_decoder_layers=24, dropout_rate=0.0), device=dev)
+    model.train()
+    B = 32
+    batch = {k: v.to(dev) for k, v in R.synthetic_batch(R.Cfg(), B=B, L=20, V=36, T=5, seed=777, task_id=0).items()}
+
+    def fwd(idx):
+        out = model(input_ids=batch["input_ids"][idx], vis_inputs=(batch["vis_feats"][idx], batch["boxes"][idx]),
+                    labels=batch["target_ids"][idx], proto_update=False)
+        return out["encoder_hidden_states"].clone(), out["logits"].clone(), out["loss"].detach().clone().view(len(idx), -1), out
+
+    ident = torch.arange(B, device=dev)
+    e0, l0, t0, _ = fwd(ident)
+    e1, l1, t1, _ = fwd(ident)
+    assert torch.equal(e0, e1) and torch.equal(l0, l1) and torch.equal(t0, t1)
+    assert torch.isfinite(e0).all() and torch.isfinite(l0).all() and torch.isfinite(t0).all()
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(2)).to(dev)
+    e2, l2, t2, _ = fwd(perm)
+    assert torch.equal(e2, e0[perm]) and torch.equal(l2, l0[perm]) and torch.equal(t2, t0[perm])
+    grads = []
+    for scale in (1.0, 2.0, 2.0):
+        for p in model.parameters():
+            p.grad = None
+        (fwd(ident)[3]["loss"].sum() * scale).backward()
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert len(grads[0]) > 500
+    for n in grads[0]:
+        assert torch.isfinite(grads[0][n]).all(), n
+        assert torch.equal(grads[1][n], 2 * grads[0][n]), n
+        assert torch.equal(grads[2][n], grads[1][n]), n
+    del model, grads
+    torch.cuda.empty_cache()
+
+
 def test_full_size_batch_properties(dev):
     """BASELINE configs[1] size (VL-T5-base, B=80, L=20, V=36, T=5), where the CPU oracle is too slow: size-independent
     properties of the path.  (a) determinism of the forward; (b) per-sample independence: permuting the batch permutes encoder
@@ -839,11 +988,15 @@ def test_full_size_batch_properties(dev):
         (out["loss"].sum() * scale).backward()
         grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
     assert set(grads[0]) == set(grads[1]) and len(grads[0]) > 250
-    for n in grads[0]:
-        if "shared" in n or "embed_tokens" in n or "lm_head" in n:        # token-embedding scatter: f32 atomics, order-dependent
-            assert torch.allclose(grads[1][n], 2 * grads[0][n], rtol=1e-4, atol=1e-7), n
-        else:
-            assert torch.equal(grads[1][n], 2 * grads[0][n]), n
+    for n in grads[0]:            # (the token-embedding scatter included: it sums in a fixed order since round 3, no atomics)
+        assert torch.equal(grads[1][n], 2 * grads[0][n]), n
+    # run-to-run determinism of the whole backward, the three-way tied table first
+    for p in model.parameters():
+        p.grad = None
+    (fwd(ident)[3]["loss"].sum() * 2.0).backward()
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, grads[1][n]), f"{n}: backward is not bit-reproducible"
 
 
 def test_data_parallel_bucket_math_on_deep_stack(dev):
@@ -931,7 +1084,7 @@ def test_extreme_batch_shapes_vs_oracle(dev, B, L, V, T):
     res["loss"].backward()
     assert abs(float(res["loss"].detach()) - float(o["loss"].detach())) < 2e-2
     assert rel_max_err(res["encoder_hidden_states"], o["encoder_hidden_states"]) < 3e-2
-    check_grads(model, {k: p.grad for k, p in oracle.P.items()}, min_cos=0.97)
+    check_grads(model, {k: p.grad for k, p in oracle.P.items()})
 
 
 def test_out_of_range_shapes_fail_loudly(dev):
@@ -966,4 +1119,4 @@ def test_degenerate_rows_vs_oracle(dev):
     res = model.train_step(batch, 0, 0.5, 0.3)
     res["loss"].backward()
     assert torch.isfinite(o["loss"].detach()) and abs(float(res["loss"].detach()) - float(o["loss"].detach())) < 2e-2
-    check_grads(model, {k: p.grad for k, p in oracle.P.items()}, min_cos=0.97)
+    check_grads(model, {k: p.grad for k, p in oracle.P.items()})

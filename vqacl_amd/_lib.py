@@ -49,6 +49,12 @@ class EncAttnGrads(C.Structure):
     _fields_ = [("dy", vp), ("dx", vp), ("d_wqkv", vp), ("d_wo", vp), ("d_ln_w", vp), ("d_scores", vp)]
 
 
+class SkinnyDesc(C.Structure):
+    _fields_ = [("A", vp), ("lda", c_i), ("ln_x", vp), ("ldx", c_i), ("ln_w", vp), ("eps", c_f), ("rstd_out", vp), ("xn_out_bf16", vp),
+                ("W", vp), ("ldw", c_i), ("C", vp), ("ldc", c_i), ("out_f32", c_i), ("M", c_i), ("N", c_i), ("K", c_i), ("alpha", c_f),
+                ("relu", c_i), ("drop_p", c_f), ("drop_seed", c_u32), ("resid", vp), ("ldr", c_i), ("panel_rows", c_i), ("chunk_cols", c_i)]
+
+
 class GemmTimingRec(C.Structure):
     _fields_ = [("M", c_i), ("N", c_i), ("K", c_i), ("batch", c_i), ("tile_m", c_i), ("tile_n", c_i), ("a_kmajor", c_i),
                 ("b_kmajor", c_i), ("splits", c_i), ("workgroups", c_i), ("out_f32", c_i), ("ms", c_f), ("M2", c_i), ("N2", c_i), ("K2", c_i), ("batch2", c_i)]
@@ -78,6 +84,8 @@ PROTOTYPES = {
     "vlt5_gemm_bf16": (c_i, [C.POINTER(GemmDesc), vp]),
     "vlt5_gemm_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
     "vlt5_gemm_auto_split": (c_i, [c_i, c_i, c_i, c_ll]),
+    "vlt5_skinny_gemm": (c_i, [C.POINTER(SkinnyDesc), vp]),
+    "vlt5_skinny_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "vlt5_gemm_timing_enable": (c_i, [c_i]),
     "vlt5_gemm_timing_collect": (c_i, [C.POINTER(GemmTimingRec), c_i]),
     "vlt5_layernorm_fwd": (c_i, [vp, vp, vp, vp, vp, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),

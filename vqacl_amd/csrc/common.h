@@ -107,5 +107,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Kernels with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, per kernel AND per device.  `done` is
+// the caller's per-kernel mask of device ordinals that already have it (one relaxed load on the hot path); safe from several host
+// threads and after hipSetDevice: nothing about the launch path is tied to the first caller.
+#include <atomic>
+static inline int vlt5_lds_optin(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return VLT5_ERR_ARG;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return VLT5_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done.fetch_or(bit, std::memory_order_release);
+    return VLT5_OK;
+}
+
 #define HIP_RET(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return (int)e__; } while (0)
 #define LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

@@ -29,23 +29,67 @@ __global__ void embed_fwd_kernel(const long long* __restrict__ ids, const float*
     }
 }
 
-__global__ void embed_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dout, long long sb, long long st,
-                                 float* __restrict__ dtable, int B, int T, int d, int vocab, uint32_t thr, uint32_t seed,
-                                 int drop_rows, int drop_row0) {
-    const int row = blockIdx.x;
-    const int b = row / T, t = row % T;
-    long long id = ids[row];
-    if (id < 0 || id >= vocab) id = 0;
-    const float* src = dout + b * sb + t * st;
-    float* dst = dtable + (size_t)id * d;
+// Scatter-add of the token-embedding gradients, DETERMINISTIC: the table row of an id that occurs several times in the batch (the
+// pad id: hundreds of rows) receives its contributions in a fixed order instead of in the order atomics happen to arrive.
+// One workgroup per (token row, 256-column chunk); it acts only if its row is the FIRST occurrence of its id in `ids`.  It then
+// lists every occurrence (blocked scan of the id list + prefix sum, so the list is in row order), wave w sums occurrences
+// w, w+4, w+8, ... in list order, the four partial sums are combined in wave order and the total is added to the table row with
+// plain stores -- no other workgroup of the launch touches that row.  n = B*T <= EMB_MAXN rows (the list: n ints of dynamic LDS).
+constexpr int EMB_MAXN = 12288;
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dout, long long sb, long long st,
+                                                        float* __restrict__ dtable, int B, int T, int d, int vocab, uint32_t thr, uint32_t seed,
+                                                        int drop_rows, int drop_row0) {
+    extern __shared__ int list[];
+    __shared__ int wtot[4];
+    __shared__ float4 part[4][64];
+    const int n = B * T, row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto clamp_id = [&](long long v) { return (v < 0 || v >= vocab) ? 0ll : v; };
+    const long long id = clamp_id(ids[row]);
+    const int per = (n + 255) / 256, j0 = tid * per, j1 = min(n, j0 + per);
+    int cnt = 0, earlier = 0;
+    for (int j = j0; j < j1; ++j) {
+        const bool m = clamp_id(ids[j]) == id;
+        cnt += m ? 1 : 0;
+        earlier |= (m && j < row) ? 1 : 0;
+    }
+    if (__syncthreads_or(earlier)) return;               // another row owns this id
+    int incl = cnt;                                       // inclusive prefix over the lanes of a wave, then over the waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int off = incl - cnt;
+    for (int w = 0; w < wave; ++w) off += wtot[w];
+    const int total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    for (int j = j0; j < j1; ++j)
+        if (clamp_id(ids[j]) == id) list[off++] = j;
+    __syncthreads();
+    const int c = blockIdx.y * 256 + lane * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const float dsc = drop_scale(thr);
-    for (int c = threadIdx.x; c < d; c += blockDim.x) {
-        float g = src[c];
-        if (thr) {
-            uint32_t idx = (uint32_t)(((size_t)b * drop_rows + drop_row0 + t) * d + c);
-            g = drop_keep(seed, idx, thr) ? g * dsc : 0.f;
+    if (c < d) {
+        for (int k = wave; k < total; k += 4) {
+            const int j = list[k], b = j / T, t = j - b * T;
+            float4 g = *reinterpret_cast<const float4*>(dout + b * sb + t * st + c);
+            if (thr) {
+                bool kp[4];
+                drop_keep4(seed, (uint32_t)(((size_t)b * drop_rows + drop_row0 + t) * d + c), thr, kp);
+                g.x = kp[0] ? g.x * dsc : 0.f; g.y = kp[1] ? g.y * dsc : 0.f; g.z = kp[2] ? g.z * dsc : 0.f; g.w = kp[3] ? g.w * dsc : 0.f;
+            }
+            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
         }
-        atomicAdd(dst + c, g);
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < d) {
+        float* dst = dtable + (size_t)id * d + c;
+        float4 o = *reinterpret_cast<const float4*>(dst);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { o.x += part[w][lane].x; o.y += part[w][lane].y; o.z += part[w][lane].z; o.w += part[w][lane].w; }
+        *reinterpret_cast<float4*>(dst) = o;
     }
 }
 
@@ -296,8 +340,9 @@ extern "C" int vlt5_embed_fwd(const long long* ids, const float* table, float* o
 }
 extern "C" int vlt5_embed_bwd(const long long* ids, const float* dout, long long sb, long long st, float* dtable, int B, int T,
                               int d, int vocab, float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* stream) {
-    if (!ids || !dout || !dtable || B <= 0 || T <= 0) return VLT5_ERR_ARG;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * T), dim3(256), 0, ST, ids, dout, sb, st, dtable, B, T, d, vocab,
+    if (!ids || !dout || !dtable || B <= 0 || T <= 0 || (long long)B * T > EMB_MAXN) return VLT5_ERR_ARG;
+    if ((d & 3) || (sb & 3) || (st & 3)) return VLT5_ERR_ALIGN;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * T, (d + 255) / 256), dim3(256), (size_t)B * T * sizeof(int), ST, ids, dout, sb, st, dtable, B, T, d, vocab,
                        thr_of(drop_p), drop_seed, drop_rows, drop_row0);
     LAUNCH_CHECK();
     return VLT5_OK;

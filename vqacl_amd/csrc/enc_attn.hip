@@ -268,11 +268,12 @@ extern "C" int vlt5_qkv_attn_fwd(const void* xn_bf16, const void* wqkv_bf16, voi
     t.drop_thr = core->drop_p > 0.f ? drop_thr16(core->drop_p) : 0u; t.drop_seed = core->drop_seed;
     t.d_ctx = nullptr; t.do_sb = t.do_st = 0; t.dq = t.dk_ = t.dv = nullptr;
     t.dq_sb = t.dq_st = t.dk_sb = t.dk_st = t.dv_sb = t.dv_st = 0; t.dbias = nullptr;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS));
-        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS));
-        attr_set = true;
+    static std::atomic<unsigned long long> optin_a{0}, optin_b{0};      // devices on which the kernels may use FUSED_LDS bytes of LDS
+    {
+        int rc = vlt5_lds_optin(reinterpret_cast<const void*>(&qkv_attn_fwd_kernel<false>), FUSED_LDS, optin_a);
+        if (rc) return rc;
+        rc = vlt5_lds_optin(reinterpret_cast<const void*>(&qkv_attn_fwd_kernel<true>), FUSED_LDS, optin_b);
+        if (rc) return rc;
     }
     const int grid = ((a.B + 1) / 2) * (a.H / 2);
     vlt5gemm::TimingState& tm = vlt5_gemm_timing_state;           // bench.py's in-situ roofline covers this MFMA kernel too

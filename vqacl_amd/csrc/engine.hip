@@ -761,7 +761,9 @@ int dec_wgrad(const Ctx& k, int which, vlt5_gemm_desc* desc, int lo, int n) {   
 // CUs idle for their whole duration; as the second problem of those grouped launches the decoder's tiles run there.
 bool shadow_wgrads(const Ctx& k) {
     static const bool off = getenv("VLT5_WGRAD_SHADOW") && atoi(getenv("VLT5_WGRAD_SHADOW")) == 0;
-    return !off && k.s.defer_decoder_wgrads && !k.side && k.c.num_layers > 1 && k.c.num_decoder_layers > 0;
+    // (never with gradient-bucket events: the decoder buckets would be signalled at the end of vlt5_decoder_bwd although five of
+    // their six weight gradients are only written inside vlt5_encoder_bwd)
+    return !off && k.s.defer_decoder_wgrads && !k.side && !(k.s.events && k.s.n_events > 0) && k.c.num_layers > 1 && k.c.num_decoder_layers > 0;
 }
 
 // weight gradients of encoder layers [lo, hi): one batched GEMM per weight kind (grid.z = layer); guest_wo / guest_wi >= 0: that

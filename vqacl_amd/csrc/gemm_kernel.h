@@ -971,12 +971,8 @@ template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
 int launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
     constexpr int NT_ = WM * WN * 64;
     constexpr size_t lds = (size_t)NS * ((BM * 8 + NT_ - 1) / NT_ + (BN * 8 + NT_ - 1) / NT_) * NT_ * 16;
-    static bool attr_set = false;                           // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
-    if (!attr_set) {
-        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WM, WN, AKM, BKM, NS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> optin{0};        // > 64 KB of dynamic LDS needs an explicit opt-in, per kernel and device
+    if (int rc = vlt5_lds_optin(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WM, WN, AKM, BKM, NS>), (int)lds, optin)) return rc;
 #ifdef GEMM_TIMELINE
     const_cast<GemmArgs&>(a).timeline = vlt5_gemm_timeline_buf;
 #endif

@@ -192,11 +192,8 @@ extern "C" int vlt5_proto_pool(const float* hidden, long long sb, int B, int S, 
                                void* stream) {
     if (!hidden || !poolQ || !poolV || B <= 0 || S <= 0 || d <= 0 || split <= 0) return VLT5_ERR_ARG;
     if ((d & 3) || d > 2048 || (sb & 3)) return VLT5_ERR_ALIGN;
-    static bool attr_set = false;                           // 16*d floats of dynamic LDS: above 64 KB for d > 1024
-    if (!attr_set) {
-        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 4));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> optin{0};        // 16*d floats of dynamic LDS: above 64 KB for d > 1024
+    if (int rc = vlt5_lds_optin(reinterpret_cast<const void*>(&pool_kernel), 16 * 2048 * 4, optin)) return rc;
     hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(512), 16 * (size_t)d * sizeof(float), ST, hidden, sb, B, S, d, split, poolQ, poolV);
     LAUNCH_CHECK();
     return VLT5_OK;

@@ -344,14 +344,23 @@ class VLT5(nn.Module):
         self.proto.V_prototype.copy_(v.to(self.proto.V_prototype.device))
 
     # ------------------------------------------------------------------ engine plumbing ---------------
-    def flat_params(self):
+    def _require_whole_master(self, what):
+        """ZeRO-1 data parallel with gather_master=False: the f32 master of the layer buckets is only current on the owning rank.
+        Reading parameters then needs the collective `dp.consolidate()` first -- a silent collective here would hang the
+        reference's rank-0-only checkpoint (vqacl.py:413-414), so this raises instead."""
         if self.dp is not None and getattr(self.dp, "params_sharded", False):
-            self.dp.materialize_params(self)     # ZeRO-1 data parallel: collective, every rank must call it
+            raise L.Vlt5Error(f"{what}: the f32 master weights are sharded over the data-parallel ranks "
+                              "(DataParallelVLT5(algo='zero1', gather_master=False)); call dp.consolidate() on EVERY rank first, "
+                              "or keep the default gather_master=True")
+
+    def flat_params(self):
+        self.sync_optimizer()
+        self._require_whole_master("flat_params()")
         return self._flat
 
     def flat_grads(self):
-        if self.dp is not None and getattr(self.dp, "g16_valid", False):
-            self.dp.materialize_grads(self)      # data parallel, deferred cast-back: the averaged gradients are still bf16
+        if self.dp is not None and (getattr(self.dp, "g16_valid", False) or getattr(self.dp, "shards_valid", False)):
+            self.dp.materialize_grads(self)      # data parallel: the averaged gradients are still bf16 / only this rank's chunks are reduced (collective under zero1)
         return self._flat_grad
 
     def flat_bf16(self):
@@ -438,11 +447,14 @@ class VLT5(nn.Module):
             cur = torch.cuda.current_stream()
             for e in self._opt_events:
                 cur.wait_event(e)
+        ready = getattr(self.dp, "master_ready", None) if self.dp is not None else None
+        if ready is not None:           # ZeRO-1 data parallel: the f32 master chunks of the other ranks are (still) arriving
+            torch.cuda.current_stream().wait_event(ready)
 
     def state_dict(self, *a, **k):
+        """Local on every rank, under every data-parallel mode (the reference saves on rank 0 only: trainer_base.py:246-249)."""
         self.sync_optimizer()
-        if self.dp is not None and getattr(self.dp, "params_sharded", False):
-            self.dp.materialize_params(self)     # ZeRO-1 data parallel: collective, every rank must call it
+        self._require_whole_master("state_dict()")
         return super().state_dict(*a, **k)
 
     # ------------------------------------------------------------------ forward ----------------------
@@ -534,8 +546,8 @@ class VLT5(nn.Module):
         if direct:
             target = self._flat_grad
         else:
-            if self.dp is not None and getattr(self.dp, "g16_valid", False):
-                self.dp.materialize_grads(self)  # accumulate onto the averaged gradients of the previous backward, not the local ones
+            if self.dp is not None and (getattr(self.dp, "g16_valid", False) or getattr(self.dp, "shards_valid", False)):
+                self.dp.materialize_grads(self)  # accumulate onto the averaged gradients of the previous backward, not the local / partly reduced ones
             if self._flat_grad_tmp is None:
                 self._flat_grad_tmp = torch.zeros_like(self._flat_grad)
             target = self._flat_grad_tmp

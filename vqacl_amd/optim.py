@@ -130,7 +130,11 @@ class FusedAdamW(torch.optim.Optimizer):
                     model._gviews[name].copy_(p.grad)
         self._t += 1
         dp = getattr(model, "dp", None)
-        if dp is not None and dp.shards_valid and dp.sharded_optimizer and grad.data_ptr() == model._flat_grad.data_ptr():
+        if dp is not None and dp.sharded_optimizer:
+            # ZeRO-1: EVERY step is the sharded one -- the Adam moments (and, with gather_master=False, the f32 master) of the chunks
+            # this rank does not own are stale from the first sharded step on, so a whole-buffer update must never run again.
+            # Backward left the chunks reduce-scattered (shards_valid), or -- gradient accumulation, gradients read through
+            # flat_grads() before the step -- every rank holds the fully reduced f32 gradients: its own chunks of them are used.
             return self._step_zero1(model, dp, flat, grad, bf16)
         g16 = dp._g16 if (dp is not None and dp.g16_valid and grad.data_ptr() == model._flat_grad.data_ptr()) else None
         gs = dp.grad_scale if g16 is not None else 1.0
@@ -188,11 +192,16 @@ class FusedAdamW(torch.optim.Optimizer):
         all-reduced squared norm of the chunks, update the chunks, all-gather them slice by slice in the order the next forward
         reads the weights."""
         import torch.distributed as dist
-        slices = list(dp._slices_done)
-        use16 = dp.grad_dtype is torch.bfloat16 and flat.is_cuda
+        scattered = dp.shards_valid
+        slices = list(dp._slices_done) if scattered else dp.slice_plan()
+        # the reduced bf16 chunks of this backward as the reduce-scatter left them (x 1/world), or f32: the f32 buffer holds this
+        # rank's reduced chunks (f32 wire) / the fully reduced gradients (accumulation, flat_grads() before the step)
+        use16 = scattered and dp.g16_valid and dp.grad_dtype is torch.bfloat16 and flat.is_cuda
         g16 = dp._g16 if use16 else None
         gs = dp.grad_scale if use16 else 1.0
         st = stream_ptr()
+        if dp.master_ready is not None:
+            torch.cuda.current_stream().wait_event(dp.master_ready)     # the previous step's master all-gather reads what this update writes
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
         if clip:
             # block partials of every chunk side by side, ONE reduction at the end (a reduction per slice was a 10 us launch each)
@@ -256,7 +265,11 @@ class FusedAdamW(torch.optim.Optimizer):
         dp._slices_done = []
         dp.shards_valid = False
         dp.g16_valid = False
-        dp.params_sharded = dp.world > 1
+        if dp.gather_master:
+            dp.gather_master_async(model, [slices[i] for i in order])
+            dp.params_sharded = False
+        else:
+            dp.params_sharded = dp.world > 1
         model.external_bf16_sync = True
         model._bf16_version = flat._version
         return None

@@ -21,11 +21,16 @@ Gradient exchange (`algo`):
                  needs them, each behind an event the engine's forward waits for (`vlt5_step.wait_events`).  Bytes on the links
                  per step and GPU, N = 8, bf16 buckets: reduce-scatter 7/8 x 451 MB + all-gather 7/8 x (401 + 99) MB = 0.83 GB,
                  against 2 x 7/8 x 451 MB = 0.79 GB for the all-reduce of the gradients alone and 1.58 GB for an f32 all-reduce.
-                 The f32 master of the layer buckets is then only current on the owning rank; `materialize_params()` (called by
-                 `state_dict()` / `flat_params()`) all-gathers it on demand.  Needs `FusedAdamW`; with any other optimizer the
-                 wrapper completes the gradients like "rs_ag".
-  * "auto":      "zero1" when the world size divides 64 (every slice length is a multiple of 64 elements, so the chunks stay
-                 16-byte aligned), "allreduce" otherwise.
+                 The f32 master of the layer buckets follows behind the shadows on the same stream (`gather_master=True`, the
+                 default: +4 B/param x 7/8 on the links per step, under the next forward, nothing waits for it but the next
+                 update), so `state_dict()` / `flat_params()` / a rank-0-only checkpoint (the reference saves on rank 0 only,
+                 vqacl.py:413-414, trainer_base.py:246-249) stay LOCAL calls: the Trainer is driven unchanged.
+                 `gather_master=False` keeps the master of the layer buckets current only on the owning rank; then
+                 `consolidate()` -- a collective every rank must call -- has to run before parameters are read, and
+                 `state_dict()` raises until it has.  Needs `FusedAdamW`; with any other optimizer the wrapper completes the
+                 gradients like "rs_ag".
+  * "auto":      "zero1" when the world size divides 8 (every slice length is a multiple of 64 elements, so the chunks are
+                 multiples of 8 elements = 16 bytes of bf16, what the chunk kernels read), "allreduce" otherwise.
 
 `grad_dtype=torch.bfloat16` (default on the GPU) halves the bytes on the links: each merged slice travels as bf16 (the engine's
 weight-gradient GEMMs write the bf16 staging copy themselves, `vlt5_step.grads_bf16`; only the last bucket is cast) and the
@@ -42,7 +47,8 @@ ALGOS = ("auto", "allreduce", "rs_ag", "zero1")
 
 
 class DataParallelVLT5:
-    def __init__(self, model, process_group=None, bucket_mb=128, average=True, grad_dtype=None, algo="auto", small_group=True):
+    def __init__(self, model, process_group=None, bucket_mb=128, average=True, grad_dtype=None, algo="auto", small_group=True,
+                 gather_master=True):
         self.module = model
         if grad_dtype is None:
             grad_dtype = torch.bfloat16 if model._flat.is_cuda else torch.float32
@@ -56,10 +62,12 @@ class DataParallelVLT5:
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         if algo == "auto":
-            algo = "zero1" if (self.world > 1 and 64 % self.world == 0) else "allreduce"
-        if algo != "allreduce" and 64 % self.world != 0:
-            raise ValueError("rs_ag / zero1 need a world size that divides 64 (chunks of a slice must stay 16-byte aligned)")
+            algo = "zero1" if (self.world > 1 and 8 % self.world == 0) else "allreduce"
+        if algo != "allreduce" and 8 % self.world != 0:
+            raise ValueError("rs_ag / zero1 need a world size that divides 8 (chunks of a slice must stay 16-byte aligned in bf16)")
         self.algo = algo
+        self.gather_master = bool(gather_master)
+        self.master_ready = None            # event behind the f32-master all-gather of the last sharded step (gather_master)
         self.average = average
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         model.dp = self
@@ -87,6 +95,14 @@ class DataParallelVLT5:
         self.shards_valid = False           # this backward left only this rank's chunks reduced (zero1, between backward and step)
         self.params_sharded = False         # the f32 master of the layer buckets is only current on the owning rank (zero1)
         self._slices_done = []              # slices reduce-scattered by the current backward, in issue order
+        self._param_slices = []
+        # the ranges the engine releases gradients in (VLT5._engine_backward): decoder + cross k/v, upper half of the encoder,
+        # the last bucket (embeddings / norms), lower half of the encoder -- the slice plan, and with it the chunk every rank
+        # owns under zero1, only depends on these
+        from ._lib import lib
+        Ld, Le, nb = model.cfg.num_decoder_layers, model.cfg.num_layers, len(self.bucket_end)
+        cut = Ld + 1 + (Le - lib().vlt5_encoder_late_layers(Le)) if Le > 1 else Ld + 1
+        self.release_ranges = ((0, Ld + 1), (Ld + 1, cut), (nb - 1, nb), (cut, nb - 1))
         # identical initial weights on every rank (what DDP's constructor would do)
         dist.broadcast(model._flat, src=0, group=process_group)
         model._bf16_version = -1
@@ -96,7 +112,12 @@ class DataParallelVLT5:
 
     def describe(self):
         return {"algo": self.algo, "grad_dtype": str(self.grad_dtype).replace("torch.", ""), "world": self.world,
-                "bucket_mb": self.bucket_bytes >> 20, "sharded_optimizer": bool(self.sharded_optimizer)}
+                "bucket_mb": self.bucket_bytes >> 20, "sharded_optimizer": bool(self.sharded_optimizer),
+                "gather_master": bool(self.gather_master)}
+
+    def slice_plan(self):
+        """Every merged slice a backward reduce-scatters, [(a, b)] in flat elements, in issue order."""
+        return [(a, b) for lo, hi in self.release_ranges for a, b, _, _ in self.slices_of(lo, hi)]
 
     # ---- slice plan -----------------------------------------------------------------------------------
     def slices_of(self, lo, hi):
@@ -131,9 +152,10 @@ class DataParallelVLT5:
 
     def materialize_grads(self, model=None):
         """Deferred mode: write the averaged gradients into the f32 gradient buffer (what `.grad` views) on the current stream.
-        (zero1: between backward and the optimizer step only this rank's chunks are reduced; the chunks are all-gathered first.)"""
+        (zero1: between backward and the optimizer step only this rank's chunks are reduced; the chunks are all-gathered first --
+        a collective, every rank must call it.  The rank's own chunks stay valid, so the sharded optimizer step still runs.)"""
         if self.shards_valid:
-            self._allgather_grads((model or self.module)._flat_grad)
+            self._allgather_grads((model or self.module)._flat_grad, keep=self.sharded_optimizer)
             if self.comm_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
         if not self.g16_valid:
@@ -182,8 +204,10 @@ class DataParallelVLT5:
         elif self.average:
             t.div_(self.world)
 
-    def _allgather_grads(self, flat):
-        """Second half of rs_ag (and the fall-back of zero1 without a sharded optimizer): every rank receives every chunk."""
+    def _allgather_grads(self, flat, keep=False):
+        """Second half of rs_ag (and the fall-back of zero1 without a sharded optimizer): every rank receives every chunk.
+        keep: the reduce-scattered state (slice list, shards_valid) survives -- the sharded optimizer step that follows reads
+        this rank's chunks, which the all-gather leaves as they are."""
         wire = self._wire(flat)
         bf16 = wire is not flat
         ctx = torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else _null()
@@ -195,8 +219,9 @@ class DataParallelVLT5:
                     if not (self.defer_cast_back and self.grad_dtype is torch.bfloat16):
                         from ._lib import check, lib, ptr, stream_ptr
                         check(lib().vlt5_cast_f32(ptr(wire[a:b]), ptr(flat[a:b]), b - a, self.grad_scale, stream_ptr()), "vlt5_cast_f32")
-        self._slices_done = []
-        self.shards_valid = False
+        if not keep:
+            self._slices_done = []
+            self.shards_valid = False
 
     def reduce_range(self, model, events, lo, hi, final=False, mirrored=False):
         """Issue the collectives of buckets [lo, hi) on the comm stream: consecutive buckets are merged up to `bucket_bytes`, each
@@ -249,13 +274,29 @@ class DataParallelVLT5:
                     dist.all_gather_into_tensor(model._flat[a:b], model._flat[ca:cb], group=self.group)
                 dist.all_gather_into_tensor(model._flat_bf16[a:b], model._flat_bf16[ca:cb], group=self.group)
 
-    def materialize_params(self, model=None):
-        """zero1: make the f32 master complete on this rank (all-gather of every rank's chunks); collective -- every rank calls it
-        (state_dict() / flat_params() / checkpointing do)."""
+    def gather_master_async(self, model, slices):
+        """zero1 with gather_master: all-gather the f32 master chunks of the layer buckets on the comm stream, BEHIND the shadow
+        all-gathers the next forward waits for.  Every rank issues it as part of its optimizer step, so reading parameters
+        afterwards (state_dict(), a rank-0-only checkpoint) is a local wait for `master_ready`, never a collective."""
+        last_a = self.bucket_start[-1]
+        with torch.cuda.stream(self.comm_stream):
+            for a, b in slices:
+                if a >= last_a:
+                    continue            # embeddings / norms: gathered in f32 together with their shadow
+                ca, cb = self.chunk(a, b)
+                dist.all_gather_into_tensor(model._flat[a:b], model._flat[ca:cb], group=self.group)
+            if self.master_ready is None:
+                self.master_ready = torch.cuda.Event()
+            self.master_ready.record(self.comm_stream)
+
+    def consolidate(self, model=None):
+        """zero1 with gather_master=False: make the f32 master complete on this rank (all-gather of every rank's chunks).
+        COLLECTIVE -- every rank must call it, at the same point of the program; `state_dict()` refuses to run before."""
         if not self.params_sharded:
             return
         model = model or self.module
         model.sync_optimizer()
+        in_sync = model._bf16_version == model._flat._version
         last_a = self.bucket_start[-1]
         for a, b in self._param_slices:
             if a >= last_a:
@@ -263,7 +304,10 @@ class DataParallelVLT5:
             ca, cb = self.chunk(a, b)
             dist.all_gather_into_tensor(model._flat[a:b], model._flat[ca:cb], group=self.group)
         self.params_sharded = False
-        model._bf16_version = model._flat._version     # the shadow already equals bf16(master) everywhere
+        if in_sync:                 # the shadow already equals bf16(master) everywhere; a pending refresh (load_state_dict,
+            model._bf16_version = model._flat._version     # p.data.copy_ since the last step) stays pending
+
+    materialize_params = consolidate
 
 
 class _null:
