@@ -26,7 +26,7 @@ extern "C" {
 #define VLT5_OK 0
 #define VLT5_ERR_ARG 1001
 #define VLT5_ERR_ALIGN 1002
-#define VLT5_ABI_VERSION 3
+#define VLT5_ABI_VERSION 4
 
 int vlt5_abi_version(void);
 
@@ -58,6 +58,15 @@ typedef struct vlt5_gemm_desc_s {
                                                 operand orders and alpha, no split; its own shape, reduction length and batch count:
                                                 weight gradients whose tile counts fill the chip only together, or a short problem
                                                 in the shadow of a long one.  Its own grouped_with / tile fields are ignored */
+    /* T5 RMS norm (HF T5LayerNorm.forward: x * rsqrt(mean(x^2) + eps) * w, no mean, no bias) folded AROUND the GEMMs instead of
+     * launched between them: LN(x) W^T = rstd (.) ((x (.) w) W^T).
+     * producer (f32 output with residual, no bias / relu / gate / split-K; N <= 1024): the finished rows x are ALSO written as
+     *   bf16(x * emit_norm_w[n]) to emit_xw_bf16 (same ldc) and every 32- / 64-column slice of a row leaves its sum of squares in
+     *   emit_partials[m * 32 + slice]; emit_nparts (out) = slices per row.
+     * consumer: A = that bf16 operand; every output row m is scaled by rstd[m] = rsqrt(sum_{s < norm_nparts} norm_partials[m*32+s]
+     *   / norm_d + norm_eps) before the rest of the epilogue, and rstd[m] is stored to norm_rstd_out (for the norm's backward). */
+    const float* emit_norm_w; void* emit_xw_bf16; float* emit_partials; int emit_nparts;
+    const float* norm_partials; int norm_nparts, norm_d; float norm_eps; float* norm_rstd_out;
     float* sumsq; long long sumsq_batch_stride; /* optional (plain f32 output, no split): sum of squares of every output tile, written to
                                                 sumsq[z * sumsq_batch_stride + t], t < tiles of the launch's tile shape (at most
                                                 ceil(M/64)*ceil(N/64)); fixed reduction order -- the optimizer's gradient norm
@@ -131,6 +140,13 @@ int vlt5_layernorm_bwd_slabs(const float* dy, int nslabs, long long slab_stride,
                              int accum_dx, int accum_dw, float drop_p, uint32_t drop_seed,
                              int in_group, int in_group_stride, void* dx_bf16, float dx_drop_p, uint32_t dx_drop_seed,
                              void* stream);
+/* same, plus xn_out_bf16 (optional): the norm's FORWARD output bf16(x * rstd * w) is written there -- the operand of the weight
+ * gradient of the projection behind the norm, for a forward that folded the norm around its GEMMs and never materialised it */
+int vlt5_layernorm_bwd_full(const float* dy, int nslabs, long long slab_stride, const float* x, const float* w,
+                            const float* rstd, float* dx, float* dw, float* dw_partial, int rows, int d,
+                            int accum_dx, int accum_dw, float drop_p, uint32_t drop_seed,
+                            int in_group, int in_group_stride, void* dx_bf16, float dx_drop_p, uint32_t dx_drop_seed,
+                            void* xn_out_bf16, void* stream);
 /* job j < njobs (<= 64): out_base[out_off[j] + c] = sum_{b < nblk[j]} partial[(j*slot_rows + b)*width + c], c < width.
  * out_off / nblk are HOST arrays (passed by value to the kernel). */
 int vlt5_colsum_multi(const float* partial, float* out_base, const long long* out_off, const int* nblk, int njobs,
@@ -168,6 +184,12 @@ int vlt5_attn_bwd(const vlt5_attn_desc* d, void* stream);
  * q/k/v = qkv_bf16 + {0, H*64, 2*H*64}, token stride 3*H*64, sample stride S*3*H*64, Tq = Tk = S.  Bit-identical to
  * vlt5_gemm_bf16 + vlt5_attn_fwd. */
 int vlt5_qkv_attn_fwd(const void* xn_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model, void* stream);
+/* the same kernel with the T5 RMS norm folded in (HF T5LayerSelfAttention: T5LayerNorm -> q/k/v): xw_bf16 = bf16(x * w_norm) and the
+ * per-row partial sums of squares of x as the producing GEMM's epilogue left them (vlt5_gemm_desc.emit_xw_bf16 / emit_partials);
+ * the q|k|v rows are scaled by rstd[m] = rsqrt(sum of the norm_nparts (<= 16) partials / d_model + norm_eps) on their way out of
+ * the accumulators, rstd goes to norm_rstd_out [B*S] (optional) for the norm's backward. */
+int vlt5_qkv_attn_fwd_norm(const void* xw_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model,
+                           const float* norm_partials, int norm_nparts, float norm_eps, float* norm_rstd_out, void* stream);
 /* the whole sublayer: x_out = x + dropout(o(attention(LN(x)))) -- HF T5LayerSelfAttention.forward; norm + fused kernel + output
  * projection (dropout + residual in its epilogue); xn / rstd / qkv / ctx / lse are left for the backward */
 typedef struct {

@@ -25,7 +25,9 @@ class GemmDesc(C.Structure):
                 ("relu", c_i), ("out_f32", c_i), ("accum", c_i), ("split_k", c_i), ("workspace", vp),
                 ("tile_m", c_i), ("tile_n", c_i), ("batch", c_i), ("batch_stride_a", c_ll), ("batch_stride_b", c_ll),
                 ("batch_stride_c", c_ll), ("defer_reduce", c_i), ("split_used", c_i), ("c_bf16_copy", vp),
-                ("grouped_with", vp), ("sumsq", vp), ("sumsq_batch_stride", c_ll)]
+                ("grouped_with", vp), ("emit_norm_w", vp), ("emit_xw_bf16", vp), ("emit_partials", vp), ("emit_nparts", c_i),
+                ("norm_partials", vp), ("norm_nparts", c_i), ("norm_d", c_i), ("norm_eps", c_f), ("norm_rstd_out", vp),
+                ("sumsq", vp), ("sumsq_batch_stride", c_ll)]
 
 
 class AttnDesc(C.Structure):
@@ -92,6 +94,7 @@ PROTOTYPES = {
     "vlt5_layernorm_fwd_slabs": (c_i, [vp, c_i, c_ll, vp, vp, c_f, c_u32, vp, vp, vp, vp, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),
     "vlt5_layernorm_bwd": (c_i, [vp, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, c_f, c_u32, vp]),
     "vlt5_layernorm_bwd_slabs": (c_i, [vp, c_i, c_ll, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, c_f, c_u32, vp]),
+    "vlt5_layernorm_bwd_full": (c_i, [vp, c_i, c_ll, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, c_f, c_u32, vp, vp]),
     "vlt5_encoder_late_layers": (c_i, [c_i]),
     "vlt5_side_stream_create": (c_i, [C.POINTER(vp)]),
     "vlt5_side_stream_destroy": (c_i, [vp]),
@@ -101,6 +104,7 @@ PROTOTYPES = {
     "vlt5_layernorm_bwd_blocks": (c_i, [c_i]),
     "vlt5_attn_fwd": (c_i, [C.POINTER(AttnDesc), vp]),
     "vlt5_qkv_attn_fwd": (c_i, [vp, vp, vp, C.POINTER(AttnDesc), c_i, vp]),
+    "vlt5_qkv_attn_fwd_norm": (c_i, [vp, vp, vp, C.POINTER(AttnDesc), c_i, vp, c_i, c_f, vp, vp]),
     "vlt5_enc_attn_fwd": (c_i, [C.POINTER(EncAttnDesc), vp]),
     "vlt5_enc_attn_bwd_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i]),
     "vlt5_enc_attn_bwd": (c_i, [C.POINTER(EncAttnDesc), C.POINTER(EncAttnGrads), vp, vp]),
@@ -173,7 +177,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.vlt5_abi_version() != 3:
+        if L.vlt5_abi_version() != 4:
             raise Vlt5Error("libvlt5_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -38,6 +38,9 @@ struct QkvAttnArgs {
     bf16_t* qkv;               // [B*S, 3*inner] bf16 out
     AttnArgs at;               // core: q/k/v strides describe `qkv`; ctx, lse, bias, key_mask, dropout
     int B, S, H, d;
+    // T5 RMS norm folded into the kernel (vlt5_qkv_attn_fwd_norm): xn holds bf16(x * w_norm); the q|k|v rows are scaled by
+    // rstd[m] = rsqrt(sum of the rs_n partial sums of squares of row m / d + eps) on their way out of the accumulators
+    const float* rs_part; int rs_n; float rs_eps; float* rstd_out;
 };
 
 constexpr int FBM = 128, FBN = 384, FWM = 2, FWN = 4, FNT = 512;
@@ -84,6 +87,20 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
         const int c = tid + i * FNT, row = c >> 3, kc = (c & 7) ^ (row & 7);
         const int grow = (row >> 7) * inner + h0 * 64 + (row & 127);
         src[PA + i] = p.wqkv + (size_t)grow * p.d + kc * 8;
+    }
+    // folded norm: the partial sums of squares of this lane's four rows are requested first (the oldest loads: they have landed
+    // long before the first k-tile) and reduced to rstd behind the prologue's DMA requests
+    constexpr int RSV = 4;                                   // float4 per row: <= 16 partials
+    float4 rsraw[FFM][RSV];
+    int rsrow[FFM];
+    if (p.rs_part) {
+#pragma unroll
+        for (int i = 0; i < FFM; ++i) {
+            rsrow[i] = min(b0 + wm, p.B - 1) * p.S + min(i * 16 + lrow, p.S - 1);
+            const float4* q = reinterpret_cast<const float4*>(p.rs_part + (size_t)rsrow[i] * vlt5gemm::SSQ_STRIDE);
+#pragma unroll
+            for (int k = 0; k < RSV; ++k) rsraw[i][k] = (k * 4 < p.rs_n) ? q[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     const int wave_base = tid & ~63;
     auto piece = [&](int kt, int s, int pc) __attribute__((always_inline)) {
@@ -150,6 +167,26 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
 #pragma unroll
     for (int pc = 0; pc < LPT; ++pc) piece(min(1, nk - 1), 1, pc);
     stamp(1);
+    float rsc[FFM];
+#pragma unroll
+    for (int i = 0; i < FFM; ++i) rsc[i] = 1.f;
+    if (p.rs_part) {
+        const float inv_d = 1.0f / (float)p.d;
+#pragma unroll
+        for (int i = 0; i < FFM; ++i) {
+            float ss = 0.f;
+#pragma unroll
+            for (int k = 0; k < RSV; ++k) {
+                const float4 v = rsraw[i][k];
+                ss += (k * 4 < p.rs_n) ? v.x : 0.f;
+                ss += (k * 4 + 1 < p.rs_n) ? v.y : 0.f;
+                ss += (k * 4 + 2 < p.rs_n) ? v.z : 0.f;
+                ss += (k * 4 + 3 < p.rs_n) ? v.w : 0.f;
+            }
+            rsc[i] = rsqrtf(ss * inv_d + p.rs_eps);
+            if (p.rstd_out && h0 == 0 && wn == 0 && lg == 0 && b0 + wm < p.B && i * 16 + lrow < p.S) p.rstd_out[rsrow[i]] = rsc[i];
+        }
+    }
     bf16x8_t fa0[FFM], fb0[FFN_], fa1[FFM], fb1[FFN_];
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");          // tile 0 (the older group) has landed
     __builtin_amdgcn_s_barrier();
@@ -194,8 +231,8 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
 #pragma unroll
         for (int i = 0; i < FFM; ++i) {
             uint2 pk;
-            pk.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
-            pk.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+            pk.x = pack_bf16x2(acc[i][j][0] * rsc[i], acc[i][j][1] * rsc[i]);
+            pk.y = pack_bf16x2(acc[i][j][2] * rsc[i], acc[i][j][3] * rsc[i]);
             *reinterpret_cast<uint2*>(tl + (i * 16 + lrow) * TS) = pk;
         }
     }
@@ -244,8 +281,22 @@ unsigned long long* g_tl_buf = nullptr;      // vlt5dbg_qkv_attn_timeline: devic
 
 // q|k|v projection + attention core of one encoder self-attention (the kernel above).  Shapes: d_kv = 64, H even, S <= 64,
 // d_model a multiple of 64; the strides in `core` must describe `qkv` ([B, S, 3*H*64], q | k | v).
+static int qkv_attn_launch(const void* xn_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model,
+                           const float* norm_partials, int norm_nparts, float norm_eps, float* norm_rstd_out, void* stream);
 extern "C" int vlt5_qkv_attn_fwd(const void* xn_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model,
                                  void* stream) {
+    return qkv_attn_launch(xn_bf16, wqkv_bf16, qkv_bf16, core, d_model, nullptr, 0, 0.f, nullptr, stream);
+}
+// the same kernel with the T5 RMS norm in front of the projection folded in: xw_bf16 = bf16(x * w_norm) and the per-row partial
+// sums of squares of x as the producing GEMM's epilogue left them (vlt5_gemm_desc.emit_*); the q|k|v rows are scaled by rstd on
+// their way out of the accumulators and rstd goes to norm_rstd_out [B*S] for the backward.  norm_nparts <= 16.
+extern "C" int vlt5_qkv_attn_fwd_norm(const void* xw_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model,
+                                      const float* norm_partials, int norm_nparts, float norm_eps, float* norm_rstd_out, void* stream) {
+    if (!norm_partials || norm_nparts < 1 || norm_nparts > 16 || (((uintptr_t)norm_partials) & 15)) return VLT5_ERR_ARG;
+    return qkv_attn_launch(xw_bf16, wqkv_bf16, qkv_bf16, core, d_model, norm_partials, norm_nparts, norm_eps, norm_rstd_out, stream);
+}
+static int qkv_attn_launch(const void* xn_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model,
+                           const float* norm_partials, int norm_nparts, float norm_eps, float* norm_rstd_out, void* stream) {
     if (!xn_bf16 || !wqkv_bf16 || !qkv_bf16 || !core || !core->ctx) return VLT5_ERR_ARG;
     if (core->dk != 64 || (core->H & 1) || core->Tq != core->Tk || core->Tq < 1 || core->Tq > 64 || core->B < 1 || d_model < 64) return VLT5_ERR_ARG;
     if (d_model & 63) return VLT5_ERR_ALIGN;
@@ -258,6 +309,7 @@ extern "C" int vlt5_qkv_attn_fwd(const void* xn_bf16, const void* wqkv_bf16, voi
     QkvAttnArgs a;
     a.xn = (const bf16_t*)xn_bf16; a.wqkv = (const bf16_t*)wqkv_bf16; a.qkv = (bf16_t*)qkv_bf16;
     a.B = core->B; a.S = S; a.H = core->H; a.d = d_model;
+    a.rs_part = norm_partials; a.rs_n = norm_nparts; a.rs_eps = norm_eps; a.rstd_out = norm_rstd_out;
     AttnArgs& t = a.at;
     t.q = base; t.k = base + inner; t.v = base + 2 * inner;
     t.q_sb = core->q_sb; t.q_st = core->q_st; t.k_sb = core->k_sb; t.k_st = core->k_st; t.v_sb = core->v_sb; t.v_st = core->v_st;

@@ -134,6 +134,7 @@ struct Plan {
     size_t y[3 * MAXL + 1], yr[3 * MAXL + 1];
     size_t yn_a[MAXL], dqkv_s[MAXL], lse_s[MAXL], ctx_s[MAXL], yn_c[MAXL], qc[MAXL], lse_c[MAXL], ctx_c[MAXL], yn_f[MAXL], hd[MAXL], ud[MAXL];
     size_t dec_out, logits, lse_ce, loss_tok, row_w, loss;
+    size_t ssq_e[2 * MAXL + 1], ssq_d[3 * MAXL + 1];      // per-norm partial sums of squares of the residual stream (norm folded around its GEMMs)
     // backward scratch
     size_t dx, tmp, dctx, dkv_all, d_enc_ext, dS_enc, dS_dec, dlogits, slab, ln_partial, vis_partial, rel_scratch, vis_dG, small, slab2;
     // per-layer gradient operands kept until the end of the phase: the weight-gradient GEMMs of all layers run as ONE
@@ -165,6 +166,7 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
         p.ctx[l] = take(M * inner * 2); p.xn_f[l] = take(M * d * 2); p.h[l] = take(M * ff * 2);
         p.u[l] = c.gated_act ? take(M * ffw * 2) : 0;
     }
+    for (int i = 0; i <= 2 * Le; ++i) p.ssq_e[i] = take(M * 32 * 4);
     p.enc_out = take(Mx * d * 4);
     p.enc_ext = take(Mx * d * 2);
     p.mask_ext = take((size_t)B * p.Sx * 4);
@@ -179,6 +181,7 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
         p.hd[l] = take(Md * ff * 2);
         p.ud[l] = c.gated_act ? take(Md * ffw * 2) : 0;
     }
+    for (int i = 0; i <= 3 * Ld; ++i) p.ssq_d[i] = take(Md * 32 * 4);       // (everything whose size depends on T lies behind the encoder's part)
     p.dec_out = take(Md * d * 2);
     p.logits = take(Md * (size_t)c.vocab * 4);
     p.lse_ce = take(Md * 4); p.loss_tok = take(Md * 4); p.row_w = take(Md * 4); p.loss = take(256);
@@ -212,6 +215,9 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     p.small = take(10 * d * 4);
     p.total = off;
 }
+
+// A T5 RMS norm folded around its GEMMs: what the consumer needs (partials per row of the producer's epilogue, where rstd goes)
+struct NormIn { const float* part = nullptr; int n = 0; float* rstd_out = nullptr; };
 
 struct Ctx {
     const vlt5_config& c;
@@ -275,23 +281,51 @@ struct Ctx {
         return VLT5_OK;
     }
 
+    // A T5 RMS norm folded around its GEMMs (vlt5_gemm_desc.emit_* / norm_*): the producer of the residual stream leaves
+    // bf16(x * w_norm) and per-row partial sums of squares, the consumer scales its output rows by rstd and stores rstd
     // y[M,N] = epi(alpha * x[M,K] W[N,K]^T)
     int lin_fwd(const bf16_t* X, const bf16_t* W, void* C, int M, int N, int K, int out_f32, float alpha = 1.f,
-                const float* bias = nullptr, int relu = 0, float dp = 0.f, uint32_t dseed = 0, const float* resid = nullptr) const {
+                const float* bias = nullptr, int relu = 0, float dp = 0.f, uint32_t dseed = 0, const float* resid = nullptr,
+                NormIn nin = NormIn()) const {
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);
         g.A = X; g.B = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
         g.alpha = alpha; g.bias = bias; g.relu = relu; g.drop_p = dp; g.drop_seed = dseed; g.resid = resid; g.ldr = N;
         g.out_f32 = out_f32;
+        if (nin.part) { g.norm_partials = nin.part; g.norm_nparts = nin.n; g.norm_d = K; g.norm_eps = c.eps; g.norm_rstd_out = nin.rstd_out; }
         return vlt5_gemm_bf16(&g, st);
     }
+    // y = resid + dropout(x W^T), and for the norm that consumes y next: bf16(y * w_norm) -> xw, partial sums of squares -> ssq;
+    // *nparts = partials per row
+    int lin_fwd_emit(const bf16_t* X, const bf16_t* W, float* Y, int M, int N, int K, float dp, uint32_t dseed, const float* resid,
+                     long long w_norm, void* xw, float* ssq, int* nparts) const {
+        vlt5_gemm_desc g;
+        memset(&g, 0, sizeof g);
+        g.A = X; g.B = W; g.C = Y; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
+        g.alpha = 1.f; g.drop_p = dp; g.drop_seed = dseed; g.resid = resid; g.ldr = N; g.out_f32 = 1;
+        g.emit_norm_w = P + w_norm; g.emit_xw_bf16 = xw; g.emit_partials = ssq;
+        int rc = vlt5_gemm_bf16(&g, st);
+        *nparts = g.emit_nparts;
+        return rc;
+    }
+    // which norms are folded (same answer in forward and backward: a function of the configuration and the shapes only).
+    // VLT5_FOLD_NORM=0 / VLT5_FOLD_NORM_DEC=0: experiment knobs (A/B runs, tests of the unfolded path)
+    bool fold_on() const {
+        static const bool off = getenv("VLT5_FOLD_NORM") && atoi(getenv("VLT5_FOLD_NORM")) == 0;
+        return !off && d <= 1024 && (d & 31) == 0;
+    }
+    bool fold_dec() const {
+        static const bool off = getenv("VLT5_FOLD_NORM_DEC") && atoi(getenv("VLT5_FOLD_NORM_DEC")) == 0;
+        return !off && fold_on();
+    }
+    bool fold_enc_first(int l) const { return fold_on() && l > 0 && pick_split(p.M, d, ff) <= 1; }     // the norm in front of layer l's attention
     int pick_split(int M, int N, int Kred) const { return vlt5_gemm_auto_split(M, N, Kred, (long long)p.slab_bytes); }
     int ffw() const { return c.gated_act ? 2 * ff : ff; }
     // hidden activation of an FFN: h = dropout(act(xn Wi^T)).  ReLU: one GEMM with the activation in its epilogue.  Gated GELU (HF
     // T5DenseGatedActDense): u = xn [wi_0; wi_1]^T kept for the backward, then h = dropout(gelu_new(u0) * u1)
-    int ffn_hidden(const bf16_t* xn, long long wi, bf16_t* u, bf16_t* h, int M, float dp, uint32_t dseed) const {
-        if (!c.gated_act) return lin_fwd(xn, Pb + wi, h, M, ff, d, 0, 1.f, nullptr, 1, dp, dseed);
-        int rc = lin_fwd(xn, Pb + wi, u, M, 2 * ff, d, 0);
+    int ffn_hidden(const bf16_t* xn, long long wi, bf16_t* u, bf16_t* h, int M, float dp, uint32_t dseed, NormIn nin = NormIn()) const {
+        if (!c.gated_act) return lin_fwd(xn, Pb + wi, h, M, ff, d, 0, 1.f, nullptr, 1, dp, dseed, nullptr, nin);
+        int rc = lin_fwd(xn, Pb + wi, u, M, 2 * ff, d, 0, 1.f, nullptr, 0, 0.f, 0, nullptr, nin);
         if (rc) return rc;
         return vlt5_glu_fwd(u, h, M, ff, dp, dseed, st);
     }
@@ -369,15 +403,17 @@ struct Ctx {
     // slot `ln_jobs`; ln_flush() reduces all slots of the phase with one launch.
     int ln_bwd(const float* dy, const float* x, long long w_off, const float* rstd, float* dx, int rows, int accum_dx,
                float dp, uint32_t dseed, int in_group, int in_group_stride, bf16_t* next_dst, uint32_t next_seed,
-               int nslabs = 1, long long slab_stride = 0) const {
+               int nslabs = 1, long long slab_stride = 0, bf16_t* xn_out = nullptr) const {
         if (ln_jobs >= 64) { int rc = ln_flush(); if (rc) return rc; }     // deep stacks (t5-large: 73 norms per phase)
         float* part = w<float>(p.ln_partial) + (size_t)ln_jobs * LNB_MAXBLK * d;
         ln_out[ln_jobs] = w_off;
         ln_nblk[ln_jobs] = vlt5_layernorm_bwd_blocks(rows);
         ++ln_jobs;
         if (nslabs > 1) dy = w<float>(p.slab);            // the producing GEMM left its split-K slabs there
-        return vlt5_layernorm_bwd_slabs(dy, nslabs, slab_stride, x, P + w_off, rstd, dx, nullptr, part, rows, d, accum_dx, 0, dp,
-                                        dseed, in_group, in_group_stride, next_dst, next_dst ? pdrop : 0.f, next_seed, st);
+        // xn_out: the norm was folded around its GEMMs in the forward -- its bf16 output, the operand of the weight gradient of the
+        // projection behind it, is written now
+        return vlt5_layernorm_bwd_full(dy, nslabs, slab_stride, x, P + w_off, rstd, dx, nullptr, part, rows, d, accum_dx, 0, dp,
+                                       dseed, in_group, in_group_stride, next_dst, next_dst ? pdrop : 0.f, next_seed, xn_out, st);
     }
     int ln_flush() const {
         if (ln_jobs == 0) return VLT5_OK;
@@ -473,6 +509,7 @@ int encoder_fwd(const Ctx& k) {
                           k.P + L.vis_img, k.P + L.shared, x0 + (size_t)s.L * d, (long long)S * d, d, k.w<float>(p.vis_rf),
                           k.w<float>(p.vis_rp), B, s.V, d, c.vocab, c.eps, k.pdrop, k.seed(SITE_ENC_EMBED), S, s.L, k.st));
     int pending = 0;                                          // split-K slabs of the previous layer's FFN output, if any
+    int np_a = 0;                                             // > 0: the norm in front of this layer's attention is folded (partials per row)
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& E = L.enc[l];
         const uint32_t sb = SITE_ENC_BASE + l * 8;
@@ -481,9 +518,14 @@ int encoder_fwd(const Ctx& k) {
         float* xf = k.w<float>(p.x[2 * l + 1]);
         float* xo = k.w<float>(p.x[2 * l + 2]);
         bf16_t* qkv = k.w<bf16_t>(p.qkv[l]);
-        RC(k.ln_fwd_pending(pending, xa, l > 0 ? k.w<float>(p.x[2 * l - 1]) : nullptr, k.pdrop, k.seed(sb - 8 + E_FFN_OUT), E.ln_s,
-                            k.w<void>(p.xn_a[l]), nullptr, k.w<float>(p.xr[2 * l]), M, 0.f, 0, 0, 0));
-        if (fused_attn_ok(k)) {
+        // T5 RMS norm + q|k|v projection + attention core.  Folded norm (np_a > 0): the FFN output GEMM of the previous layer left
+        // bf16(x * w) in xn_a and the rows' partial sums of squares; the projection's rows are scaled by rstd, no norm launch
+        if (np_a == 0)
+            RC(k.ln_fwd_pending(pending, xa, l > 0 ? k.w<float>(p.x[2 * l - 1]) : nullptr, k.pdrop, k.seed(sb - 8 + E_FFN_OUT), E.ln_s,
+                                k.w<void>(p.xn_a[l]), nullptr, k.w<float>(p.xr[2 * l]), M, 0.f, 0, 0, 0));
+        NormIn nin_a;
+        if (np_a > 0) { nin_a.part = k.w<float>(p.ssq_e[2 * l]); nin_a.n = np_a; nin_a.rstd_out = k.w<float>(p.xr[2 * l]); }
+        if (fused_attn_ok(k) && np_a <= 16) {
             vlt5_attn_desc a;
             memset(&a, 0, sizeof a);
             a.q = qkv; a.k = qkv + inner; a.v = qkv + 2 * inner;
@@ -491,17 +533,36 @@ int encoder_fwd(const Ctx& k) {
             a.ctx = k.w<void>(p.ctx[l]); a.o_sb = (long long)S * inner; a.o_st = inner; a.lse = k.w<float>(p.lse[l]);
             a.bias = k.w<float>(p.enc_bias); a.bias_q = s.L; a.bias_k = s.L; a.key_mask = k.w<float>(p.mask); a.mask_value = -10000.f;
             a.B = B; a.H = k.H; a.Tq = S; a.Tk = S; a.dk = c.d_kv; a.drop_p = k.pdrop; a.drop_seed = k.seed(sb + E_PROBS);
-            RC(vlt5_qkv_attn_fwd(k.w<void>(p.xn_a[l]), k.Pb + E.sqkv, qkv, &a, d, k.st));
+            if (np_a > 0)
+                RC(vlt5_qkv_attn_fwd_norm(k.w<void>(p.xn_a[l]), k.Pb + E.sqkv, qkv, &a, d, nin_a.part, nin_a.n, c.eps, nin_a.rstd_out, k.st));
+            else
+                RC(vlt5_qkv_attn_fwd(k.w<void>(p.xn_a[l]), k.Pb + E.sqkv, qkv, &a, d, k.st));
         } else {
-            RC(k.lin_fwd(k.w<bf16_t>(p.xn_a[l]), k.Pb + E.sqkv, qkv, M, 3 * inner, d, 0));
+            RC(k.lin_fwd(k.w<bf16_t>(p.xn_a[l]), k.Pb + E.sqkv, qkv, M, 3 * inner, d, 0, 1.f, nullptr, 0, 0.f, 0, nullptr, nin_a));
             RC(attn_call(k, false, qkv, (long long)S * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)S * 3 * inner,
                          3 * inner, k.w<bf16_t>(p.ctx[l]), k.w<float>(p.lse[l]), k.w<float>(p.enc_bias), s.L, s.L, k.w<float>(p.mask),
                          -10000.f, 0, S, S, k.seed(sb + E_PROBS)));
         }
-        RC(k.lin_fwd(k.w<bf16_t>(p.ctx[l]), k.Pb + E.so, xf, M, d, inner, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + E_ATTN_OUT), xa));
-        RC(vlt5_layernorm_fwd(xf, k.P + E.ln_f, k.w<void>(p.xn_f[l]), nullptr, k.w<float>(p.xr[2 * l + 1]), M, d, c.eps, 0.f, 0, 0, 0, k.st));
-        RC(k.ffn_hidden(k.w<bf16_t>(p.xn_f[l]), E.wi, k.w<bf16_t>(p.u[l]), k.w<bf16_t>(p.h[l]), M, k.pdrop, k.seed(sb + E_FFN_H)));
-        RC(k.lin_fwd_for_norm(k.w<bf16_t>(p.h[l]), k.Pb + E.wo, xo, M, d, ff, k.pdrop, k.seed(sb + E_FFN_OUT), xf, &pending));
+        // output projection (+ dropout + residual); folded: its epilogue also leaves the operand and the partials of the FFN's norm
+        NormIn nin_f;
+        if (k.fold_on()) {
+            int np_f = 0;
+            RC(k.lin_fwd_emit(k.w<bf16_t>(p.ctx[l]), k.Pb + E.so, xf, M, d, inner, k.pdrop, k.seed(sb + E_ATTN_OUT), xa, E.ln_f,
+                              k.w<void>(p.xn_f[l]), k.w<float>(p.ssq_e[2 * l + 1]), &np_f));
+            nin_f.part = k.w<float>(p.ssq_e[2 * l + 1]); nin_f.n = np_f; nin_f.rstd_out = k.w<float>(p.xr[2 * l + 1]);
+        } else {
+            RC(k.lin_fwd(k.w<bf16_t>(p.ctx[l]), k.Pb + E.so, xf, M, d, inner, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + E_ATTN_OUT), xa));
+            RC(vlt5_layernorm_fwd(xf, k.P + E.ln_f, k.w<void>(p.xn_f[l]), nullptr, k.w<float>(p.xr[2 * l + 1]), M, d, c.eps, 0.f, 0, 0, 0, k.st));
+        }
+        RC(k.ffn_hidden(k.w<bf16_t>(p.xn_f[l]), E.wi, k.w<bf16_t>(p.u[l]), k.w<bf16_t>(p.h[l]), M, k.pdrop, k.seed(sb + E_FFN_H), nin_f));
+        np_a = 0;
+        if (l + 1 < c.num_layers && k.fold_enc_first(l + 1)) {
+            pending = 0;
+            RC(k.lin_fwd_emit(k.w<bf16_t>(p.h[l]), k.Pb + E.wo, xo, M, d, ff, k.pdrop, k.seed(sb + E_FFN_OUT), xf, L.enc[l + 1].ln_s,
+                              k.w<void>(p.xn_a[l + 1]), k.w<float>(p.ssq_e[2 * l + 2]), &np_a));
+        } else {
+            RC(k.lin_fwd_for_norm(k.w<bf16_t>(p.h[l]), k.Pb + E.wo, xo, M, d, ff, k.pdrop, k.seed(sb + E_FFN_OUT), xf, &pending));
+        }
     }
     const int Le = c.num_layers;
     RC(k.ln_fwd_pending(pending, k.w<float>(p.x[2 * Le]), k.w<float>(p.x[2 * Le - 1]), k.pdrop,
@@ -541,6 +602,23 @@ int decoder_fwd(const Ctx& k) {
                      k.seed(sb + D_SPROBS)));
         // (the two attention output projections, 84 tiles over K = 768, are cut along K like the FFN output: the norm that follows
         // sums the slabs while it assembles the row)
+        if (k.fold_dec()) {
+            // folded norms: the two attention output projections run un-split and leave bf16(y * w) + the rows' partial sums of
+            // squares for the norm that follows; the cross-attention query projection / the FFN input projection scale their rows
+            // by rstd -- two norm launches less per layer on the decoder's latency chain
+            int np_c = 0, np_f = 0;
+            RC(k.lin_fwd_emit(k.w<bf16_t>(p.ctx_s[l]), k.Pb + D.so, y1, Md, d, inner, k.pdrop, k.seed(sb + D_SOUT), y0, D.ln_c,
+                              k.w<void>(p.yn_c[l]), k.w<float>(p.ssq_d[3 * l + 1]), &np_c));
+            NormIn nc; nc.part = k.w<float>(p.ssq_d[3 * l + 1]); nc.n = np_c; nc.rstd_out = k.w<float>(p.yr[3 * l + 1]);
+            RC(k.lin_fwd(k.w<bf16_t>(p.yn_c[l]), k.Pb + D.cq, k.w<void>(p.qc[l]), Md, inner, d, 0, 1.f, nullptr, 0, 0.f, 0, nullptr, nc));
+            RC(attn_call(k, false, k.w<bf16_t>(p.qc[l]), (long long)T * inner, inner, kv, kv + inner, (long long)Sx * kvw, kvw,
+                         k.w<bf16_t>(p.ctx_c[l]), k.w<float>(p.lse_c[l]), nullptr, 0, 0, k.w<float>(p.mask_ext), -1e9f, 0, T, Sx,
+                         k.seed(sb + D_CPROBS)));
+            RC(k.lin_fwd_emit(k.w<bf16_t>(p.ctx_c[l]), k.Pb + D.co, y2, Md, d, inner, k.pdrop, k.seed(sb + D_COUT), y1, D.ln_f,
+                              k.w<void>(p.yn_f[l]), k.w<float>(p.ssq_d[3 * l + 2]), &np_f));
+            NormIn nf; nf.part = k.w<float>(p.ssq_d[3 * l + 2]); nf.n = np_f; nf.rstd_out = k.w<float>(p.yr[3 * l + 2]);
+            RC(k.ffn_hidden(k.w<bf16_t>(p.yn_f[l]), D.wi, k.w<bf16_t>(p.ud[l]), k.w<bf16_t>(p.hd[l]), Md, k.pdrop, k.seed(sb + D_FFN_H), nf));
+        } else {
         int pend_s = 0, pend_c = 0;
         RC(k.lin_fwd_for_norm(k.w<bf16_t>(p.ctx_s[l]), k.Pb + D.so, y1, Md, d, inner, k.pdrop, k.seed(sb + D_SOUT), y0, &pend_s));
         RC(k.ln_fwd_pending(pend_s, y1, y0, k.pdrop, k.seed(sb + D_SOUT), D.ln_c, k.w<void>(p.yn_c[l]), nullptr,
@@ -553,6 +631,7 @@ int decoder_fwd(const Ctx& k) {
         RC(k.ln_fwd_pending(pend_c, y2, y1, k.pdrop, k.seed(sb + D_COUT), D.ln_f, k.w<void>(p.yn_f[l]), nullptr,
                             k.w<float>(p.yr[3 * l + 2]), Md, 0.f, 0, 0, 0));
         RC(k.ffn_hidden(k.w<bf16_t>(p.yn_f[l]), D.wi, k.w<bf16_t>(p.ud[l]), k.w<bf16_t>(p.hd[l]), Md, k.pdrop, k.seed(sb + D_FFN_H)));
+        }
         RC(k.lin_fwd_for_norm(k.w<bf16_t>(p.hd[l]), k.Pb + D.wo, y3, Md, d, ff, k.pdrop, k.seed(sb + D_FFN_OUT), y2, &pending));
     }
     RC(k.ln_fwd_pending(pending, k.w<float>(p.y[3 * Ld]), k.w<float>(p.y[3 * Ld - 1]), k.pdrop,
@@ -630,7 +709,8 @@ int decoder_step(const Ctx& k, const long long* tokens, int t, bf16_t* cache, fl
 // `dyd` holds bf16(dropout_out(dx)) on entry (emitted by the producer of dx); `dh` receives the hidden gradient; both are
 // kept for the batched weight-gradient GEMMs at the end of the phase.  `next_dst` receives the operand of the next sublayer.
 int ffn_bwd(const Ctx& k, int M, float* dx, const float* x_in, const float* rstd, const bf16_t* h, const bf16_t* u, uint32_t h_seed,
-            const bf16_t* dyd, bf16_t* dh, long long wi, long long wo, long long ln, bf16_t* next_dst, uint32_t next_seed) {
+            const bf16_t* dyd, bf16_t* dh, long long wi, long long wo, long long ln, bf16_t* next_dst, uint32_t next_seed,
+            bf16_t* xn_out = nullptr) {
     const Plan& p = k.p;
     const int d = k.d, ff = k.ff;
     float* tmp = k.w<float>(p.tmp);
@@ -645,7 +725,7 @@ int ffn_bwd(const Ctx& k, int M, float* dx, const float* x_in, const float* rstd
     }
     int ns = 1;
     RC(k.lin_dgrad(dh, k.Pb + wi, tmp, M, k.ffw(), d, 1, 1.f, nullptr, 1.f, &ns));
-    RC(k.ln_bwd(tmp, x_in, ln, rstd, dx, M, 1, 0.f, 0, 0, 0, next_dst, next_seed, ns, (long long)M * d));
+    RC(k.ln_bwd(tmp, x_in, ln, rstd, dx, M, 1, 0.f, 0, 0, 0, next_dst, next_seed, ns, (long long)M * d, xn_out));
     return VLT5_OK;
 }
 
@@ -679,7 +759,8 @@ int decoder_bwd(const Ctx& k) {
         bf16_t* dq_c = k.w<bf16_t>(p.d_dq_c[l]);
         bf16_t* dqkv = k.w<bf16_t>(p.d_dqkv[l]);
         RC(ffn_bwd(k, Md, dx, k.w<float>(p.y[3 * l + 2]), k.w<float>(p.yr[3 * l + 2]), k.w<bf16_t>(p.hd[l]), k.w<bf16_t>(p.ud[l]),
-                   k.seed(sb + D_FFN_H), k.w<bf16_t>(p.d_dyd_f[l]), k.w<bf16_t>(p.d_dh[l]), D.wi, D.wo, D.ln_f, dyd_c, k.seed(sb + D_COUT)));
+                   k.seed(sb + D_FFN_H), k.w<bf16_t>(p.d_dyd_f[l]), k.w<bf16_t>(p.d_dh[l]), D.wi, D.wo, D.ln_f, dyd_c, k.seed(sb + D_COUT),
+                   k.fold_dec() ? k.w<bf16_t>(p.yn_f[l]) : nullptr));
         // cross-attention sublayer
         RC(k.lin_dgrad(dyd_c, k.Pb + D.co, dctx, Md, d, inner, 0));
         RC(attn_call(k, true, k.w<bf16_t>(p.qc[l]), (long long)T * inner, inner, kv, kv + inner, (long long)Sx * kvw, kvw, nullptr,
@@ -688,7 +769,7 @@ int decoder_bwd(const Ctx& k) {
         int ns_c = 1;
         RC(k.lin_dgrad(dq_c, k.Pb + D.cq, tmp, Md, inner, d, 1, 1.f, nullptr, 1.f, &ns_c));
         RC(k.ln_bwd(tmp, k.w<float>(p.y[3 * l + 1]), D.ln_c, k.w<float>(p.yr[3 * l + 1]), dx, Md, 1, 0.f, 0, 0, 0, dyd_s, k.seed(sb + D_SOUT),
-                    ns_c, (long long)Md * d));
+                    ns_c, (long long)Md * d, k.fold_dec() ? k.w<bf16_t>(p.yn_c[l]) : nullptr));
         // causal self-attention sublayer
         RC(k.lin_dgrad(dyd_s, k.Pb + D.so, dctx, Md, d, inner, 0));
         RC(attn_call(k, true, qkv, (long long)T * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)T * 3 * inner,
@@ -810,7 +891,8 @@ int encoder_bwd(const Ctx& k) {
         bf16_t* dyd_a = k.w<bf16_t>(p.e_dyd_a[l]);
         bf16_t* dqkv = k.w<bf16_t>(p.e_dqkv[l]);
         RC(ffn_bwd(k, M, dx, k.w<float>(p.x[2 * l + 1]), k.w<float>(p.xr[2 * l + 1]), k.w<bf16_t>(p.h[l]), k.w<bf16_t>(p.u[l]),
-                   k.seed(sb + E_FFN_H), k.w<bf16_t>(p.e_dyd_f[l]), k.w<bf16_t>(p.e_dh[l]), E.wi, E.wo, E.ln_f, dyd_a, k.seed(sb + E_ATTN_OUT)));
+                   k.seed(sb + E_FFN_H), k.w<bf16_t>(p.e_dyd_f[l]), k.w<bf16_t>(p.e_dh[l]), E.wi, E.wo, E.ln_f, dyd_a, k.seed(sb + E_ATTN_OUT),
+                   k.fold_on() ? k.w<bf16_t>(p.xn_f[l]) : nullptr));
         RC(k.lin_dgrad(dyd_a, k.Pb + E.so, dctx, M, d, inner, 0));
         RC(attn_call(k, true, qkv, (long long)S * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)S * 3 * inner,
                      3 * inner, nullptr, k.w<float>(p.lse[l]), k.w<float>(p.enc_bias), s.L, s.L, k.w<float>(p.mask), -10000.f, 0, S, S,
@@ -820,7 +902,7 @@ int encoder_bwd(const Ctx& k) {
         RC(k.lin_dgrad(dqkv, k.Pb + E.sqkv, tmp, M, 3 * inner, d, 1, 1.f, nullptr, 1.f, &ns_e));
         RC(k.ln_bwd(tmp, k.w<float>(p.x[2 * l]), E.ln_s, k.w<float>(p.xr[2 * l]), dx, M, 1, 0.f, 0, 0, 0,
                     l > 0 ? k.w<bf16_t>(p.e_dyd_f[l - 1]) : nullptr, l > 0 ? k.seed(SITE_ENC_BASE + (l - 1) * 8 + E_FFN_OUT) : 0u, ns_e,
-                    (long long)M * d));
+                    (long long)M * d, k.fold_enc_first(l) ? k.w<bf16_t>(p.xn_a[l]) : nullptr));
         if (Le > 1 && l == enc_cut(Le)) {
             // upper half of the stack: its weight gradients are complete early, so a data-parallel all-reduce of these
             // buckets overlaps with the backward of the lower half

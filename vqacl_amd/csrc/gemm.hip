@@ -53,6 +53,24 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         a.sumsq = d->sumsq; a.sumsq_zstride = d->sumsq_batch_stride;
     }
     a.batch_a = d->batch_stride_a; a.batch_b = d->batch_stride_b; a.batch_c = d->batch_stride_c;
+    a.rs_part = nullptr; a.rs_n = 0; a.rs_inv_d = 0.f; a.rs_eps = 0.f; a.rstd_out = nullptr;
+    if (d->norm_partials) {            // consumer of a folded T5 RMS norm: rows scaled by rstd from the producer's partial sums of squares
+        if (d->norm_nparts < 1 || d->norm_nparts > SSQ_STRIDE || d->norm_d < 1 || d->a_kmajor || d->split_k > 1 || d->grouped_with ||
+            d->out_f32 || d->gate || d->resid || d->accum || d->bias)        // (bf16 outputs without auxiliary operand: the projections behind a norm)
+            return VLT5_ERR_ARG;
+        if (((uintptr_t)d->norm_partials) & 15) return VLT5_ERR_ALIGN;
+        a.rs_part = d->norm_partials; a.rs_n = d->norm_nparts; a.rs_inv_d = 1.0f / (float)d->norm_d; a.rs_eps = d->norm_eps;
+        a.rstd_out = d->norm_rstd_out;
+    }
+    a.emit_w = nullptr; a.emit_xw = nullptr; a.emit_ssq = nullptr;
+    const bool emit = d->emit_xw_bf16 != nullptr;
+    if (emit) {                        // producer of a folded norm: f32 residual epilogue only
+        if (!d->emit_norm_w || !d->emit_partials || !d->out_f32 || !d->resid || d->accum || d->bias || d->relu || d->gate || d->split_k > 1 ||
+            d->grouped_with || d->batch > 1 || d->N > 1024)
+            return VLT5_ERR_ARG;
+        if ((((uintptr_t)d->emit_xw_bf16) & 15) || (((uintptr_t)d->emit_norm_w) & 15) || (d->ldc & 7)) return VLT5_ERR_ALIGN;
+        a.emit_w = d->emit_norm_w; a.emit_xw = (bf16_t*)d->emit_xw_bf16; a.emit_ssq = d->emit_partials;
+    }
     a.grp_tiles = 0; a.gA = nullptr;
     const vlt5_gemm_desc* g2 = d->grouped_with;
     if (g2) {
@@ -121,7 +139,9 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         }
         else { bm = 64; bn = 64; }                                     // small-M (decoder) problems: most workgroups
     }
+    if (emit && bn > 128) { bm = 64; bn = 128; }     // (the norm-emitting epilogue lives in the 4-wave tiles: two column slices per tile)
     if (!(((bm == 128 || bm == 64) && (bn == 128 || bn == 64)) || ((bm == 256 || bm == 224 || bm == 160) && bn == 256))) return VLT5_ERR_ARG;
+    if (emit) d->emit_nparts = ((d->N + bn - 1) / bn) * 2;
     if ((bm == 224 || bm == 160) && d->a_kmajor) return VLT5_ERR_ARG;
 
     int splits = d->split_k > 1 ? d->split_k : 1;

@@ -60,6 +60,12 @@ struct GemmArgs {
     int relu, out_f32, accum;
     int ktiles_per_split; long long c_split_stride;
     long long batch_a, batch_b, batch_c;          // element strides between batch entries (blockIdx.z)
+    // T5 RMS norm folded around the GEMM (vlt5_gemm_desc.norm_*).  Consumer side: A holds bf16(x * w_norm) and the epilogue scales
+    // row m by rstd[m] = rsqrt(sum of its rs_n partial sums of squares / d + eps); tiles of column 0 also store rstd[m].  Producer
+    // side (f32 residual epilogue): the finished row values v are also written as bf16(v * emit_w[n]) to emit_xw and each wave
+    // leaves sum(v^2) over its columns in emit_ssq[m * SSQ_STRIDE + tile_n * WN + wave_n].
+    const float* rs_part; int rs_n; float rs_inv_d, rs_eps; float* rstd_out;
+    const float* emit_w; bf16_t* emit_xw; float* emit_ssq;
     bf16_t* C2;                                   // optional bf16 copy of a plain f32 output (same indexing as C), or null
     float* sumsq; long long sumsq_zstride;        // optional: sum of squares of the tile's (plain f32) output -> sumsq[z*zstride + tile]
     // grouped launch (flat grid: x = every tile of every batch entry of problem 1, then those of problem 2; y = z = 1): workgroups
@@ -74,6 +80,21 @@ struct GemmArgs {
 };
 
 constexpr int BK = 64;
+constexpr int SSQ_STRIDE = 32;          // floats per row of a sum-of-squares partials buffer (<= 32 column slices of a row)
+
+// rstd of row m from the partial sums of squares the producing GEMM's epilogue left (fixed summation order; slots >= n hold garbage)
+__device__ __forceinline__ float rstd_from_partials(const float* __restrict__ part, int n, int m, float inv_d, float eps) {
+    const float4* q = reinterpret_cast<const float4*>(part + (size_t)m * SSQ_STRIDE);
+    float s = 0.f;
+    for (int k = 0; k * 4 < n; ++k) {
+        const float4 v = q[k];
+        s += v.x;
+        if (k * 4 + 1 < n) s += v.y;
+        if (k * 4 + 2 < n) s += v.z;
+        if (k * 4 + 3 < n) s += v.w;
+    }
+    return rsqrtf(s * inv_d + eps);
+}
 
 __device__ __forceinline__ uint32_t lds_off(int row, int kchunk) {            // byte offset in a [R][64] bf16 tile
     return (uint32_t)(row * 128 + ((kchunk ^ (row & 7)) << 4));
@@ -725,19 +746,37 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     // cost per launch before this change).
     const float dscale = drop_scale(p.drop_thr);
     const bool aux_f32 = (p.resid != nullptr) || p.accum;             // block-uniform
+    // per-row factor of a bf16 output: alpha, times rstd[m] when a T5 RMS norm is folded in front of this GEMM (GemmArgs.rs_part;
+    // bf16 outputs without auxiliary operand only: the q|k|v / query projections and the FFN input projection)
+    auto row_factors = [&](float (&rf)[FM]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) rf[i] = p.alpha;
+        if (p.rs_part) {                                                  // block-uniform
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * TM + i * 16 + lrow;
+                const float rs = rstd_from_partials(p.rs_part, p.rs_n, min(m, p.M - 1), p.rs_inv_d, p.rs_eps);
+                rf[i] *= rs;
+                if (p.rstd_out && n0 == 0 && wn == 0 && lg == 0 && m < p.M && blockIdx.y == 0) p.rstd_out[m] = rs;
+            }
+        }
+    };
     // bf16 output: two neighbouring fragments j, j+1 of a row block are packed and exchanged between the lane rows with
     // v_permlane16_swap (rows 1/3 of fragment j <-> rows 0/2 of fragment j+1), after which a lane owns 8 consecutive columns:
     // one 16-byte store per lane, 64 contiguous bytes per matrix row per instruction, half as many store instructions as
     // 8-byte stores (the epilogue is store-ISSUE bound: ~50 cycles per wave-store whatever its width).  Every lane takes part
     // in the swap; only the store is predicated.
-    auto store_pair_bf16 = [&](int m, int j, const float (&v)[4], const float (&w)[4]) __attribute__((always_inline)) {
+    auto store_pair_bf16_to = [&](bf16_t* base, int m, int j, const float (&v)[4], const float (&w)[4]) __attribute__((always_inline)) {
         const uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
         const uint32_t q0 = pack_bf16x2(w[0], w[1]), q1 = pack_bf16x2(w[2], w[3]);
         const auto s0 = __builtin_amdgcn_permlane16_swap(p0, q0, false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(p1, q1, false, false);
         const int n = n0 + wn * TN + (j + (lg & 1)) * 16 + (lg >> 1) * 8;
         if (m < p.M && n < p.N)
-            st16(reinterpret_cast<bf16_t*>(Cbase) + (size_t)m * p.ldc + n, make_uint4(s0[0], s1[0], s0[1], s1[1]));
+            st16(base + (size_t)m * p.ldc + n, make_uint4(s0[0], s1[0], s0[1], s1[1]));
+    };
+    auto store_pair_bf16 = [&](int m, int j, const float (&v)[4], const float (&w)[4]) __attribute__((always_inline)) {
+        store_pair_bf16_to(reinterpret_cast<bf16_t*>(Cbase), m, j, v, w);
     };
     if (!p.bias && !p.relu && !p.gate && !p.drop_thr && !aux_f32) {
         // plain epilogue (QKV / cross-K/V / lm_head projections, every dgrad without gate, every weight gradient): straight-line
@@ -782,6 +821,8 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                 }
             }
         } else {
+            float rowf[FM];
+            row_factors(rowf);
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int m = m0 + wm * TM + i * 16 + lrow;
@@ -789,7 +830,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                 for (int j = 0; j < FN; j += 2) {
                     float v[4], w[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { v[r] = acc[i][j][r] * p.alpha; w[r] = acc[i][j + 1][r] * p.alpha; }
+                    for (int r = 0; r < 4; ++r) { v[r] = acc[i][j][r] * rowf[i]; w[r] = acc[i][j + 1][r] * rowf[i]; }
                     store_pair_bf16(m, j, v, w);
                 }
             }
@@ -809,6 +850,9 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
         constexpr bool kBias = decltype(c_bias)::value, kRelu = decltype(c_relu)::value, kGate = decltype(c_gate)::value;
         constexpr bool kDrop = decltype(c_drop)::value, kAux = decltype(c_aux)::value, kF32 = decltype(c_f32)::value;
         constexpr bool kGen = decltype(c_generic)::value;      // generic instance: a compiled-in option is still tested at run time
+        constexpr bool kRowScale = !kF32 && !kAux && !kGate;   // (the FFN input projection behind a folded norm)
+        float rowf[kRowScale ? FM : 1];
+        if constexpr (kRowScale) row_factors(rowf);
         const bool do_bias = kBias && (!kGen || bias), do_relu = kRelu && (!kGen || relu), do_drop = kDrop && (!kGen || drop);
         const bool do_aux = kAux && (!kGen || aux_f32);
         float4 bs[FN];
@@ -855,7 +899,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                 const int i = ib + ii;
                 const int n = n0 + wn * TN + j * 16 + lg * 4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * (kRowScale ? rowf[kRowScale ? i : 0] : p.alpha);
                 if constexpr (kBias) { v[0] += bs[j].x; v[1] += bs[j].y; v[2] += bs[j].z; v[3] += bs[j].w; }
                 if constexpr (kRelu) {
                     if (do_relu) {
@@ -886,6 +930,36 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                 if (ib + ii >= FM) continue;
                 const int m = m0 + wm * TM + (ib + ii) * 16 + lrow;
                 if constexpr (kF32) {
+                    if constexpr (kAux && !kGen && !kBias && !kRelu && !kGate && WM * WN == 4) {      // (the dispatcher gives a norm-emitting GEMM a 4-wave tile)
+                        if (p.emit_xw) {          // (block-uniform) the next sublayer's T5 RMS norm is folded around its GEMM: see GemmArgs
+                            float ss = 0.f;
+#pragma unroll
+                            for (int j = 0; j < FN; j += 2) {
+                                float v[4], w[4], ev[4], ew[4];
+                                finish(ii, j, m, v);
+                                finish(ii, j + 1, m, w);
+                                const int n = n0 + wn * TN + j * 16 + lg * 4;
+                                const bool in0 = m < p.M && n < p.N, in1 = m < p.M && n + 16 < p.N;
+                                const float4 g0 = in0 ? *reinterpret_cast<const float4*>(p.emit_w + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                                const float4 g1 = in1 ? *reinterpret_cast<const float4*>(p.emit_w + n + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (in0) {
+                                    st16f(reinterpret_cast<float*>(Cbase) + (size_t)m * p.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
+                                    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                                }
+                                if (in1) {
+                                    st16f(reinterpret_cast<float*>(Cbase) + (size_t)m * p.ldc + n + 16, make_float4(w[0], w[1], w[2], w[3]));
+                                    ss += w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3];
+                                }
+                                ev[0] = v[0] * g0.x; ev[1] = v[1] * g0.y; ev[2] = v[2] * g0.z; ev[3] = v[3] * g0.w;
+                                ew[0] = w[0] * g1.x; ew[1] = w[1] * g1.y; ew[2] = w[2] * g1.z; ew[3] = w[3] * g1.w;
+                                store_pair_bf16_to(p.emit_xw, m, j, ev, ew);
+                            }
+                            ss += __shfl_xor(ss, 16, 64);
+                            ss += __shfl_xor(ss, 32, 64);
+                            if (lg == 0 && m < p.M) p.emit_ssq[(size_t)m * SSQ_STRIDE + (n0 / BN) * WN + wn] = ss;
+                            continue;
+                        }
+                    }
                     if (m >= p.M) continue;
 #pragma unroll
                     for (int j = 0; j < FN; ++j) {

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      float* __restrict__ dx, float* __restrict__ dwp, int rows, int d,
                                                      int accum_dx, uint32_t thr, uint32_t seed, int group, int gstride,
                                                      bf16_t* __restrict__ dxb, uint32_t thr2, uint32_t seed2, int nslabs,
-                                                     long long slab_stride) {
+                                                     long long slab_stride, bf16_t* __restrict__ xn_out) {
     extern __shared__ float red[];                       // [4][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 dwacc[LN_MAXCH];
@@ -188,6 +188,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 float* dp = dx + (size_t)row * d + c;
                 if (accum_dx) { o.x += qv[k].x; o.y += qv[k].y; o.z += qv[k].z; o.w += qv[k].w; }
                 *reinterpret_cast<float4*>(dp) = o;
+                if (xn_out) {                   // the norm's forward output bf16(x * rstd * w): the operand of the weight-gradient GEMM of the
+                    uint2 pn;                   // projection behind it, when the forward never materialised it (norm folded around the GEMM)
+                    pn.x = pack_bf16x2(wreg[k].x * (xv[k].x * rs), wreg[k].y * (xv[k].y * rs));
+                    pn.y = pack_bf16x2(wreg[k].z * (xv[k].z * rs), wreg[k].w * (xv[k].w * rs));
+                    *reinterpret_cast<uint2*>(xn_out + (size_t)row * d + c) = pn;
+                }
                 if (dxb) {                      // bf16(dropout(dx)) = the A operand of the next sublayer's backward GEMMs
                     float q[4] = {o.x, o.y, o.z, o.w};
                     if (thr2) {
@@ -315,6 +321,14 @@ extern "C" int vlt5_layernorm_bwd_slabs(const float* dy, int nslabs, long long s
                                         const float* rstd, float* dx, float* dw, float* dw_partial, int rows, int d, int accum_dx,
                                         int accum_dw, float drop_p, uint32_t drop_seed, int in_group, int in_group_stride,
                                         void* dx_bf16, float dx_drop_p, uint32_t dx_drop_seed, void* stream) {
+    return vlt5_layernorm_bwd_full(dy, nslabs, slab_stride, x, w, rstd, dx, dw, dw_partial, rows, d, accum_dx, accum_dw, drop_p, drop_seed,
+                                   in_group, in_group_stride, dx_bf16, dx_drop_p, dx_drop_seed, nullptr, stream);
+}
+
+extern "C" int vlt5_layernorm_bwd_full(const float* dy, int nslabs, long long slab_stride, const float* x, const float* w,
+                                       const float* rstd, float* dx, float* dw, float* dw_partial, int rows, int d, int accum_dx,
+                                       int accum_dw, float drop_p, uint32_t drop_seed, int in_group, int in_group_stride,
+                                       void* dx_bf16, float dx_drop_p, uint32_t dx_drop_seed, void* xn_out_bf16, void* stream) {
     if (!dy || !x || !w || !rstd || !dx || !dw_partial || rows <= 0) return VLT5_ERR_ARG;
     if (nslabs < 1 || (nslabs > 1 && (slab_stride <= 0 || (slab_stride & 3)))) return VLT5_ERR_ARG;
     if ((d & 3) || d > 256 * LN_MAXCH_MAX) return VLT5_ERR_ALIGN;
@@ -324,11 +338,11 @@ extern "C" int vlt5_layernorm_bwd_slabs(const float* dy, int nslabs, long long s
     if (d <= 1024)
         hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(256), 4 * d * sizeof(float), (hipStream_t)stream, dy, x, w, rstd, dx,
                            dw_partial, rows, d, accum_dx, thr, drop_seed, in_group, in_group_stride, (bf16_t*)dx_bf16, thr2,
-                           dx_drop_seed, nslabs, slab_stride);
+                           dx_drop_seed, nslabs, slab_stride, (bf16_t*)xn_out_bf16);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<8>, dim3(nblk), dim3(256), 4 * d * sizeof(float), (hipStream_t)stream, dy, x, w, rstd, dx,
                            dw_partial, rows, d, accum_dx, thr, drop_seed, in_group, in_group_stride, (bf16_t*)dx_bf16, thr2,
-                           dx_drop_seed, nslabs, slab_stride);
+                           dx_drop_seed, nslabs, slab_stride, (bf16_t*)xn_out_bf16);
     LAUNCH_CHECK();
     if (dw) {
         hipLaunchKernelGGL(colsum_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)stream, dw_partial, dw, nblk, d, d,
