@@ -1129,15 +1129,18 @@ def test_degenerate_rows_vs_oracle(dev):
 
 
 def test_unfolded_norm_path_still_matches_the_oracle():
-    """The engine folds the T5 RMS norms around their GEMMs by default (csrc/engine.hip fold_on / fold_dec); the path with norm
-    launches stays in the library (small batches whose FFN output is cut along K take it per layer anyway).  The knobs are read
-    once per process, so the oracle comparisons of the tiny fixture and of the base model re-run in a child with the folding off."""
+    """The engine folds the encoder's T5 RMS norms around their GEMMs by default (csrc/engine.hip fold_on / fold_dec); the path with
+    norm launches stays in the library (small batches whose FFN output is cut along K take it per layer anyway), and the decoder's
+    folding is an option.  The knobs are read once per process, so the oracle comparisons of the tiny fixture and of the base
+    model re-run in children with the other settings."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, VLT5_FOLD_NORM="0", VLT5_FOLD_NORM_DEC="0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_model.py"), "-m", "gpu", "-q", "-x", "-k",
-                        "tiny_model_against_golden_fixture or base_model_forward_backward_vs_oracle"], env=env, cwd=root,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # the default folds the encoder's norms only: (off, off) is the plain path, (on, on) also folds the decoder's cross / FFN norms
+    for enc, dec in (("0", "0"), ("1", "1")):
+        env = dict(os.environ, VLT5_FOLD_NORM=enc, VLT5_FOLD_NORM_DEC=dec)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_model.py"), "-m", "gpu", "-q", "-x", "-k",
+                            "tiny_model_against_golden_fixture or base_model_forward_backward_vs_oracle"], env=env, cwd=root,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "2 passed" in r.stdout, (enc, dec, r.stdout[-2000:] + r.stderr[-2000:])

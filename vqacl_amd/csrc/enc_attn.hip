@@ -88,20 +88,11 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
         const int grow = (row >> 7) * inner + h0 * 64 + (row & 127);
         src[PA + i] = p.wqkv + (size_t)grow * p.d + kc * 8;
     }
-    // folded norm: the partial sums of squares of this lane's four rows are requested first (the oldest loads: they have landed
-    // long before the first k-tile) and reduced to rstd behind the prologue's DMA requests
-    constexpr int RSV = 4;                                   // float4 per row: <= 16 partials
-    float4 rsraw[FFM][RSV];
-    int rsrow[FFM];
-    if (p.rs_part) {
-#pragma unroll
-        for (int i = 0; i < FFM; ++i) {
-            rsrow[i] = min(b0 + wm, p.B - 1) * p.S + min(i * 16 + lrow, p.S - 1);
-            const float4* q = reinterpret_cast<const float4*>(p.rs_part + (size_t)rsrow[i] * vlt5gemm::SSQ_STRIDE);
-#pragma unroll
-            for (int k = 0; k < RSV; ++k) rsraw[i][k] = (k * 4 < p.rs_n) ? q[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
+    // folded norm: a wave's 64 rows are spread over its lanes (row wm*64 + lane); the partial sums of squares are requested first
+    // (the oldest loads: they have landed long before the first k-tile) and reduced to rstd behind the prologue's DMA requests
+    vlt5gemm::NormRaw rsraw;
+    const int rsrow = min(b0 + wm, p.B - 1) * p.S + min(lane, p.S - 1);
+    if (p.rs_part) vlt5gemm::norm_request(p.rs_part, p.rs_n, rsrow, rsraw);
     const int wave_base = tid & ~63;
     auto piece = [&](int kt, int s, int pc) __attribute__((always_inline)) {
         char* dst = smem + s * STAGE_BYTES + (pc < PA ? 0 : A_BYTES) + ((pc < PA ? pc : pc - PA) * FNT + wave_base) * 16;
@@ -167,25 +158,10 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
 #pragma unroll
     for (int pc = 0; pc < LPT; ++pc) piece(min(1, nk - 1), 1, pc);
     stamp(1);
-    float rsc[FFM];
-#pragma unroll
-    for (int i = 0; i < FFM; ++i) rsc[i] = 1.f;
+    float rs_own = 1.f;
     if (p.rs_part) {
-        const float inv_d = 1.0f / (float)p.d;
-#pragma unroll
-        for (int i = 0; i < FFM; ++i) {
-            float ss = 0.f;
-#pragma unroll
-            for (int k = 0; k < RSV; ++k) {
-                const float4 v = rsraw[i][k];
-                ss += (k * 4 < p.rs_n) ? v.x : 0.f;
-                ss += (k * 4 + 1 < p.rs_n) ? v.y : 0.f;
-                ss += (k * 4 + 2 < p.rs_n) ? v.z : 0.f;
-                ss += (k * 4 + 3 < p.rs_n) ? v.w : 0.f;
-            }
-            rsc[i] = rsqrtf(ss * inv_d + p.rs_eps);
-            if (p.rstd_out && h0 == 0 && wn == 0 && lg == 0 && b0 + wm < p.B && i * 16 + lrow < p.S) p.rstd_out[rsrow[i]] = rsc[i];
-        }
+        rs_own = vlt5gemm::norm_reduce(rsraw, p.rs_n, 1.0f / (float)p.d, p.rs_eps);
+        if (p.rstd_out && h0 == 0 && wn == 0 && b0 + wm < p.B && lane < p.S) p.rstd_out[rsrow] = rs_own;
     }
     bf16x8_t fa0[FFM], fb0[FFN_], fa1[FFM], fb1[FFN_];
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");          // tile 0 (the older group) has landed
@@ -221,6 +197,9 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
     stamp(9);
 
     // ---- phase 2: accumulators -> bf16 natural tiles; tile (s, hh, part) at ((s*2 + hh)*3 + part) * TILE_BYTES ---------------
+    float rsc[FFM];                                          // rstd of fragment row i*16 + lrow: held by lane i*16 + lrow of this wave
+#pragma unroll
+    for (int i = 0; i < FFM; ++i) rsc[i] = p.rs_part ? __shfl(rs_own, i * 16 + lrow, 64) : 1.f;
     auto tile = [&](int s, int hh, int part) __attribute__((always_inline)) -> bf16_t* {
         return reinterpret_cast<bf16_t*>(smem + ((s * 2 + hh) * 3 + part) * TILE_BYTES);
     };

@@ -314,9 +314,12 @@ struct Ctx {
         static const bool off = getenv("VLT5_FOLD_NORM") && atoi(getenv("VLT5_FOLD_NORM")) == 0;
         return !off && d <= 1024 && (d & 31) == 0;
     }
+    // (decoder: the norms in front of the cross-attention query and the FFN could lose their launches too, but their producers --
+    // the 400-row attention output projections -- then run un-split over K and the 64 x 64 consumers pay the row scale: measured
+    // +0.13 ms per step against -0.17 ms of norm launches saved ... and +0.13 ms of slower 84-tile GEMMs: a net loss, off by default)
     bool fold_dec() const {
-        static const bool off = getenv("VLT5_FOLD_NORM_DEC") && atoi(getenv("VLT5_FOLD_NORM_DEC")) == 0;
-        return !off && fold_on();
+        static const bool on = getenv("VLT5_FOLD_NORM_DEC") && atoi(getenv("VLT5_FOLD_NORM_DEC")) == 1;
+        return on && fold_on();
     }
     bool fold_enc_first(int l) const { return fold_on() && l > 0 && pick_split(p.M, d, ff) <= 1; }     // the norm in front of layer l's attention
     int pick_split(int M, int N, int Kred) const { return vlt5_gemm_auto_split(M, N, Kred, (long long)p.slab_bytes); }

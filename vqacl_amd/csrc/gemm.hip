@@ -55,7 +55,7 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
     a.batch_a = d->batch_stride_a; a.batch_b = d->batch_stride_b; a.batch_c = d->batch_stride_c;
     a.rs_part = nullptr; a.rs_n = 0; a.rs_inv_d = 0.f; a.rs_eps = 0.f; a.rstd_out = nullptr;
     if (d->norm_partials) {            // consumer of a folded T5 RMS norm: rows scaled by rstd from the producer's partial sums of squares
-        if (d->norm_nparts < 1 || d->norm_nparts > SSQ_STRIDE || d->norm_d < 1 || d->a_kmajor || d->split_k > 1 || d->grouped_with ||
+        if (d->norm_nparts < 1 || d->norm_nparts > SSQ_STRIDE || d->norm_d < 1 || d->a_kmajor || d->b_kmajor || d->split_k > 1 || d->grouped_with ||
             d->out_f32 || d->gate || d->resid || d->accum || d->bias)        // (bf16 outputs without auxiliary operand: the projections behind a norm)
             return VLT5_ERR_ARG;
         if (((uintptr_t)d->norm_partials) & 15) return VLT5_ERR_ALIGN;
@@ -66,7 +66,7 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
     const bool emit = d->emit_xw_bf16 != nullptr;
     if (emit) {                        // producer of a folded norm: f32 residual epilogue only
         if (!d->emit_norm_w || !d->emit_partials || !d->out_f32 || !d->resid || d->accum || d->bias || d->relu || d->gate || d->split_k > 1 ||
-            d->grouped_with || d->batch > 1 || d->N > 1024)
+            d->grouped_with || d->batch > 1 || d->N > 1024 || d->a_kmajor || d->b_kmajor)
             return VLT5_ERR_ARG;
         if ((((uintptr_t)d->emit_xw_bf16) & 15) || (((uintptr_t)d->emit_norm_w) & 15) || (d->ldc & 7)) return VLT5_ERR_ALIGN;
         a.emit_w = d->emit_norm_w; a.emit_xw = (bf16_t*)d->emit_xw_bf16; a.emit_ssq = d->emit_partials;

@@ -82,16 +82,28 @@ struct GemmArgs {
 constexpr int BK = 64;
 constexpr int SSQ_STRIDE = 32;          // floats per row of a sum-of-squares partials buffer (<= 32 column slices of a row)
 
-// rstd of row m from the partial sums of squares the producing GEMM's epilogue left (fixed summation order; slots >= n hold garbage)
-__device__ __forceinline__ float rstd_from_partials(const float* __restrict__ part, int n, int m, float inv_d, float eps) {
-    const float4* q = reinterpret_cast<const float4*>(part + (size_t)m * SSQ_STRIDE);
+// Folded norm, consumer side: rstd of a row from the partial sums of squares the producing GEMM's epilogue left.  The partials of
+// up to RS_ROWS rows per lane are REQUESTED with norm_request() before the kernel's first DMA requests and reduced with
+// norm_reduce() behind them (one memory round trip, hidden under the prologue); a wave's rows are spread over its lanes (row
+// q*64 + lane), the epilogue fetches the factor of "its" fragment rows with a lane shuffle.  Fixed summation order.
+constexpr int RS_V = 8;                  // float4 per row: SSQ_STRIDE / 4
+struct NormRaw { float4 v[RS_V]; };
+__device__ __forceinline__ void norm_request(const float* __restrict__ part, int n, int row, NormRaw& r) {
+    const float4* q = reinterpret_cast<const float4*>(part + (size_t)row * SSQ_STRIDE);
+#pragma unroll
+    for (int k = 0; k < RS_V; ++k)
+        if (k * 4 < n) r.v[k] = q[k];                         // (n is block-uniform: whole float4s, the tail is masked in the sum)
+}
+__device__ __forceinline__ float norm_reduce(const NormRaw& r, int n, float inv_d, float eps) {
     float s = 0.f;
-    for (int k = 0; k * 4 < n; ++k) {
-        const float4 v = q[k];
-        s += v.x;
-        if (k * 4 + 1 < n) s += v.y;
-        if (k * 4 + 2 < n) s += v.z;
-        if (k * 4 + 3 < n) s += v.w;
+#pragma unroll
+    for (int k = 0; k < RS_V; ++k) {
+        if (k * 4 < n) {
+            s += r.v[k].x;
+            s += (k * 4 + 1 < n) ? r.v[k].y : 0.f;
+            s += (k * 4 + 2 < n) ? r.v[k].z : 0.f;
+            s += (k * 4 + 3 < n) ? r.v[k].w : 0.f;
+        }
     }
     return rsqrtf(s * inv_d + eps);
 }
@@ -545,6 +557,17 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
         }
 #endif
     }
+    // folded norm in front of this GEMM: the partial sums of squares of this wave's rows (row q*64 + lane of its TM rows)
+    constexpr int RS_ROWS = (TM + 63) / 64;
+    constexpr bool NORM_IN = !AKM && !BKM;                   // (forward projections only: both operands row-major)
+    NormRaw rs_raw[RS_ROWS];
+    float rs_own[RS_ROWS];
+#pragma unroll
+    for (int q = 0; q < RS_ROWS; ++q) rs_own[q] = 1.f;
+    if (NORM_IN && p.rs_part) {                              // block-uniform
+#pragma unroll
+        for (int q = 0; q < RS_ROWS; ++q) norm_request(p.rs_part, p.rs_n, min(m0 + wm * TM + q * 64 + lane, p.M - 1), rs_raw[q]);
+    }
     const bool has_tail = (kt1 == nk_total) && (p.K % BK != 0) && (kt1 > kt0);
     const int nmain = (kt1 - kt0) - (has_tail ? 1 : 0);
     if constexpr (KM_STEP) {
@@ -558,6 +581,14 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
 #pragma unroll
         for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
             if (s0 < nmain) glds(kt0 + s0, s0);
+    }
+    if (NORM_IN && p.rs_part) {
+#pragma unroll
+        for (int q = 0; q < RS_ROWS; ++q) {
+            rs_own[q] = norm_reduce(rs_raw[q], p.rs_n, p.rs_inv_d, p.rs_eps);
+            const int r = q * 64 + lane, m = m0 + wm * TM + r;
+            if (p.rstd_out && n0 == 0 && wn == 0 && r < TM && m < p.M && blockIdx.y == 0) p.rstd_out[m] = rs_own[q];
+        }
     }
     int stage = 0, fill = NSTAGE - 1;                      // stage of tile i, stage that tile i+NSTAGE-1 goes to
     TL(1);
@@ -751,14 +782,9 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     auto row_factors = [&](float (&rf)[FM]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) rf[i] = p.alpha;
-        if (p.rs_part) {                                                  // block-uniform
+        if (NORM_IN && p.rs_part) {                                       // block-uniform
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int m = m0 + wm * TM + i * 16 + lrow;
-                const float rs = rstd_from_partials(p.rs_part, p.rs_n, min(m, p.M - 1), p.rs_inv_d, p.rs_eps);
-                rf[i] *= rs;
-                if (p.rstd_out && n0 == 0 && wn == 0 && lg == 0 && m < p.M && blockIdx.y == 0) p.rstd_out[m] = rs;
-            }
+            for (int i = 0; i < FM; ++i) rf[i] *= __shfl(rs_own[(i * 16) >> 6], (i * 16 + lrow) & 63, 64);     // fragment row i*16 + lrow of the wave
         }
     };
     // bf16 output: two neighbouring fragments j, j+1 of a row block are packed and exchanged between the lane rows with
@@ -892,6 +918,16 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                     }
                 }
             }
+            float4 gw[FN];                           // norm-emitting epilogue: the next norm's weight for this lane's columns
+            if constexpr (kAux && !kGen && !kBias && !kRelu && !kGate && kF32 && WM * WN == 4 && !AKM && !BKM) {
+                if (p.emit_xw) {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const int n = n0 + wn * TN + j * 16 + lg * 4;
+                        gw[j] = n < p.N ? *reinterpret_cast<const float4*>(p.emit_w + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
             // one explicit vmcnt(0) that EVERY path passes: the loads above sit in divergent branches, and a conservative
             // re-wait before each fragment would land between the stores (vmcnt counts stores too on CDNA)
             __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -930,7 +966,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                 if (ib + ii >= FM) continue;
                 const int m = m0 + wm * TM + (ib + ii) * 16 + lrow;
                 if constexpr (kF32) {
-                    if constexpr (kAux && !kGen && !kBias && !kRelu && !kGate && WM * WN == 4) {      // (the dispatcher gives a norm-emitting GEMM a 4-wave tile)
+                    if constexpr (kAux && !kGen && !kBias && !kRelu && !kGate && WM * WN == 4 && !AKM && !BKM) {      // (the dispatcher gives a norm-emitting GEMM a 4-wave tile)
                         if (p.emit_xw) {          // (block-uniform) the next sublayer's T5 RMS norm is folded around its GEMM: see GemmArgs
                             float ss = 0.f;
 #pragma unroll
@@ -940,8 +976,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                                 finish(ii, j + 1, m, w);
                                 const int n = n0 + wn * TN + j * 16 + lg * 4;
                                 const bool in0 = m < p.M && n < p.N, in1 = m < p.M && n + 16 < p.N;
-                                const float4 g0 = in0 ? *reinterpret_cast<const float4*>(p.emit_w + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                                const float4 g1 = in1 ? *reinterpret_cast<const float4*>(p.emit_w + n + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                                const float4 g0 = gw[j], g1 = gw[j + 1];
                                 if (in0) {
                                     st16f(reinterpret_cast<float*>(Cbase) + (size_t)m * p.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
                                     ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
