@@ -229,8 +229,13 @@ int vlt5_relbias_bwd(const float* dS, const int* lut, float* dtable, float* scra
  * the dropout index is ((b*drop_rows + drop_row0 + t)*d + c). */
 int vlt5_embed_fwd(const long long* ids, const float* table, float* out, long long out_sb, long long out_st,
                    int B, int T, int d, int vocab, float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* stream);
+/* dtable[ids[b,t]] += dropout'(dout[b,t]) -- the scatter-add of nn.Embedding's backward (src/vqacl.py:461), DETERMINISTIC: the
+ * contributions of an id that occurs several times are summed in a fixed two-level tree, no atomics.  scratch:
+ * vlt5_embed_bwd_scratch_bytes(B, T, d) bytes of device memory (16-byte aligned). */
+long long vlt5_embed_bwd_scratch_bytes(int B, int T, int d);
 int vlt5_embed_bwd(const long long* ids, const float* dout, long long sb, long long st, float* dtable,
-                   int B, int T, int d, int vocab, float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* stream);
+                   int B, int T, int d, int vocab, float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* scratch,
+                   void* stream);
 /* labels -> decoder input ids (HF _shift_right, called at src/modeling_t5_our.py:620) */
 int vlt5_shift_right(const long long* labels, long long* out, int B, int T, int start_id, int pad_id, void* stream);
 /* f32 [B,S] encoder mask: 1 where input_ids != pad for the L text columns, 1 for the rest (:225-232, :631-638) */

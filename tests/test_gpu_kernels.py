@@ -640,8 +640,6 @@ def test_fused_qkv_attention_rejects_unsupported_shapes(dev):
     from vqacl_amd._lib import Vlt5Error
     x = torch.zeros(2 * 8, 64, device=dev, dtype=BF)
     with pytest.raises(Vlt5Error):
-        ops.qkv_attn_fwd(x, torch.zeros(3 * 3 * 64, 64, device=dev, dtype=BF), 2, 8, 3)         # odd head count
-    with pytest.raises(Vlt5Error):
         ops.qkv_attn_fwd(torch.zeros(16, 72, device=dev, dtype=BF), torch.zeros(3 * 128, 72, device=dev, dtype=BF), 2, 8, 2)   # d % 64
 
 
@@ -933,7 +931,10 @@ def test_embedding_gather_and_scatter(dev):
     dout = rnd((B, T + 3, d), g)
     dt = torch.zeros(vocab, d, device=dev)
     dout_d = dout.to(dev)
-    check(lib().vlt5_embed_bwd(ptr(ids_d), ptr(dout_d), (T + 3) * d, d, ptr(dt), B, T, d, vocab, 0.0, 0, T + 3, 0,
+    def scratch(b_, t_, d_):
+        return torch.empty(lib().vlt5_embed_bwd_scratch_bytes(b_, t_, d_), dtype=torch.uint8, device=dev)
+    sc = scratch(B, T, d)
+    check(lib().vlt5_embed_bwd(ptr(ids_d), ptr(dout_d), (T + 3) * d, d, ptr(dt), B, T, d, vocab, 0.0, 0, T + 3, 0, ptr(sc),
                                stream_ptr()))
     ref = torch.zeros(vocab, d).index_add_(0, ids.view(-1), dout[:, :T].reshape(-1, d))
     close(dt, ref, 1e-5, 1e-5, "scatter-add")
@@ -945,9 +946,11 @@ def test_embedding_gather_and_scatter(dev):
     ids2[::3, 4] = 7
     ids2_d, dout2 = ids2.to(dev), rnd((B2, T2, d2), g).to(dev)
     runs = []
+    sc2 = scratch(B2, T2, d2)
     for _ in range(4):
         t2 = torch.full((vocab, d2), 0.5, device=dev)
-        check(lib().vlt5_embed_bwd(ptr(ids2_d), ptr(dout2), T2 * d2, d2, ptr(t2), B2, T2, d2, vocab, 0.1, 1234, T2, 0, stream_ptr()))
+        sc2.random_(0, 255)                                     # (stale scratch contents must not matter)
+        check(lib().vlt5_embed_bwd(ptr(ids2_d), ptr(dout2), T2 * d2, d2, ptr(t2), B2, T2, d2, vocab, 0.1, 1234, T2, 0, ptr(sc2), stream_ptr()))
         runs.append(t2.cpu())
     assert all(torch.equal(runs[0], r) for r in runs[1:]), "embedding-gradient scatter must be bit-identical run to run"
     absent = torch.ones(vocab, dtype=torch.bool)
@@ -957,7 +960,7 @@ def test_embedding_gather_and_scatter(dev):
     # (dropout on: compare the row sums' support instead of values -- every present id received something)
     assert bool(((runs[0] - 0.5).abs().sum(1)[~absent] > 0).all())
     t3 = torch.full((vocab, d2), 0.5, device=dev)
-    check(lib().vlt5_embed_bwd(ptr(ids2_d), ptr(dout2), T2 * d2, d2, ptr(t3), B2, T2, d2, vocab, 0.0, 0, T2, 0, stream_ptr()))
+    check(lib().vlt5_embed_bwd(ptr(ids2_d), ptr(dout2), T2 * d2, d2, ptr(t3), B2, T2, d2, vocab, 0.0, 0, T2, 0, ptr(sc2), stream_ptr()))
     close(t3, ref2, 2e-4, 5e-4, "scatter-add with 880 occurrences of one id")     # (f32 sums of 880 terms in another order than index_add_)
 
 

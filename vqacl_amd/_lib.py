@@ -112,7 +112,8 @@ PROTOTYPES = {
     "vlt5_relbias_build": (c_i, [vp, vp, vp, c_i, c_i, c_i, c_i, vp]),
     "vlt5_relbias_bwd": (c_i, [vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_i, c_i, vp]),
     "vlt5_embed_fwd": (c_i, [vp, vp, vp, c_ll, c_ll, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp]),
-    "vlt5_embed_bwd": (c_i, [vp, vp, c_ll, c_ll, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp]),
+    "vlt5_embed_bwd_scratch_bytes": (c_ll, [c_i, c_i, c_i]),
+    "vlt5_embed_bwd": (c_i, [vp, vp, c_ll, c_ll, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, vp]),
     "vlt5_shift_right": (c_i, [vp, vp, c_i, c_i, c_i, c_i, vp]),
     "vlt5_build_mask": (c_i, [vp, vp, c_i, c_i, c_i, c_i, vp]),
     "vlt5_vis_embed_fwd": (c_i, [vp] * 9 + [c_ll, c_ll, vp, vp, c_i, c_i, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),

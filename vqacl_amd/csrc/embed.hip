@@ -31,66 +31,110 @@ __global__ void embed_fwd_kernel(const long long* __restrict__ ids, const float*
 
 // Scatter-add of the token-embedding gradients, DETERMINISTIC: the table row of an id that occurs several times in the batch (the
 // pad id: hundreds of rows) receives its contributions in a fixed order instead of in the order atomics happen to arrive.
-// One workgroup per (token row, 256-column chunk); it acts only if its row is the FIRST occurrence of its id in `ids`.  It then
-// lists every occurrence (blocked scan of the id list + prefix sum, so the list is in row order), wave w sums occurrences
-// w, w+4, w+8, ... in list order, the four partial sums are combined in wave order and the total is added to the table row with
-// plain stores -- no other workgroup of the launch touches that row.  n = B*T <= EMB_MAXN rows (the list: n ints of dynamic LDS).
-constexpr int EMB_MAXN = 12288;
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dout, long long sb, long long st,
-                                                        float* __restrict__ dtable, int B, int T, int d, int vocab, uint32_t thr, uint32_t seed,
-                                                        int drop_rows, int drop_row0) {
-    extern __shared__ int list[];
-    __shared__ int wtot[4];
-    __shared__ float4 part[4][64];
-    const int n = B * T, row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    auto clamp_id = [&](long long v) { return (v < 0 || v >= vocab) ? 0ll : v; };
-    const long long id = clamp_id(ids[row]);
-    const int per = (n + 255) / 256, j0 = tid * per, j1 = min(n, j0 + per);
-    int cnt = 0, earlier = 0;
-    for (int j = j0; j < j1; ++j) {
-        const bool m = clamp_id(ids[j]) == id;
-        cnt += m ? 1 : 0;
-        earlier |= (m && j < row) ? 1 : 0;
+// The sum over the occurrences of an id is a two-level tree with a fixed shape:
+//   index pass, one wave per row: one sweep over the id list gives the row's position in the order sorted by (id, row) -- rows with
+//     a smaller id + earlier rows with the same id (its rank) -- and the number of rows that share its id; sorted[pos] = row.
+//   pass 1, one wave per (row, 256-column chunk): rows with rank % EMB_G == 0 ("leaders") sum the gradient rows of sorted[pos ..
+//     pos + EMB_G) that carry their id, in that order; an id with at most EMB_G occurrences is finished here (added to the table).
+//   pass 2: the first row of an id with more occurrences sums its leaders' partial sums, in order, and adds the total to the table.
+// Every table row is written by exactly one wave of a launch, with plain loads / stores; eight rows are in flight per wave.
+constexpr int EMB_G = 24;
+struct EmbIdx { int pos, rank, cnt, pad; };          // per row: place in the sorted order, rank among the rows of its id, their number
+__device__ __forceinline__ long long emb_clamp(long long v, int vocab) { return (v < 0 || v >= vocab) ? 0ll : v; }
+__device__ __forceinline__ float4 emb_row(const float* __restrict__ dout, long long sb, long long st, int j, int T, int d, int c, uint32_t thr,
+                                          uint32_t seed, float dsc, int drop_rows, int drop_row0) {
+    const int b = j / T, t = j - b * T;
+    float4 g = *reinterpret_cast<const float4*>(dout + b * sb + t * st + c);
+    if (thr) {
+        bool kp[4];
+        drop_keep4(seed, (uint32_t)(((size_t)b * drop_rows + drop_row0 + t) * d + c), thr, kp);
+        g.x = kp[0] ? g.x * dsc : 0.f; g.y = kp[1] ? g.y * dsc : 0.f; g.z = kp[2] ? g.z * dsc : 0.f; g.w = kp[3] ? g.w * dsc : 0.f;
     }
-    if (__syncthreads_or(earlier)) return;               // another row owns this id
-    int incl = cnt;                                       // inclusive prefix over the lanes of a wave, then over the waves
+    return g;
+}
+__global__ __launch_bounds__(64) void embed_index_kernel(const long long* __restrict__ ids, EmbIdx* __restrict__ idx, int* __restrict__ sorted,
+                                                         int n, int vocab) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const long long id = emb_clamp(ids[row], vocab);
+    int less = 0, before = 0, equal = 0;
+    for (int base = 0; base < n; base += 256) {             // four independent loads per lane and round
+        long long v[4];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-    }
-    if (lane == 63) wtot[wave] = incl;
-    __syncthreads();
-    int off = incl - cnt;
-    for (int w = 0; w < wave; ++w) off += wtot[w];
-    const int total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-    for (int j = j0; j < j1; ++j)
-        if (clamp_id(ids[j]) == id) list[off++] = j;
-    __syncthreads();
-    const int c = blockIdx.y * 256 + lane * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float dsc = drop_scale(thr);
-    if (c < d) {
-        for (int k = wave; k < total; k += 4) {
-            const int j = list[k], b = j / T, t = j - b * T;
-            float4 g = *reinterpret_cast<const float4*>(dout + b * sb + t * st + c);
-            if (thr) {
-                bool kp[4];
-                drop_keep4(seed, (uint32_t)(((size_t)b * drop_rows + drop_row0 + t) * d + c), thr, kp);
-                g.x = kp[0] ? g.x * dsc : 0.f; g.y = kp[1] ? g.y * dsc : 0.f; g.z = kp[2] ? g.z * dsc : 0.f; g.w = kp[3] ? g.w * dsc : 0.f;
-            }
-            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        for (int u = 0; u < 4; ++u) v[u] = ids[min(base + u * 64 + lane, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = base + u * 64 + lane;
+            const long long w = emb_clamp(v[u], vocab);
+            less += (j < n && w < id) ? 1 : 0;
+            equal += (j < n && w == id) ? 1 : 0;
+            before += (j < row && w == id) ? 1 : 0;
         }
     }
-    part[wave][lane] = acc;
-    __syncthreads();
-    if (wave == 0 && c < d) {
-        float* dst = dtable + (size_t)id * d + c;
-        float4 o = *reinterpret_cast<const float4*>(dst);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { o.x += part[w][lane].x; o.y += part[w][lane].y; o.z += part[w][lane].z; o.w += part[w][lane].w; }
-        *reinterpret_cast<float4*>(dst) = o;
+    for (int o = 32; o > 0; o >>= 1) {
+        less += __shfl_xor(less, o, 64); equal += __shfl_xor(equal, o, 64); before += __shfl_xor(before, o, 64);
     }
+    if (lane == 0) {
+        idx[row].pos = less + before; idx[row].rank = before; idx[row].cnt = equal; idx[row].pad = 0;
+        sorted[less + before] = row;
+    }
+}
+__global__ __launch_bounds__(64) void embed_bwd_pass1_kernel(const float* __restrict__ dout, long long sb, long long st, const EmbIdx* __restrict__ idx,
+                                                             const int* __restrict__ sorted, const long long* __restrict__ ids,
+                                                             float* __restrict__ partial, float* __restrict__ dtable, int T, int d, int vocab,
+                                                             uint32_t thr, uint32_t seed, int drop_rows, int drop_row0) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const EmbIdx e = idx[row];
+    if (e.rank % EMB_G != 0) return;
+    const int cnt = min(EMB_G, e.cnt - e.rank);
+    const int mine = lane < cnt ? sorted[e.pos + lane] : row;          // this group's rows, in order
+    const int c = blockIdx.y * 256 + lane * 4;
+    const float dsc = drop_scale(thr);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < cnt; k += 8) {
+        float4 g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = __shfl(mine, min(k + u, cnt - 1), 64);
+            g[u] = (k + u < cnt && c < d) ? emb_row(dout, sb, st, j, T, d, c, thr, seed, dsc, drop_rows, drop_row0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
+    }
+    if (c >= d) return;
+    if (e.cnt <= EMB_G) {                                     // the whole id: finish it here
+        float* dst = dtable + (size_t)emb_clamp(ids[row], vocab) * d + c;
+        float4 o = *reinterpret_cast<const float4*>(dst);
+        o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+        *reinterpret_cast<float4*>(dst) = o;
+    } else {
+        *reinterpret_cast<float4*>(partial + (size_t)row * d + c) = acc;
+    }
+}
+__global__ __launch_bounds__(64) void embed_bwd_pass2_kernel(const EmbIdx* __restrict__ idx, const int* __restrict__ sorted,
+                                                             const long long* __restrict__ ids, const float* __restrict__ partial,
+                                                             float* __restrict__ dtable, int d, int vocab) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const EmbIdx e = idx[row];
+    if (e.rank != 0 || e.cnt <= EMB_G) return;
+    const int c = blockIdx.y * 256 + lane * 4;
+    if (c >= d) return;
+    const int nlead = (e.cnt + EMB_G - 1) / EMB_G;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < nlead; k += 8) {
+        float4 g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = sorted[e.pos + min(k + u, nlead - 1) * EMB_G];
+            g[u] = k + u < nlead ? *reinterpret_cast<const float4*>(partial + (size_t)j * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
+    }
+    float* dst = dtable + (size_t)emb_clamp(ids[row], vocab) * d + c;
+    float4 o = *reinterpret_cast<const float4*>(dst);
+    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+    *reinterpret_cast<float4*>(dst) = o;
 }
 
 __global__ void shift_right_kernel(const long long* __restrict__ labels, long long* __restrict__ out, int B, int T,
@@ -338,12 +382,28 @@ extern "C" int vlt5_embed_fwd(const long long* ids, const float* table, float* o
     LAUNCH_CHECK();
     return VLT5_OK;
 }
+extern "C" long long vlt5_embed_bwd_scratch_bytes(int B, int T, int d) {
+    if (B < 1 || T < 1 || d < 1) return -1;
+    const long long n = (long long)B * T;
+    return (n * d * 4 + 255) / 256 * 256 + n * 16 + n * 4;        // leaders' partial sums, per-row index records, the sorted order
+}
 extern "C" int vlt5_embed_bwd(const long long* ids, const float* dout, long long sb, long long st, float* dtable, int B, int T,
-                              int d, int vocab, float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* stream) {
-    if (!ids || !dout || !dtable || B <= 0 || T <= 0 || (long long)B * T > EMB_MAXN) return VLT5_ERR_ARG;
-    if ((d & 3) || (sb & 3) || (st & 3)) return VLT5_ERR_ALIGN;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * T, (d + 255) / 256), dim3(256), (size_t)B * T * sizeof(int), ST, ids, dout, sb, st, dtable, B, T, d, vocab,
-                       thr_of(drop_p), drop_seed, drop_rows, drop_row0);
+                              int d, int vocab, float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* scratch,
+                              void* stream) {
+    if (!ids || !dout || !dtable || !scratch || B <= 0 || T <= 0) return VLT5_ERR_ARG;
+    if ((d & 3) || (sb & 3) || (st & 3) || (((uintptr_t)scratch) & 15)) return VLT5_ERR_ALIGN;
+    const long long n = (long long)B * T;
+    float* partial = (float*)scratch;
+    EmbIdx* idx = (EmbIdx*)((char*)scratch + (n * d * 4 + 255) / 256 * 256);
+    int* sorted = (int*)(idx + n);
+    const dim3 grid((unsigned)n, (d + 255) / 256);
+    hipLaunchKernelGGL(embed_index_kernel, dim3((unsigned)n), dim3(64), 0, ST, ids, idx, sorted, (int)n, vocab);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(embed_bwd_pass1_kernel, grid, dim3(64), 0, ST, dout, sb, st, (const EmbIdx*)idx, (const int*)sorted, ids, partial, dtable,
+                       T, d, vocab, thr_of(drop_p), drop_seed, drop_rows, drop_row0);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(embed_bwd_pass2_kernel, grid, dim3(64), 0, ST, (const EmbIdx*)idx, (const int*)sorted, ids, (const float*)partial, dtable, d,
+                       vocab);
     LAUNCH_CHECK();
     return VLT5_OK;
 }

@@ -43,17 +43,27 @@ struct QkvAttnArgs {
     const float* rs_part; int rs_n; float rs_eps; float* rstd_out;
 };
 
-constexpr int FBM = 128, FBN = 384, FWM = 2, FWN = 4, FNT = 512;
-constexpr int FTM = FBM / FWM, FTN = FBN / FWN;          // 64 x 96 per wave
-constexpr int FFM = FTM / 16, FFN_ = FTN / 16;           // 4 x 6 fragments
-constexpr int A_BYTES = FBM * BK * 2, B_BYTES = FBN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;   // 16 + 48 = 64 KB
-constexpr int PA = FBM * 8 / FNT, PB = FBN * 8 / FNT, LPT = PA + PB;                             // 2 + 6 DMA pieces per wave per k-tile
-constexpr int FUSED_LDS = 2 * STAGE_BYTES;
-static_assert(12 * TILE_BYTES <= FUSED_LDS, "the Q/K/V tiles of 2 samples x 2 heads overlay the retired stages");
+// NH = heads per workgroup.  NH = 2: 8 waves as 2 (samples) x 4, a 128 x 384 projection tile, 128 KB of LDS (one workgroup per CU).
+// NH = 1: 4 waves as 2 x 2, a 128 x 192 tile, 80 KB of LDS: TWO workgroups share a CU, so the softmax / dropout / store phases of
+// one (VALU and memory work with the matrix pipe idle) run under the MFMA main loop of the other.
+template <int NH>
+struct FusedGeo {
+    static constexpr int FBM = 128, FBN = 192 * NH, FWM = 2, FWN = 2 * NH, FNT = 256 * NH;
+    static constexpr int FTM = FBM / FWM, FTN = FBN / FWN;          // 64 x 96 per wave
+    static constexpr int FFM = FTM / 16, FFN_ = FTN / 16;           // 4 x 6 fragments
+    static constexpr int A_BYTES = FBM * BK * 2, B_BYTES = FBN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;   // 16 + 48 (24) KB
+    static constexpr int PA = FBM * 8 / FNT, PB = FBN * 8 / FNT, LPT = PA + PB;                             // DMA pieces per wave per k-tile
+    static constexpr int FUSED_LDS = 2 * STAGE_BYTES;
+    static_assert(6 * NH * TILE_BYTES <= FUSED_LDS, "the Q/K/V tiles of 2 samples x NH heads overlay the retired stages");
+};
 
 // TL: debug build of the same kernel that records the shader clock of wave 0 at the phase boundaries (vlt5dbg_qkv_attn_timeline)
-template <bool TL>
-__global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsigned long long* tl_out) {
+template <bool TL, int NH>
+__device__ __forceinline__ void qkv_attn_fwd_body(QkvAttnArgs p, unsigned long long* tl_out) {
+    using G = FusedGeo<NH>;
+    constexpr int FBM = G::FBM, FBN = G::FBN, FWN = G::FWN, FNT = G::FNT, FTM = G::FTM, FTN = G::FTN, FFM = G::FFM, FFN_ = G::FFN_;
+    constexpr int A_BYTES = G::A_BYTES, STAGE_BYTES = G::STAGE_BYTES, PA = G::PA, PB = G::PB, LPT = G::LPT;
+    (void)FBM; (void)FBN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long tl[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto stamp = [&](int i) __attribute__((always_inline)) { if (TL && threadIdx.x == 0) tl[i] = __builtin_readcyclecounter(); };
@@ -61,7 +71,7 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / FWN, wn = wave % FWN;
     const int lrow = lane & 15, lg = lane >> 4;
-    const int HP = p.H >> 1, inner = p.H * 64;
+    const int HP = p.H / NH, inner = p.H * 64;
     // XCD-aware order: workgroup b runs on XCD b % 8; every XCD gets one contiguous run of (sample pair, head pair) tiles, head
     // pair fastest, so the A rows of a sample pair are fetched into ONE L2 and the 6 weight slices (3.5 MB) stay resident in each
     const int ntiles = gridDim.x;
@@ -70,8 +80,8 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
         const int b = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = b & 7, loc = b >> 3;
         tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int b0 = (tile_id / HP) * 2, h0 = (tile_id % HP) * 2;
-    const int pi = wave >> 1, cs = pi >> 1, chh = pi & 1;          // phase 3 roles: two waves per (sample, head)
+    const int b0 = (tile_id / HP) * 2, h0 = (tile_id % HP) * NH;
+    const int pi = wave >> 1, cs = NH == 2 ? pi >> 1 : pi, chh = NH == 2 ? pi & 1 : 0;          // phase 3 roles: two waves per (sample, head)
     const int cb = min(b0 + cs, p.B - 1), ch = h0 + chh;
 
     // per-lane source of each DMA piece at k = 0 (the swizzle of the LDS image is applied to the SOURCE chunk: gemm_kernel.h)
@@ -85,7 +95,7 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         const int c = tid + i * FNT, row = c >> 3, kc = (c & 7) ^ (row & 7);
-        const int grow = (row >> 7) * inner + h0 * 64 + (row & 127);
+        const int grow = (row / (64 * NH)) * inner + h0 * 64 + (row % (64 * NH));
         src[PA + i] = p.wqkv + (size_t)grow * p.d + kc * 8;
     }
     // folded norm: a wave's 64 rows are spread over its lanes (row wm*64 + lane); the partial sums of squares are requested first
@@ -201,12 +211,12 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
 #pragma unroll
     for (int i = 0; i < FFM; ++i) rsc[i] = p.rs_part ? __shfl(rs_own, i * 16 + lrow, 64) : 1.f;
     auto tile = [&](int s, int hh, int part) __attribute__((always_inline)) -> bf16_t* {
-        return reinterpret_cast<bf16_t*>(smem + ((s * 2 + hh) * 3 + part) * TILE_BYTES);
+        return reinterpret_cast<bf16_t*>(smem + ((s * NH + hh) * 3 + part) * TILE_BYTES);
     };
 #pragma unroll
     for (int j = 0; j < FFN_; ++j) {
         const int n = wn * FTN + j * 16;                       // 16 | 64: a fragment lies inside one (part, head) tile
-        bf16_t* tl = tile(wm, (n >> 6) & 1, n >> 7) + (n & 63) + lg * 4;
+        bf16_t* tl = tile(wm, NH == 2 ? (n >> 6) & 1 : 0, n / (64 * NH)) + (n & 63) + lg * 4;
 #pragma unroll
         for (int i = 0; i < FFM; ++i) {
             uint2 pk;
@@ -218,16 +228,21 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
     stamp(10);
     __syncthreads();
     stamp(4);
-    // q | k | v rows to HBM (saved for the backward): 12 tiles x S rows x 128 bytes; 8 lanes per row, 64 rows per pass
+    // q | k | v rows to HBM (saved for the backward): 6 * NH tiles x S rows x 128 bytes; 8 lanes per row, FNT / 8 rows per pass
     {
-        const int t = tid >> 3, ch8 = (tid & 7) * 8;
-        if (t < p.S) {
+        constexpr int RPP = FNT / 8;                            // rows per pass: 64 (8 waves) / 32 (4 waves)
+        const int ch8 = (tid & 7) * 8;
 #pragma unroll
-            for (int ti = 0; ti < 12; ++ti) {
-                const int s = ti / 6, hh = (ti / 3) & 1, part = ti % 3;
-                if (b0 + s < p.B) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(smem + ti * TILE_BYTES + (t * TS + ch8) * 2);
-                    *reinterpret_cast<uint4*>(p.qkv + ((size_t)(b0 + s) * p.S + t) * (3 * inner) + part * inner + (h0 + hh) * 64 + ch8) = v;
+        for (int t0 = 0; t0 < 64; t0 += RPP) {
+            const int t = t0 + (tid >> 3);
+            if (t < p.S) {
+#pragma unroll
+                for (int ti = 0; ti < 6 * NH; ++ti) {
+                    const int s = ti / (3 * NH), hh = (ti / 3) % NH, part = ti % 3;
+                    if (b0 + s < p.B) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(smem + ti * TILE_BYTES + (t * TS + ch8) * 2);
+                        *reinterpret_cast<uint4*>(p.qkv + ((size_t)(b0 + s) * p.S + t) * (3 * inner) + part * inner + (h0 + hh) * 64 + ch8) = v;
+                    }
                 }
             }
         }
@@ -254,12 +269,45 @@ __global__ __launch_bounds__(FNT) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsign
     }
 }
 
+// one head per workgroup: 4 waves, registers capped for two waves per SIMD (two workgroups per CU); two heads: 8 waves
+template <bool TL>
+__global__ __launch_bounds__(256, 2) void qkv_attn_fwd_kernel(QkvAttnArgs p, unsigned long long* tl_out) { qkv_attn_fwd_body<TL, 1>(p, tl_out); }
+template <bool TL>
+__global__ __launch_bounds__(512) void qkv_attn_fwd2_kernel(QkvAttnArgs p, unsigned long long* tl_out) { qkv_attn_fwd_body<TL, 2>(p, tl_out); }
+
 unsigned long long* g_tl_buf = nullptr;      // vlt5dbg_qkv_attn_timeline: device buffer of 8 x u64 per workgroup, or null
 
-}  // namespace
 
 // q|k|v projection + attention core of one encoder self-attention (the kernel above).  Shapes: d_kv = 64, H even, S <= 64,
 // d_model a multiple of 64; the strides in `core` must describe `qkv` ([B, S, 3*H*64], q | k | v).
+template <int NH, class KF, class KT>
+static int qkv_attn_dispatch(const QkvAttnArgs& a, KF kernel, KT kernel_tl, void* stream) {
+    using G = FusedGeo<NH>;
+    static std::atomic<unsigned long long> optin_a{0}, optin_b{0};      // devices on which the kernels may use FUSED_LDS bytes of LDS
+    {
+        int rc = vlt5_lds_optin(reinterpret_cast<const void*>(kernel), G::FUSED_LDS, optin_a);
+        if (rc) return rc;
+        rc = vlt5_lds_optin(reinterpret_cast<const void*>(kernel_tl), G::FUSED_LDS, optin_b);
+        if (rc) return rc;
+    }
+    const int inner = a.H * 64;
+    const int grid = ((a.B + 1) / 2) * (a.H / NH);
+    vlt5gemm::TimingState& tm = vlt5_gemm_timing_state;           // bench.py's in-situ roofline covers this MFMA kernel too
+    if (g_tl_buf) hipLaunchKernelGGL(kernel_tl, dim3(grid), dim3(G::FNT), G::FUSED_LDS, (hipStream_t)stream, a, g_tl_buf);
+    else if (tm.on && tm.rec.size() < tm.cap) {
+        const size_t i = tm.rec.size();
+        vlt5_gemm_timing_rec r;
+        r.M = a.B * a.S; r.N = 3 * inner; r.K = a.d; r.batch = 1; r.tile_m = G::FBM; r.tile_n = 384; r.a_kmajor = 0; r.b_kmajor = 0;
+        r.splits = 1; r.workgroups = grid; r.out_f32 = 0; r.ms = 0.f; r.M2 = 0; r.N2 = 0; r.K2 = 0; r.batch2 = 0;
+        tm.rec.push_back(r);
+        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(G::FNT), G::FUSED_LDS, (hipStream_t)stream, tm.ev[2 * i], tm.ev[2 * i + 1], 0, a,
+                              (unsigned long long*)nullptr);
+    } else hipLaunchKernelGGL(kernel, dim3(grid), dim3(G::FNT), G::FUSED_LDS, (hipStream_t)stream, a, (unsigned long long*)nullptr);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+}  // namespace
+
 static int qkv_attn_launch(const void* xn_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model,
                            const float* norm_partials, int norm_nparts, float norm_eps, float* norm_rstd_out, void* stream);
 extern "C" int vlt5_qkv_attn_fwd(const void* xn_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model,
@@ -277,7 +325,7 @@ extern "C" int vlt5_qkv_attn_fwd_norm(const void* xw_bf16, const void* wqkv_bf16
 static int qkv_attn_launch(const void* xn_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model,
                            const float* norm_partials, int norm_nparts, float norm_eps, float* norm_rstd_out, void* stream) {
     if (!xn_bf16 || !wqkv_bf16 || !qkv_bf16 || !core || !core->ctx) return VLT5_ERR_ARG;
-    if (core->dk != 64 || (core->H & 1) || core->Tq != core->Tk || core->Tq < 1 || core->Tq > 64 || core->B < 1 || d_model < 64) return VLT5_ERR_ARG;
+    if (core->dk != 64 || core->Tq != core->Tk || core->Tq < 1 || core->Tq > 64 || core->B < 1 || d_model < 64) return VLT5_ERR_ARG;
     if (d_model & 63) return VLT5_ERR_ALIGN;
     const int inner = core->H * 64, S = core->Tq;
     const bf16_t* base = (const bf16_t*)qkv_bf16;
@@ -299,27 +347,12 @@ static int qkv_attn_launch(const void* xn_bf16, const void* wqkv_bf16, void* qkv
     t.drop_thr = core->drop_p > 0.f ? drop_thr16(core->drop_p) : 0u; t.drop_seed = core->drop_seed;
     t.d_ctx = nullptr; t.do_sb = t.do_st = 0; t.dq = t.dk_ = t.dv = nullptr;
     t.dq_sb = t.dq_st = t.dk_sb = t.dk_st = t.dv_sb = t.dv_st = 0; t.dbias = nullptr;
-    static std::atomic<unsigned long long> optin_a{0}, optin_b{0};      // devices on which the kernels may use FUSED_LDS bytes of LDS
-    {
-        int rc = vlt5_lds_optin(reinterpret_cast<const void*>(&qkv_attn_fwd_kernel<false>), FUSED_LDS, optin_a);
-        if (rc) return rc;
-        rc = vlt5_lds_optin(reinterpret_cast<const void*>(&qkv_attn_fwd_kernel<true>), FUSED_LDS, optin_b);
-        if (rc) return rc;
-    }
-    const int grid = ((a.B + 1) / 2) * (a.H / 2);
-    vlt5gemm::TimingState& tm = vlt5_gemm_timing_state;           // bench.py's in-situ roofline covers this MFMA kernel too
-    if (g_tl_buf) hipLaunchKernelGGL(qkv_attn_fwd_kernel<true>, dim3(grid), dim3(FNT), FUSED_LDS, (hipStream_t)stream, a, g_tl_buf);
-    else if (tm.on && tm.rec.size() < tm.cap) {
-        const size_t i = tm.rec.size();
-        vlt5_gemm_timing_rec r;
-        r.M = a.B * a.S; r.N = 3 * inner; r.K = a.d; r.batch = 1; r.tile_m = FBM; r.tile_n = FBN; r.a_kmajor = 0; r.b_kmajor = 0;
-        r.splits = 1; r.workgroups = grid; r.out_f32 = 0; r.ms = 0.f; r.M2 = 0; r.N2 = 0; r.K2 = 0; r.batch2 = 0;
-        tm.rec.push_back(r);
-        hipExtLaunchKernelGGL(qkv_attn_fwd_kernel<false>, dim3(grid), dim3(FNT), FUSED_LDS, (hipStream_t)stream, tm.ev[2 * i], tm.ev[2 * i + 1],
-                              0, a, (unsigned long long*)nullptr);
-    } else hipLaunchKernelGGL(qkv_attn_fwd_kernel<false>, dim3(grid), dim3(FNT), FUSED_LDS, (hipStream_t)stream, a, (unsigned long long*)nullptr);
-    LAUNCH_CHECK();
-    return VLT5_OK;
+    // one head per workgroup (4 waves, two workgroups per CU) or two (8 waves, one per CU): VLT5_FUSED_HEADS = 1 / 2 is an
+    // experiment knob; an odd number of heads can only run the one-head kernel
+    static const int heads_env = getenv("VLT5_FUSED_HEADS") ? atoi(getenv("VLT5_FUSED_HEADS")) : 2;
+    const int nh = (heads_env == 2 && !(a.H & 1)) ? 2 : 1;
+    if (nh == 2) return qkv_attn_dispatch<2>(a, &qkv_attn_fwd2_kernel<false>, &qkv_attn_fwd2_kernel<true>, stream);
+    return qkv_attn_dispatch<1>(a, &qkv_attn_fwd_kernel<false>, &qkv_attn_fwd_kernel<true>, stream);
 }
 
 // The whole encoder self-attention sublayer forward (SURVEY 8(b) `vlt5_enc_attn_fwd`; HF T5LayerSelfAttention.forward as called from
