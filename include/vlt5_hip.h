@@ -294,6 +294,27 @@ int vlt5_proto_retrieve(const float* protos, const float* pool, long long* idx, 
 /* memory_loss (nextqa/modeling_t5_nextqa.py:544-555): out[0] = mean_b ||pool_b - (onehot P)_b||^2 */
 int vlt5_proto_memory_loss(const float* pool, const float* onehot, const float* protos, float* out, int B, int C, int d, void* stream);
 
+/* The whole head of one forward in three launches (token pooling; one workgroup per prototype row: class mean of the batch, per-task
+ * state update, tanh-normalised copy; retrieval of both heads) -- the same arithmetic as vlt5_proto_pool / _class_mean / _update /
+ * _retrieve, bit for bit.  hidden f32 [B, >= S, d] (sample stride hidden_sb): the encoder output; rows [0, split) pool to Q, [split, S)
+ * to V.  update = 1: calculate_current_prototype + update_prototype with the one-hot labels (first / task / qmem* as for
+ * vlt5_proto_update; the per-task control flow stays with the caller); update = 0: retrieval from the current prototypes only.
+ * The retrieved Q / V prototype of sample b is written to out_f32 + b*out_sb (+ d for V) and out_bf16 + b*out_sb_bf16 (+ d) -- rows
+ * S, S+1 of the decoder's memory -- either may be NULL.  scratch: f32 [(CQ + CV) * d]. */
+typedef struct {
+    const float* hidden; long long hidden_sb; int B, S, d, split;
+    float *poolQ, *poolV;                       /* out: [B, d] each */
+    const float *onehotQ, *onehotV;             /* [B, CQ], [B, CV] (update only) */
+    float *Qproto, *Vproto, *Qnum, *Vnum;       /* state: [CQ, d], [CV, d], [CQ], [CV] */
+    float* qmem; int qmem_initialised, first, task, update;
+    float alpha, beta;
+    int CQ, CV;
+    long long *idxQ, *idxV;                     /* out: [B] argmax indices */
+    float* out_f32; long long out_sb; void* out_bf16; long long out_sb_bf16;
+    float* scratch;
+} vlt5_proto_head_desc;
+int vlt5_proto_head_fwd(const vlt5_proto_head_desc* h, void* stream);
+
 /* ---- optimizer: clip_grad_norm_(5) + HF AdamW (src/vqacl.py:466-487, src/trainer_base.py:187-190) */
 /* partial: vlt5_sqnorm_blocks(n) floats.  accum_total: 0 total_sq = sum, 1 total_sq += sum, 2 leave only the block partials (no
  * reduction: several ranges are then summed by one vlt5_gnorm_finish over the concatenated partials) */

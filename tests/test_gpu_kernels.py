@@ -869,6 +869,27 @@ def test_prototype_head_vs_reference_golden(dev):
         assert torch.equal(iv.cpu(), G[f"s{step}_idxV"]), f"V indices step {step}"
         close(ext[:, S], G[f"s{step}_retQ"], 1e-6, 1e-6, "retrieved Q row")
         close(ext16[:, S + 1], G[f"s{step}_retV"], 1e-2, 1e-2, "retrieved V row bf16")
+        # the fused head (vlt5_proto_head_fwd: pooling + per-row update + both retrievals in three launches) walks the same sequence
+        # on a second state and must reproduce the separate kernels bit for bit: pooled features, prototypes, counts, memory
+        # tensors, integer indices and the rows written into the decoder's memory
+        if step == 0:
+            fused = PrototypeHead(10, 80, 768, dev)
+        ext2 = torch.zeros(B, S + 2, d, device=dev)
+        ext2[:, :S] = h
+        ext2_16 = torch.zeros(B, S + 2, d, device=dev, dtype=BF)
+        fq, fv, fiq, fiv = fused.forward(ext2, ext2_16, S, 20, ql, cl, task, float(G["alpha"]), float(G["beta"]), update=True)
+        assert torch.equal(fq, pq) and torch.equal(fv, pv)
+        assert torch.equal(fused.Q_prototype, head.Q_prototype) and torch.equal(fused.V_prototype, head.V_prototype), f"step {step}"
+        assert torch.equal(fused.Q_prototype_num, head.Q_prototype_num) and torch.equal(fused.V_prototype_num, head.V_prototype_num)
+        assert fused.seen_tasks == head.seen_tasks and set(fused.Q_task_mem_proto) == set(head.Q_task_mem_proto)
+        for t_ in head.Q_task_mem_proto:
+            assert torch.equal(fused.Q_task_mem_proto[t_], head.Q_task_mem_proto[t_]), f"memory tensor of task {t_}, step {step}"
+        assert torch.equal(fiq, iq) and torch.equal(fiv, iv)
+        assert torch.equal(ext2, ext) and torch.equal(ext2_16, ext16)
+        # retrieval only (evaluation / proto_update=False): state untouched, same indices
+        q_before = fused.Q_prototype.clone()
+        _, _, eiq, eiv = fused.forward(ext2, ext2_16, S, 20, update=False)
+        assert torch.equal(eiq, iq) and torch.equal(eiv, iv) and torch.equal(fused.Q_prototype, q_before)
 
 
 @pytest.mark.parametrize("tag,d,fd,vocab", [("tiny", 64, 64, 400), ("mid", 128, 256, 512)])

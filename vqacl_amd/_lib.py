@@ -57,6 +57,14 @@ class SkinnyDesc(C.Structure):
                 ("relu", c_i), ("drop_p", c_f), ("drop_seed", c_u32), ("resid", vp), ("ldr", c_i), ("panel_rows", c_i), ("chunk_cols", c_i)]
 
 
+class ProtoHeadDesc(C.Structure):
+    _fields_ = [("hidden", vp), ("hidden_sb", c_ll), ("B", c_i), ("S", c_i), ("d", c_i), ("split", c_i), ("poolQ", vp), ("poolV", vp),
+                ("onehotQ", vp), ("onehotV", vp), ("Qproto", vp), ("Vproto", vp), ("Qnum", vp), ("Vnum", vp), ("qmem", vp),
+                ("qmem_initialised", c_i), ("first", c_i), ("task", c_i), ("update", c_i), ("alpha", c_f), ("beta", c_f),
+                ("CQ", c_i), ("CV", c_i), ("idxQ", vp), ("idxV", vp), ("out_f32", vp), ("out_sb", c_ll), ("out_bf16", vp),
+                ("out_sb_bf16", c_ll), ("scratch", vp)]
+
+
 class GemmTimingRec(C.Structure):
     _fields_ = [("M", c_i), ("N", c_i), ("K", c_i), ("batch", c_i), ("tile_m", c_i), ("tile_n", c_i), ("a_kmajor", c_i),
                 ("b_kmajor", c_i), ("splits", c_i), ("workgroups", c_i), ("out_f32", c_i), ("ms", c_f), ("M2", c_i), ("N2", c_i), ("K2", c_i), ("batch2", c_i)]
@@ -130,6 +138,7 @@ PROTOTYPES = {
     "vlt5_proto_update": (c_i, [vp] * 9 + [c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, vp]),
     "vlt5_proto_retrieve": (c_i, [vp, vp, vp, vp, c_ll, vp, c_ll, vp, c_i, c_i, c_i, vp]),
     "vlt5_proto_memory_loss": (c_i, [vp, vp, vp, vp, c_i, c_i, c_i, vp]),
+    "vlt5_proto_head_fwd": (c_i, [C.POINTER(ProtoHeadDesc), vp]),
     "vlt5_sqnorm": (c_i, [vp, c_ll, vp, vp, c_i, vp]),
     "vlt5_gnorm_finish": (c_i, [vp, c_ll, vp, C.POINTER(c_ll), C.POINTER(c_ll), c_i, vp, vp, vp]),
     "vlt5_gnorm_slots": (c_ll, [C.POINTER(Config)]),

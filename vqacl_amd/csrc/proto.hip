@@ -185,6 +185,131 @@ __global__ __launch_bounds__(256) void memory_loss_kernel(const float* __restric
     if (threadIdx.x == 0) out[0] = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)B;
 }
 
+// ---- the fused head (vlt5_proto_head_fwd): per class row, everything between the pooled features and the retrieval -----------
+// One workgroup per prototype row (CQ question rows, then CV category rows): the class mean of the batch (calculate_current_prototype),
+// the per-task state update of that row (update_prototype) and its tanh-normalised copy for the cosine retrieval -- the same
+// arithmetic, in the same order, as class_mean_kernel + proto_update_kernel + proto_normalize_kernel (bit-identical results), in
+// one launch instead of five.  update == 0 (evaluation, proto_update=False): only the normalised copy.
+struct HeadArgs {
+    const float *poolQ, *poolV, *onehotQ, *onehotV;
+    float *Qp, *Vp, *Qnum, *Vnum, *qmem, *AnQ, *AnV;
+    int qmem_init, first, task, update;
+    float alpha, beta;
+    int B, CQ, CV, d;
+};
+__global__ __launch_bounds__(256) void proto_row_kernel(HeadArgs a) {
+    extern __shared__ float wgt[];                 // [B] one-hot column of this class
+    __shared__ float sh[4];
+    const bool isQ = (int)blockIdx.x < a.CQ;
+    const int cls = isQ ? blockIdx.x : blockIdx.x - a.CQ, C = isQ ? a.CQ : a.CV, d = a.d;
+    const float* pool = isQ ? a.poolQ : a.poolV;
+    const float* onehot = isQ ? a.onehotQ : a.onehotV;
+    float* P = (isQ ? a.Qp : a.Vp) + (size_t)cls * d;
+    float* An = (isQ ? a.AnQ : a.AnV) + (size_t)cls * d;
+    if (a.update) {
+        for (int b = threadIdx.x; b < a.B; b += blockDim.x) wgt[b] = onehot[(size_t)b * C + cls];
+        __syncthreads();
+        float n = 0.f;
+        for (int b = 0; b < a.B; ++b) n += wgt[b];
+        const float div = n <= 0.f ? 1.f : n;
+        if (threadIdx.x == 0) {
+            float* num = isQ ? a.Qnum : a.Vnum;
+            num[cls] = a.first ? n : num[cls] + n;
+        }
+        for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+            for (int b = 0; b < a.B; ++b) {
+                const float w = wgt[b];
+                const float4 v = *reinterpret_cast<const float4*>(pool + (size_t)b * d + c);
+                s.x += w * v.x; s.y += w * v.y; s.z += w * v.z; s.w += w * v.w;
+            }
+            const float cur[4] = {s.x / div, s.y / div, s.z / div, s.w / div};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = cls * d + c + e;
+                if (!isQ) {
+                    P[c + e] = a.first ? cur[e] : a.beta * P[c + e] + (1.f - a.beta) * cur[e];
+                } else if (a.first) {
+                    if (a.task == 0 || cls == a.task) P[c + e] = cur[e];
+                } else if (a.task == 0) {
+                    P[c + e] = cur[e];
+                } else {
+                    const float now = (cls == a.task) ? 0.f : cur[e];
+                    float mem = a.qmem_init ? a.alpha * a.qmem[i] + (1.f - a.alpha) * now : now;
+                    if (cls == a.task) mem = cur[e];
+                    a.qmem[i] = mem;
+                    P[c + e] = mem;
+                }
+            }
+        }
+        __syncthreads();                                // this workgroup's row of P is complete (same threads re-read their own stores
+    }                                                   // below only through the strided loop: make every store visible first)
+    float s = 0.f;
+    for (int c = threadIdx.x; c < d; c += 256) { float t = tanhf(P[c]); s += t * t; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float inv = 1.0f / fmaxf(sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3])), 1e-12f);
+    for (int c = threadIdx.x; c < d; c += 256) An[c] = tanhf(P[c]) * inv;
+}
+
+// retrieval of both heads in one launch: blockIdx.y = 0 question prototypes -> memory row S, 1 category prototypes -> row S + 1
+struct Retrieve2 { const float *protos[2], *An[2], *pool[2]; long long* idx[2]; float* out_f32[2]; bf16_t* out_bf16[2]; int C[2]; };
+__global__ __launch_bounds__(256) void retrieve2_kernel(Retrieve2 r, long long sb, long long sb16, int B, int d) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int h = blockIdx.y, C = r.C[h];
+    float* tx = lds;
+    float* sim = lds + d;
+    __shared__ float part[4];
+    __shared__ int best_sh;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* x = r.pool[h] + (size_t)b * d;
+    const float* An = r.An[h];
+    float s = 0.f;
+    for (int c = threadIdx.x; c < d; c += 256) { float t = tanhf(x[c]); tx[c] = t; s += t * t; }
+    s = wave_sum(s);
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    const float nb = fmaxf(sqrtf((part[0] + part[1]) + (part[2] + part[3])), 1e-12f);
+    for (int cls0 = wave; cls0 < C; cls0 += 16) {
+        float dot[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 t = *reinterpret_cast<const float4*>(tx + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cls = cls0 + 4 * u;
+                if (cls < C) {
+                    const float4 q = *reinterpret_cast<const float4*>(An + (size_t)cls * d + c);
+                    dot[u] += (q.x * t.x + q.y * t.y) + (q.z * t.z + q.w * t.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cls = cls0 + 4 * u;
+            const float v = wave_sum(dot[u]);
+            if (lane == 0 && cls < C) sim[cls] = v / nb;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int best = 0;
+        float bv = sim[0];
+        for (int cls = 1; cls < C; ++cls)
+            if (sim[cls] > bv) { bv = sim[cls]; best = cls; }
+        best_sh = best;
+        r.idx[h][b] = best;
+    }
+    __syncthreads();
+    const float* sel = r.protos[h] + (size_t)best_sh * d;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        const float v = sel[c];
+        if (r.out_f32[h]) r.out_f32[h][b * sb + c] = v;
+        if (r.out_bf16[h]) r.out_bf16[h][b * sb16 + c] = f32_to_bf16(v);
+    }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -233,6 +358,39 @@ extern "C" int vlt5_proto_memory_loss(const float* pool, const float* onehot, co
                                       void* stream) {
     if (!pool || !onehot || !protos || !out) return VLT5_ERR_ARG;
     hipLaunchKernelGGL(memory_loss_kernel, dim3(1), dim3(256), 0, ST, pool, onehot, protos, out, B, C, d);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+
+// The whole SS/SI prototype head of one forward (SURVEY 8(b) `vlt5_proto_head_fwd`; VL-T5/src/modeling_t5_our.py:583-615 with
+// calculate_current_prototype :500-511, update_prototype :465-498, cosine_similarity_multi :434-462) in three launches: token
+// pooling, one workgroup per prototype row (class mean of the batch + state update + normalised copy), retrieval of both heads.
+// The per-task control flow (first batch of a task, which memory tensor) stays with the caller, as plain arguments.
+extern "C" int vlt5_proto_head_fwd(const vlt5_proto_head_desc* h, void* stream) {
+    if (!h || !h->hidden || !h->poolQ || !h->poolV || !h->Qproto || !h->Vproto || !h->scratch || !h->idxQ || !h->idxV) return VLT5_ERR_ARG;
+    if (h->B <= 0 || h->S <= 0 || h->CQ <= 0 || h->CV <= 0 || h->split <= 0) return VLT5_ERR_ARG;
+    if ((h->d & 3) || h->d > 2048 || (h->hidden_sb & 3)) return VLT5_ERR_ALIGN;
+    if (h->update) {
+        if (!h->onehotQ || !h->onehotV || !h->Qnum || !h->Vnum || h->task < 0 || h->task >= h->CQ) return VLT5_ERR_ARG;
+        if (!h->first && h->task != 0 && !h->qmem) return VLT5_ERR_ARG;
+    }
+    int rc = vlt5_proto_pool(h->hidden, h->hidden_sb, h->B, h->S, h->d, h->split, h->poolQ, h->poolV, stream);
+    if (rc) return rc;
+    HeadArgs a;
+    a.poolQ = h->poolQ; a.poolV = h->poolV; a.onehotQ = h->onehotQ; a.onehotV = h->onehotV;
+    a.Qp = h->Qproto; a.Vp = h->Vproto; a.Qnum = h->Qnum; a.Vnum = h->Vnum; a.qmem = h->qmem;
+    a.AnQ = h->scratch; a.AnV = h->scratch + (size_t)h->CQ * h->d;
+    a.qmem_init = h->qmem_initialised; a.first = h->first; a.task = h->task; a.update = h->update; a.alpha = h->alpha; a.beta = h->beta;
+    a.B = h->B; a.CQ = h->CQ; a.CV = h->CV; a.d = h->d;
+    hipLaunchKernelGGL(proto_row_kernel, dim3(h->CQ + h->CV), dim3(256), h->B * sizeof(float), ST, a);
+    LAUNCH_CHECK();
+    Retrieve2 r;
+    r.protos[0] = h->Qproto; r.protos[1] = h->Vproto; r.An[0] = a.AnQ; r.An[1] = a.AnV; r.pool[0] = h->poolQ; r.pool[1] = h->poolV;
+    r.idx[0] = h->idxQ; r.idx[1] = h->idxV; r.C[0] = h->CQ; r.C[1] = h->CV;
+    r.out_f32[0] = h->out_f32; r.out_f32[1] = h->out_f32 ? h->out_f32 + h->d : nullptr;
+    r.out_bf16[0] = (bf16_t*)h->out_bf16; r.out_bf16[1] = h->out_bf16 ? (bf16_t*)h->out_bf16 + h->d : nullptr;
+    const int cmax = h->CQ > h->CV ? h->CQ : h->CV;
+    hipLaunchKernelGGL(retrieve2_kernel, dim3(h->B, 2), dim3(256), (h->d + cmax) * sizeof(float), ST, r, h->out_sb, h->out_sb_bf16, h->B, h->d);
     LAUNCH_CHECK();
     return VLT5_OK;
 }

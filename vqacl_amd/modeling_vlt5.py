@@ -502,14 +502,21 @@ class VLT5(nn.Module):
         else:
             check(lib().vlt5_encoder_fwd(C.byref(c), C.byref(cs), stream), "vlt5_encoder_fwd")
             # SS/SI prototype head (modeling_t5_our.py:583-615)
-            poolQ, poolV = ops.proto_pool(enc_f32, S, self.L)
-            if proto_update:
-                ql = to_device(ques_labels, dev, torch.float32)
-                cl = to_device(cate_labels, dev, torch.float32)
-                if memory:
-                    loss_mem_Q, loss_mem_V = self.proto.memory_loss(poolQ, poolV, ql, cl)
-                self.proto.update(poolQ, poolV, ql, cl, int(current_task_id), float(proto_alpha), float(proto_beta))
-            idxQ, idxV = self.proto.retrieve(poolQ, poolV, enc_f32, enc_b16, S)
+            fused_head = not self.proto.dist_enabled and not (proto_update and memory) and os.environ.get("VQACL_FUSED_HEAD", "1") != "0"
+            if fused_head:          # pooling, state update and retrieval of both heads in three launches (vlt5_proto_head_fwd)
+                ql = to_device(ques_labels, dev, torch.float32) if proto_update else None
+                cl = to_device(cate_labels, dev, torch.float32) if proto_update else None
+                poolQ, poolV, idxQ, idxV = self.proto.forward(enc_f32, enc_b16, S, self.L, ql, cl, int(current_task_id), float(proto_alpha),
+                                                               float(proto_beta), update=bool(proto_update))
+            else:
+                poolQ, poolV = ops.proto_pool(enc_f32, S, self.L)
+                if proto_update:
+                    ql = to_device(ques_labels, dev, torch.float32)
+                    cl = to_device(cate_labels, dev, torch.float32)
+                    if memory:
+                        loss_mem_Q, loss_mem_V = self.proto.memory_loss(poolQ, poolV, ql, cl)
+                    self.proto.update(poolQ, poolV, ql, cl, int(current_task_id), float(proto_alpha), float(proto_beta))
+                idxQ, idxV = self.proto.retrieve(poolQ, poolV, enc_f32, enc_b16, S)
             self._cached_idx = (idxQ, idxV)
         check(lib().vlt5_decoder_fwd(C.byref(c), C.byref(cs), stream), "vlt5_decoder_fwd")
         st["loss_tok"] = self._ws_view(c, dims, L.WS_LOSS_TOK, torch.float32, (B * T,))

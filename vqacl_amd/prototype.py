@@ -77,6 +77,51 @@ class PrototypeHead:
         idxV = ops.proto_retrieve(self.V_prototype, poolV, enc_f32[:, S + 1], Sx * d, enc_bf16[:, S + 1], Sx * d)
         return idxQ, idxV
 
+    # ---- the whole head of one forward: pooling, (update), retrieval of both heads -- three launches (vlt5_proto_head_fwd) ----
+    def forward(self, enc_f32, enc_bf16, S: int, split: int, ques_labels=None, cate_labels=None, task: int = 0, alpha: float = 0.5,
+                beta: float = 0.3, update: bool = False):
+        """enc_f32 / enc_bf16: [B, S+2, d] decoder-memory buffers (rows 0..S-1 = encoder output, rows S, S+1 receive the retrieved
+        prototypes).  Returns (poolQ, poolV, idxQ, idxV).  Single process only: under data parallelism the class statistics are
+        all-reduced between the class means and the state update (`update` + `retrieve`)."""
+        import ctypes as C
+        assert not (update and self.dist_enabled)
+        B, Sx, d = enc_f32.shape
+        dev = enc_f32.device
+        h = L.ProtoHeadDesc()
+        poolQ = torch.empty(B, d, device=dev, dtype=torch.float32)
+        poolV = torch.empty(B, d, device=dev, dtype=torch.float32)
+        idxQ = torch.empty(B, device=dev, dtype=torch.int64)
+        idxV = torch.empty(B, device=dev, dtype=torch.int64)
+        if getattr(self, "_scratch", None) is None:
+            self._scratch = torch.empty((self.CQ + self.CV) * d, device=dev, dtype=torch.float32)
+        h.hidden, h.hidden_sb, h.B, h.S, h.d, h.split = ptr(enc_f32), enc_f32.stride(0), B, S, d, split
+        h.poolQ, h.poolV = ptr(poolQ), ptr(poolV)
+        h.Qproto, h.Vproto, h.Qnum, h.Vnum = ptr(self.Q_prototype), ptr(self.V_prototype), ptr(self.Q_prototype_num), ptr(self.V_prototype_num)
+        h.CQ, h.CV, h.alpha, h.beta = self.CQ, self.CV, float(alpha), float(beta)
+        h.idxQ, h.idxV = ptr(idxQ), ptr(idxV)
+        h.out_f32, h.out_sb = ptr(enc_f32[:, S]), Sx * d
+        h.out_bf16, h.out_sb_bf16 = ptr(enc_bf16[:, S]), Sx * d
+        h.scratch = ptr(self._scratch)
+        keep = (poolQ, poolV, idxQ, idxV)
+        if update:
+            ql, cl = ques_labels.contiguous(), cate_labels.contiguous()
+            first = task not in self.seen_tasks
+            qmem, qinit = None, 0
+            if not first and task != 0:
+                if task in self.Q_task_mem_proto:
+                    qmem, qinit = self.Q_task_mem_proto[task], 1
+                else:
+                    qmem = torch.empty_like(self.Q_prototype)
+                    self.Q_task_mem_proto[task] = qmem
+            h.onehotQ, h.onehotV, h.qmem, h.qmem_initialised = ptr(ql), ptr(cl), ptr(qmem), qinit
+            h.first, h.task, h.update = int(first), int(task), 1
+            keep = keep + (ql, cl, qmem)
+        check(lib().vlt5_proto_head_fwd(C.byref(h), stream_ptr()), "vlt5_proto_head_fwd")
+        if update:
+            self.seen_tasks.add(task)
+        del keep
+        return poolQ, poolV, idxQ, idxV
+
     def memory_loss(self, poolQ, poolV, ques_labels, cate_labels):
         return (ops.proto_memory_loss(poolQ, ques_labels, self.Q_prototype),
                 ops.proto_memory_loss(poolV, cate_labels, self.V_prototype))
