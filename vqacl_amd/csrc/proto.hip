@@ -256,7 +256,10 @@ __global__ __launch_bounds__(256) void proto_row_kernel(HeadArgs a) {
 
 // retrieval of both heads in one launch: blockIdx.y = 0 question prototypes -> memory row S, 1 category prototypes -> row S + 1
 struct Retrieve2 { const float *protos[2], *An[2], *pool[2]; long long* idx[2]; float* out_f32[2]; bf16_t* out_bf16[2]; int C[2]; };
-__global__ __launch_bounds__(256) void retrieve2_kernel(Retrieve2 r, long long sb, long long sb16, int B, int d) {
+__global__ __launch_bounds__(1024) void retrieve2_kernel(Retrieve2 r, long long sb, long long sb16, int B, int d) {
+    // 16 waves per (sample, head): wave w scores classes w, w+16, ... -- five at a time, so the whole similarity row of the 80
+    // categories is ONE round of independent loads per wave (with four waves it was five dependent rounds: 17 us of latency).
+    // The arithmetic per class (and the norm of the sample, computed by the first four waves) is that of retrieve_kernel.
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int h = blockIdx.y, C = r.C[h];
     float* tx = lds;
@@ -266,19 +269,24 @@ __global__ __launch_bounds__(256) void retrieve2_kernel(Retrieve2 r, long long s
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* x = r.pool[h] + (size_t)b * d;
     const float* An = r.An[h];
-    float s = 0.f;
-    for (int c = threadIdx.x; c < d; c += 256) { float t = tanhf(x[c]); tx[c] = t; s += t * t; }
-    s = wave_sum(s);
-    if (lane == 0) part[wave] = s;
+    if (threadIdx.x < 256) {
+        float s = 0.f;
+        for (int c = threadIdx.x; c < d; c += 256) { float t = tanhf(x[c]); tx[c] = t; s += t * t; }
+        s = wave_sum(s);
+        if (lane == 0) part[wave] = s;
+    }
     __syncthreads();
     const float nb = fmaxf(sqrtf((part[0] + part[1]) + (part[2] + part[3])), 1e-12f);
-    for (int cls0 = wave; cls0 < C; cls0 += 16) {
-        float dot[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 5;
+    for (int cls0 = wave; cls0 < C; cls0 += 16 * U) {
+        float dot[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dot[u] = 0.f;
         for (int c = lane * 4; c < d; c += 256) {
             const float4 t = *reinterpret_cast<const float4*>(tx + c);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int cls = cls0 + 4 * u;
+            for (int u = 0; u < U; ++u) {
+                const int cls = cls0 + 16 * u;
                 if (cls < C) {
                     const float4 q = *reinterpret_cast<const float4*>(An + (size_t)cls * d + c);
                     dot[u] += (q.x * t.x + q.y * t.y) + (q.z * t.z + q.w * t.w);
@@ -286,8 +294,8 @@ __global__ __launch_bounds__(256) void retrieve2_kernel(Retrieve2 r, long long s
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int cls = cls0 + 4 * u;
+        for (int u = 0; u < U; ++u) {
+            const int cls = cls0 + 16 * u;
             const float v = wave_sum(dot[u]);
             if (lane == 0 && cls < C) sim[cls] = v / nb;
         }
@@ -390,7 +398,7 @@ extern "C" int vlt5_proto_head_fwd(const vlt5_proto_head_desc* h, void* stream) 
     r.out_f32[0] = h->out_f32; r.out_f32[1] = h->out_f32 ? h->out_f32 + h->d : nullptr;
     r.out_bf16[0] = (bf16_t*)h->out_bf16; r.out_bf16[1] = h->out_bf16 ? (bf16_t*)h->out_bf16 + h->d : nullptr;
     const int cmax = h->CQ > h->CV ? h->CQ : h->CV;
-    hipLaunchKernelGGL(retrieve2_kernel, dim3(h->B, 2), dim3(256), (h->d + cmax) * sizeof(float), ST, r, h->out_sb, h->out_sb_bf16, h->B, h->d);
+    hipLaunchKernelGGL(retrieve2_kernel, dim3(h->B, 2), dim3(1024), (h->d + cmax) * sizeof(float), ST, r, h->out_sb, h->out_sb_bf16, h->B, h->d);
     LAUNCH_CHECK();
     return VLT5_OK;
 }
