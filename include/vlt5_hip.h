@@ -241,6 +241,17 @@ int vlt5_shift_right(const long long* labels, long long* out, int B, int T, int 
 /* f32 [B,S] encoder mask: 1 where input_ids != pad for the L text columns, 1 for the rest (:225-232, :631-638) */
 int vlt5_build_mask(const long long* ids, float* mask, int B, int L, int S, int pad_id, void* stream);
 
+/* the inputs of one T5 stack in ONE launch: vlt5_build_mask(mask_ids [B,L] -> mask [B,S]) + vlt5_relbias_build + vlt5_embed_fwd of
+ * `ids` [B,T] -- or, with `labels` != NULL (the decoder, src/modeling_t5_our.py:620), of _shift_right(labels), whose ids are also
+ * stored to ids_out [B,T] for the backward's scatter.  Element for element the arithmetic of the four kernels. */
+typedef struct {
+    const long long* mask_ids; float* mask; int B, L, S;
+    const float* rel_table; const int* lut; float* bias; int H, Lq, Lk;
+    const long long* ids; const long long* labels; long long* ids_out; int T, start_id, pad_id;
+    const float* table; float* out; long long out_sb, out_st; int d, vocab; float drop_p; uint32_t drop_seed; int drop_rows, drop_row0;
+} vlt5_stack_inputs_desc;
+int vlt5_stack_inputs_fwd(const vlt5_stack_inputs_desc* s, void* stream);
+
 /* ---- VisualEmbedding.forward (src/modeling_t5_our.py:93-143) after the 2048->d projection ------
  * out[b, row0+i] = drop( LN(G[b,i]) + LN(Wp [box,area] + bp) + img_order[0] + shared[vocab-1-i] )
  * "area" reads the box columns as (x1,x2,y1,y2) exactly like get_area (:78-90). */

@@ -815,6 +815,53 @@ def test_shift_right_and_mask_bit_exact(dev):
     assert torch.equal(mask.cpu(), ref)
 
 
+def test_stack_inputs_in_one_launch_equal_the_separate_kernels(dev):
+    """vlt5_stack_inputs_fwd (key mask + relative-position bias block + token embeddings, for the decoder of the shift-right of the
+    labels) against vlt5_build_mask / vlt5_relbias_build / vlt5_shift_right / vlt5_embed_fwd: bit for bit, dropout on."""
+    import ctypes as C
+    from vqacl_amd._lib import StackInputsDesc, check, lib, ptr, stream_ptr
+    from vqacl_amd.buckets import bucket_table
+    g = torch.Generator().manual_seed(3)
+    B, L, S, T, H, d, vocab, NB = 7, 11, 49, 6, 12, 768, 500, 32
+    table = rnd((vocab, d), g).to(dev)
+    rel = rnd((NB, H), g).to(dev)
+    in_ids = torch.randint(1, vocab, (B, L), generator=g)
+    in_ids[:, 8:] = 0
+    labels = torch.randint(2, vocab, (B, T), generator=g)
+    labels[:, 4:] = -100
+    in_ids_d, labels_d = in_ids.to(dev), labels.to(dev)
+    for decoder in (False, True):
+        Lq = T if decoder else L
+        lut = torch.from_numpy(bucket_table(Lq, Lq, not decoder, NB, 128).copy()).to(dev)
+        rows = T if decoder else L
+        mask0, bias0 = torch.zeros(B, S, device=dev), torch.zeros(H, Lq, Lq, device=dev)
+        out0 = torch.zeros(B, rows + 2, d, device=dev)
+        ids0 = torch.zeros(B, T, dtype=torch.int64, device=dev)
+        check(lib().vlt5_build_mask(ptr(in_ids_d), ptr(mask0), B, L, S, 0, stream_ptr()))
+        check(lib().vlt5_relbias_build(ptr(rel), ptr(lut), ptr(bias0), H, Lq, Lq, NB, stream_ptr()))
+        if decoder:
+            check(lib().vlt5_shift_right(ptr(labels_d), ptr(ids0), B, T, 0, 0, stream_ptr()))
+        src = ids0 if decoder else in_ids_d
+        check(lib().vlt5_embed_fwd(ptr(src), ptr(table), ptr(out0), (rows + 2) * d, d, B, rows, d, vocab, 0.1, 99, rows + 2, 0, stream_ptr()))
+        mask1, bias1, out1 = torch.full_like(mask0, -1), torch.full_like(bias0, -1), torch.zeros_like(out0)
+        ids1 = torch.full_like(ids0, -7)
+        si = StackInputsDesc()
+        si.mask_ids, si.mask, si.B, si.L, si.S = ptr(in_ids_d), ptr(mask1), B, L, S
+        si.rel_table, si.lut, si.bias, si.H, si.Lq, si.Lk = ptr(rel), ptr(lut), ptr(bias1), H, Lq, Lq
+        if decoder:
+            si.labels, si.ids_out = ptr(labels_d), ptr(ids1)
+        else:
+            si.ids = ptr(in_ids_d)
+        si.T, si.start_id, si.pad_id = rows, 0, 0
+        si.table, si.out, si.out_sb, si.out_st, si.d, si.vocab = ptr(table), ptr(out1), (rows + 2) * d, d, d, vocab
+        si.drop_p, si.drop_seed, si.drop_rows, si.drop_row0 = 0.1, 99, rows + 2, 0
+        check(lib().vlt5_stack_inputs_fwd(C.byref(si), stream_ptr()))
+        assert torch.equal(mask1, mask0) and torch.equal(bias1, bias0) and torch.equal(out1, out0)
+        assert float((out1 == 0).float().mean()) > 0.05, "dropout was on"
+        if decoder:
+            assert torch.equal(ids1, ids0)
+
+
 def test_cross_entropy_and_loss_reduction(dev):
     from vqacl_amd import ops
     g = torch.Generator().manual_seed(9)

@@ -57,6 +57,13 @@ class SkinnyDesc(C.Structure):
                 ("relu", c_i), ("drop_p", c_f), ("drop_seed", c_u32), ("resid", vp), ("ldr", c_i), ("panel_rows", c_i), ("chunk_cols", c_i)]
 
 
+class StackInputsDesc(C.Structure):
+    _fields_ = [("mask_ids", vp), ("mask", vp), ("B", c_i), ("L", c_i), ("S", c_i), ("rel_table", vp), ("lut", vp), ("bias", vp),
+                ("H", c_i), ("Lq", c_i), ("Lk", c_i), ("ids", vp), ("labels", vp), ("ids_out", vp), ("T", c_i), ("start_id", c_i),
+                ("pad_id", c_i), ("table", vp), ("out", vp), ("out_sb", c_ll), ("out_st", c_ll), ("d", c_i), ("vocab", c_i),
+                ("drop_p", c_f), ("drop_seed", c_u32), ("drop_rows", c_i), ("drop_row0", c_i)]
+
+
 class ProtoHeadDesc(C.Structure):
     _fields_ = [("hidden", vp), ("hidden_sb", c_ll), ("B", c_i), ("S", c_i), ("d", c_i), ("split", c_i), ("poolQ", vp), ("poolV", vp),
                 ("onehotQ", vp), ("onehotV", vp), ("Qproto", vp), ("Vproto", vp), ("Qnum", vp), ("Vnum", vp), ("qmem", vp),
@@ -123,6 +130,7 @@ PROTOTYPES = {
     "vlt5_embed_bwd_scratch_bytes": (c_ll, [c_i, c_i, c_i]),
     "vlt5_embed_bwd": (c_i, [vp, vp, c_ll, c_ll, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, vp]),
     "vlt5_shift_right": (c_i, [vp, vp, c_i, c_i, c_i, c_i, vp]),
+    "vlt5_stack_inputs_fwd": (c_i, [C.POINTER(StackInputsDesc), vp]),
     "vlt5_build_mask": (c_i, [vp, vp, c_i, c_i, c_i, c_i, vp]),
     "vlt5_vis_embed_fwd": (c_i, [vp] * 9 + [c_ll, c_ll, vp, vp, c_i, c_i, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),
     "vlt5_vis_embed_bwd": (c_i, [vp, c_ll, c_ll] + [vp] * 11 + [c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp]),

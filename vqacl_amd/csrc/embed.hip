@@ -367,6 +367,61 @@ __global__ __launch_bounds__(256) void relbias_scatter_kernel(const float* __res
     }
 }
 
+// ---------------- the inputs of a T5 stack in one launch ---------------------------------------------
+// key mask + relative-position bias block + token embeddings (+ the decoder's shift-right): four launch-latency-bound kernels of
+// ~5 us each on the step's dependency chain become one.  Block ranges: [0, nM) mask, [nM, nM + nR) bias, then one block per token row.
+// Element for element the arithmetic of build_mask_kernel / relbias_build_kernel / shift_right_kernel / embed_fwd_kernel.
+struct StackIn {
+    const long long* mask_ids; float* mask; int B, L, S;
+    const float* rel_table; const int* lut; float* bias; int H, Lq, Lk;
+    const long long* ids; const long long* labels; long long* ids_out; int T, start_id, pad_id;
+    const float* table; float* out; long long out_sb, out_st; int d, vocab; uint32_t thr, seed; int drop_rows, drop_row0;
+    int nM, nR;
+};
+__global__ __launch_bounds__(256) void stack_inputs_kernel(StackIn a) {
+    int blk = blockIdx.x;
+    if (blk < a.nM) {
+        const int i = blk * 256 + threadIdx.x;
+        if (i < a.B * a.S) {
+            const int b = i / a.S, s = i % a.S;
+            a.mask[i] = (s < a.L) ? (a.mask_ids[b * a.L + s] != a.pad_id ? 1.f : 0.f) : 1.f;
+        }
+        return;
+    }
+    blk -= a.nM;
+    if (blk < a.nR) {
+        const int i = blk * 256 + threadIdx.x;
+        if (i < a.H * a.Lq * a.Lk) {
+            const int h = i / (a.Lq * a.Lk), pos = i % (a.Lq * a.Lk);
+            a.bias[i] = a.rel_table[a.lut[pos] * a.H + h];
+        }
+        return;
+    }
+    const int row = blk - a.nR, b = row / a.T, t = row % a.T;
+    long long id;
+    if (a.labels) {                                  // decoder: HF _shift_right of the labels, kept for the backward's scatter
+        id = (t == 0) ? (long long)a.start_id : a.labels[row - 1];
+        if (id == -100) id = a.pad_id;
+        if (threadIdx.x == 0) a.ids_out[row] = id;
+    } else {
+        id = a.ids[row];
+    }
+    if (id < 0 || id >= a.vocab) id = 0;
+    const float* src = a.table + (size_t)id * a.d;
+    float* dst = a.out + b * a.out_sb + t * a.out_st;
+    const float dsc = drop_scale(a.thr);
+    for (int c = threadIdx.x * 4; c < a.d; c += 256 * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src + c);
+        float o[4] = {v.x, v.y, v.z, v.w};
+        if (a.thr) {
+            const uint32_t idx = (uint32_t)(((size_t)b * a.drop_rows + a.drop_row0 + t) * a.d + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = drop_keep(a.seed, idx + k, a.thr) ? o[k] * dsc : 0.f;
+        }
+        *reinterpret_cast<float4*>(dst + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -416,6 +471,25 @@ extern "C" int vlt5_shift_right(const long long* labels, long long* out, int B, 
 extern "C" int vlt5_build_mask(const long long* ids, float* mask, int B, int L, int S, int pad_id, void* stream) {
     if (!ids || !mask || B <= 0 || L < 0 || S < L) return VLT5_ERR_ARG;
     hipLaunchKernelGGL(build_mask_kernel, dim3((B * S + 255) / 256), dim3(256), 0, ST, ids, mask, B, L, S, pad_id);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
+
+// key mask + relative-position bias block + token embeddings of one T5 stack (for the decoder: of the shift-right of the labels)
+// in ONE launch -- see stack_inputs_kernel
+extern "C" int vlt5_stack_inputs_fwd(const vlt5_stack_inputs_desc* s, void* stream) {
+    if (!s || !s->mask_ids || !s->mask || !s->rel_table || !s->lut || !s->bias || !s->table || !s->out) return VLT5_ERR_ARG;
+    if ((!s->ids && !s->labels) || (s->labels && !s->ids_out)) return VLT5_ERR_ARG;
+    if (s->B <= 0 || s->L < 0 || s->S < s->L || s->H <= 0 || s->Lq <= 0 || s->Lk <= 0 || s->T <= 0) return VLT5_ERR_ARG;
+    if ((s->d & 3) || (s->out_sb & 3) || (s->out_st & 3)) return VLT5_ERR_ALIGN;
+    StackIn a;
+    a.mask_ids = s->mask_ids; a.mask = s->mask; a.B = s->B; a.L = s->L; a.S = s->S;
+    a.rel_table = s->rel_table; a.lut = s->lut; a.bias = s->bias; a.H = s->H; a.Lq = s->Lq; a.Lk = s->Lk;
+    a.ids = s->ids; a.labels = s->labels; a.ids_out = s->ids_out; a.T = s->T; a.start_id = s->start_id; a.pad_id = s->pad_id;
+    a.table = s->table; a.out = s->out; a.out_sb = s->out_sb; a.out_st = s->out_st; a.d = s->d; a.vocab = s->vocab;
+    a.thr = thr_of(s->drop_p); a.seed = s->drop_seed; a.drop_rows = s->drop_rows; a.drop_row0 = s->drop_row0;
+    a.nM = (s->B * s->S + 255) / 256; a.nR = (s->H * s->Lq * s->Lk + 255) / 256;
+    hipLaunchKernelGGL(stack_inputs_kernel, dim3(a.nM + a.nR + s->B * s->T), dim3(256), 0, ST, a);
     LAUNCH_CHECK();
     return VLT5_OK;
 }

@@ -499,9 +499,16 @@ int encoder_fwd(const Ctx& k) {
     float* x0 = k.w<float>(p.x[0]);
     const int nb = c.num_decoder_layers + c.num_layers + 2;      // buckets: decoder top..0, cross k/v, encoder top..0, norms+embeddings
     RC(k.wait_bucket(nb - 1));
-    RC(vlt5_build_mask(s.input_ids, k.w<float>(p.mask), B, s.L, S, c.pad_id, k.st));
-    RC(vlt5_relbias_build(k.P + L.enc_rel, s.enc_lut, k.w<float>(p.enc_bias), k.H, s.L, s.L, c.rel_buckets, k.st));
-    RC(vlt5_embed_fwd(s.input_ids, k.P + L.shared, x0, (long long)S * d, d, B, s.L, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, 0, k.st));
+    {   // key mask, relative-position bias block and the text rows of the input embeddings: one launch
+        vlt5_stack_inputs_desc si;
+        memset(&si, 0, sizeof si);
+        si.mask_ids = s.input_ids; si.mask = k.w<float>(p.mask); si.B = B; si.L = s.L; si.S = S;
+        si.rel_table = k.P + L.enc_rel; si.lut = s.enc_lut; si.bias = k.w<float>(p.enc_bias); si.H = k.H; si.Lq = s.L; si.Lk = s.L;
+        si.ids = s.input_ids; si.T = s.L; si.pad_id = c.pad_id;
+        si.table = k.P + L.shared; si.out = x0; si.out_sb = (long long)S * d; si.out_st = d; si.d = d; si.vocab = c.vocab;
+        si.drop_p = k.pdrop; si.drop_seed = k.seed(SITE_ENC_EMBED); si.drop_rows = S; si.drop_row0 = 0;
+        RC(vlt5_stack_inputs_fwd(&si, k.st));
+    }
     if (s.feat_store)       // batch assembled from the resident store: bf16 rows as they are (the rounding the cast would apply)
         RC(vlt5_feat_gather(s.feat_store, s.box_store, s.feat_slots, s.n_slots, k.w<void>(p.feats_bf16), k.w<float>(p.boxes_g), B, s.V,
                             c.feat_dim, k.st));
@@ -581,11 +588,17 @@ int decoder_fwd(const Ctx& k) {
     long long* ids = k.w<long long>(p.dec_ids);
     RC(k.wait_bucket(Ld + c.num_layers + 1));                 // (a decoder-only call: norms + embeddings first)
     RC(k.wait_bucket(Ld));                                    // stacked cross-attention k/v
-    RC(vlt5_shift_right(s.labels, ids, B, T, c.dec_start_id, c.pad_id, k.st));
-    RC(vlt5_build_mask(s.input_ids, k.w<float>(p.mask_ext), B, s.L, Sx, c.pad_id, k.st));
-    RC(vlt5_relbias_build(k.P + L.dec_rel, s.dec_lut, k.w<float>(p.dec_bias), k.H, T, T, c.rel_buckets, k.st));
+    {   // shift-right of the labels, extended key mask, causal relative-position bias block, decoder input embeddings: one launch
+        vlt5_stack_inputs_desc si;
+        memset(&si, 0, sizeof si);
+        si.mask_ids = s.input_ids; si.mask = k.w<float>(p.mask_ext); si.B = B; si.L = s.L; si.S = Sx;
+        si.rel_table = k.P + L.dec_rel; si.lut = s.dec_lut; si.bias = k.w<float>(p.dec_bias); si.H = k.H; si.Lq = T; si.Lk = T;
+        si.labels = s.labels; si.ids_out = ids; si.T = T; si.start_id = c.dec_start_id; si.pad_id = c.pad_id;
+        si.table = k.P + L.shared; si.out = k.w<float>(p.y[0]); si.out_sb = (long long)T * d; si.out_st = d; si.d = d; si.vocab = c.vocab;
+        si.drop_p = k.pdrop; si.drop_seed = k.seed(SITE_DEC_EMBED); si.drop_rows = T; si.drop_row0 = 0;
+        RC(vlt5_stack_inputs_fwd(&si, k.st));
+    }
     RC(k.lin_fwd(k.w<bf16_t>(p.enc_ext), k.Pb + L.cross_kv, k.w<void>(p.kv_all), Mx, kvw, d, 0));
-    RC(vlt5_embed_fwd(ids, k.P + L.shared, k.w<float>(p.y[0]), (long long)T * d, d, B, T, d, c.vocab, k.pdrop, k.seed(SITE_DEC_EMBED), T, 0, k.st));
     int pending = 0;                                          // split-K slabs of the previous layer's FFN output, if any
     for (int l = 0; l < Ld; ++l) {
         const auto& D = L.dec[l];
