@@ -77,28 +77,6 @@ long long vlt5_gemm_workspace_bytes(int M, int ldc, int split_k);
 /* the split-K factor the engine uses for a plain f32 output [M,N] reduced over Kred (1 = no split) */
 int vlt5_gemm_auto_split(int M, int N, int Kred, long long slab_bytes);
 
-/* ---- row-panel ("skinny") GEMM for few-row activations (the decoder stack: M = B*T rows) ---------------------------
- * C[M,N] = epi(alpha * A W^T), W bf16 [N,K] row-major.  A is either bf16 [M,K] (A != NULL) or the T5 RMS norm of the f32 rows
- * ln_x [M,K] computed in the kernel's prologue: A = bf16(ln_x * rsqrt(mean(ln_x^2) + eps) * ln_w) -- HF T5LayerNorm.forward
- * followed by nn.Linear (T5LayerSelfAttention / T5LayerCrossAttention / T5LayerFF of the decoder T5Block,
- * VL-T5/src/modeling_t5_our.py:641-655); rstd_out [M] and xn_out_bf16 [M,K] (both optional) receive what the backward needs.
- * Epilogue: ReLU, inverted dropout on element index m*N+n (same counters as vlt5_gemm_bf16), f32 residual add (f32 output
- * only).  A workgroup keeps a panel of 16 / 32 rows of A in LDS and streams its weight rows into registers (csrc/skinny.hip).
- * K % 64 == 0, 16*K*2 bytes <= 144 KB, ln_x: K <= 1024.  panel_rows / chunk_cols: 0 = heuristic, else 16|32 and 64|128|192. */
-typedef struct {
-    const void* A; int lda;
-    const float* ln_x; int ldx; const float* ln_w; float eps; float* rstd_out; void* xn_out_bf16;
-    const void* W; int ldw;
-    void* C; int ldc; int out_f32;
-    int M, N, K;
-    float alpha;
-    int relu; float drop_p; uint32_t drop_seed;
-    const float* resid; int ldr;
-    int panel_rows, chunk_cols;
-} vlt5_skinny_desc;
-int vlt5_skinny_gemm(const vlt5_skinny_desc* d, void* stream);
-int vlt5_skinny_ok(int M, int N, int K, int with_norm);     /* 1 if vlt5_skinny_gemm takes the shape */
-
 /* measurement hook for bench.py's roofline (no counterpart in the reference): while enabled (max_launches > 0; 0 disables and
  * frees), every GEMM kernel dispatch carries its own start/stop HIP events; collect() waits for them and returns one record per
  * dispatch in launch order (the number of records, -1 on error), then resets.  Process-global, not thread-safe. */

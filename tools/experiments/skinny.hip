@@ -1,3 +1,4 @@
+// EXPERIMENT (not in libvlt5_hip.so; see tools/experiments/skinny.h for the verdict).
 // Row-panel ("skinny") bf16 GEMM for the few-row projections of the decoder stack (gfx950, wave64):
 //
 //   C[M,N] = epilogue( alpha * A[M,K] W[N,K]^T ),  A = bf16 activations, or A = bf16(RMSnorm(x) * w) computed in the prologue
@@ -21,6 +22,7 @@
 // operand for the backward), ReLU, counter-based dropout (same element index as the tiled kernel: the backward regenerates the
 // mask), f32 residual add, bf16 or f32 output.
 #include "gemm_kernel.h"
+#include "skinny.h"
 #include <string.h>
 
 extern vlt5gemm::TimingState vlt5_gemm_timing_state;

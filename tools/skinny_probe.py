@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Row-panel (skinny) GEMM against the tiled kernel on the decoder's shapes: correctness vs an f32 torch reference, graph-replayed
 timing warm (one weight matrix) and cold-ish (rotating through `--rot` weight matrices, > Infinity Cache).
-usage: python tools/skinny_probe.py ["M N K ln relu resid" ...]"""
+usage: make -C vqacl_amd/csrc exp; VLT5_LIB=vqacl_amd/libvlt5_exp.so python tools/skinny_probe.py ["M N K ln relu resid" ...]"""
 import ctypes as C
 import os
 import sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.gemm_sweep import timed_graph
+from tools.experiments import skinny_py as ops_sk
 from vqacl_amd import ops
 from vqacl_amd._lib import lib, stream_ptr
 dev = torch.device("cuda")
@@ -40,13 +41,13 @@ for spec in specs:
         kw = dict(A=A, ln_x=X if ln else None, ln_w=lw if ln else None, relu=bool(relu), resid=R, out_f32=bool(res), panel_rows=rows,
                   chunk_cols=cols)
         try:
-            out = ops.skinny_gemm(Ws[0], M, N, K, **kw)
+            out = ops_sk.skinny_gemm(Ws[0], M, N, K, **kw)
         except Exception as e:
             print(f"  {spec} panel {rows} x {cols}: {e}")
             continue
         err = float((out.float() - ref).abs().max() / ref.abs().max())
-        descs = [ops.skinny_desc(W, M, N, K, out=out, **kw) for W in Ws]
-        fn = lib().vlt5_skinny_gemm
+        descs = [ops_sk.skinny_desc(W, M, N, K, out=out, **kw) for W in Ws]
+        fn = ops_sk.bind().vlt5_skinny_gemm
         sp = stream_ptr()
         warm = timed_graph(lambda: fn(C.byref(descs[0][0]), stream_ptr()))
         it = [0]

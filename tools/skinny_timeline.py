@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Per-workgroup phase timeline of the row-panel GEMM (debug hook vlt5dbg_skinny_timeline): usage  python tools/skinny_timeline.py "M N K ln rows cols" ..."""
+"""Per-workgroup phase timeline of the row-panel GEMM (debug hook vlt5dbg_skinny_timeline): usage  make -C vqacl_amd/csrc exp; VLT5_LIB=vqacl_amd/libvlt5_exp.so python tools/skinny_timeline.py "M N K ln rows cols" ..."""
 import ctypes as C
 import os
 import sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools.experiments import skinny_py as ops_sk
 from vqacl_amd import ops
 from vqacl_amd._lib import lib, ptr
 dev = torch.device("cuda")
@@ -17,11 +18,11 @@ for spec in sys.argv[1:]:
     W = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
     kw = dict(A=None if ln else X.to(torch.bfloat16), ln_x=X if ln else None, ln_w=lw if ln else None, panel_rows=rows, chunk_cols=cols)
     for _ in range(3):
-        ops.skinny_gemm(W, M, N, K, **kw)
+        ops_sk.skinny_gemm(W, M, N, K, **kw)
     buf = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
     L.vlt5dbg_skinny_timeline(ptr(buf))
     torch.cuda.synchronize()
-    ops.skinny_gemm(W, M, N, K, **kw)
+    ops_sk.skinny_gemm(W, M, N, K, **kw)
     torch.cuda.synchronize()
     L.vlt5dbg_skinny_timeline(None)
     t = buf.view(-1, 8).cpu()

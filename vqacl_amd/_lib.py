@@ -51,12 +51,6 @@ class EncAttnGrads(C.Structure):
     _fields_ = [("dy", vp), ("dx", vp), ("d_wqkv", vp), ("d_wo", vp), ("d_ln_w", vp), ("d_scores", vp)]
 
 
-class SkinnyDesc(C.Structure):
-    _fields_ = [("A", vp), ("lda", c_i), ("ln_x", vp), ("ldx", c_i), ("ln_w", vp), ("eps", c_f), ("rstd_out", vp), ("xn_out_bf16", vp),
-                ("W", vp), ("ldw", c_i), ("C", vp), ("ldc", c_i), ("out_f32", c_i), ("M", c_i), ("N", c_i), ("K", c_i), ("alpha", c_f),
-                ("relu", c_i), ("drop_p", c_f), ("drop_seed", c_u32), ("resid", vp), ("ldr", c_i), ("panel_rows", c_i), ("chunk_cols", c_i)]
-
-
 class StackInputsDesc(C.Structure):
     _fields_ = [("mask_ids", vp), ("mask", vp), ("B", c_i), ("L", c_i), ("S", c_i), ("rel_table", vp), ("lut", vp), ("bias", vp),
                 ("H", c_i), ("Lq", c_i), ("Lk", c_i), ("ids", vp), ("labels", vp), ("ids_out", vp), ("T", c_i), ("start_id", c_i),
@@ -101,8 +95,6 @@ PROTOTYPES = {
     "vlt5_gemm_bf16": (c_i, [C.POINTER(GemmDesc), vp]),
     "vlt5_gemm_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
     "vlt5_gemm_auto_split": (c_i, [c_i, c_i, c_i, c_ll]),
-    "vlt5_skinny_gemm": (c_i, [C.POINTER(SkinnyDesc), vp]),
-    "vlt5_skinny_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "vlt5_gemm_timing_enable": (c_i, [c_i]),
     "vlt5_gemm_timing_collect": (c_i, [C.POINTER(GemmTimingRec), c_i]),
     "vlt5_layernorm_fwd": (c_i, [vp, vp, vp, vp, vp, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),

@@ -73,33 +73,6 @@ def gemm_desc(A, B, M, N, K, *, a_kmajor=False, b_kmajor=False, out=None, out_f3
     return g, out, (A, B, ws, bias, resid, gate)
 
 
-def skinny_desc(W, M, N, K, *, A=None, ln_x=None, ln_w=None, eps=1e-6, out=None, out_f32=False, alpha=1.0, relu=False, resid=None,
-                drop_p=0.0, drop_seed=0, rstd_out=None, xn_out=None, panel_rows=0, chunk_cols=0):
-    """The filled vlt5_skinny_desc (row-panel GEMM, optional RMS-norm prologue): (desc, out, keep-alive)."""
-    _need(W, BF16)
-    if out is None:
-        out = torch.empty(M, N, device=W.device, dtype=torch.float32 if out_f32 else BF16)
-    g = L.SkinnyDesc()
-    if A is not None:
-        g.A, g.lda = ptr(_need(A, BF16)), A.stride(0)
-    if ln_x is not None:
-        g.ln_x, g.ldx, g.ln_w, g.eps = ptr(_need(ln_x, torch.float32)), ln_x.stride(0), ptr(ln_w), eps
-        g.rstd_out, g.xn_out_bf16 = ptr(rstd_out), ptr(xn_out)
-    g.W, g.ldw = ptr(W), W.stride(0)
-    g.C, g.ldc, g.out_f32 = ptr(out), out.stride(0), int(out.dtype == torch.float32)
-    g.M, g.N, g.K, g.alpha = M, N, K, alpha
-    g.relu, g.drop_p, g.drop_seed = int(relu), drop_p, drop_seed
-    g.resid, g.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
-    g.panel_rows, g.chunk_cols = panel_rows, chunk_cols
-    return g, out, (A, ln_x, ln_w, W, resid, rstd_out, xn_out)
-
-
-def skinny_gemm(W, M, N, K, **kw):
-    g, out, _keep = skinny_desc(W, M, N, K, **kw)
-    check(lib().vlt5_skinny_gemm(C.byref(g), stream_ptr()), "vlt5_skinny_gemm")
-    return out
-
-
 def layernorm_fwd(x, w, eps=1e-6, want_f32=False, drop_p=0.0, drop_seed=0):
     rows, d = x.shape
     yb = torch.empty(rows, d, device=x.device, dtype=BF16)
