@@ -168,6 +168,28 @@ int vlt5_qkv_attn_fwd(const void* xn_bf16, const void* wqkv_bf16, void* qkv_bf16
  * the accumulators, rstd goes to norm_rstd_out [B*S] (optional) for the norm's backward. */
 int vlt5_qkv_attn_fwd_norm(const void* xw_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model,
                            const float* norm_partials, int norm_nparts, float norm_eps, float* norm_rstd_out, void* stream);
+
+/* Fused decoder attention sublayers (between the two norms): projection of one head + attention core + that head's share of the
+ * output projection, one workgroup per (sample group, head) -- three launches of a 400-row decoder sublayer in one.
+ * Replaces HF T5LayerSelfAttention / T5LayerCrossAttention.forward without the norm and the residual (VL-T5/src/modeling_t5_our.py:641-655
+ * -> HF T5Block): the H output slabs are summed -- with dropout and the residual -- by vlt5_layernorm_fwd_slabs.
+ * core: as for vlt5_attn_fwd (d_kv = 64, Tq <= 16, Tk <= 64); proj_bf16, core.ctx and core.lse are written for the backward.
+ *   self : w_bf16 [3*H*64, d_model] q | k | v rows; proj_bf16 [B*Tq, 3*H*64]; core.q / k / v and their strides must describe proj_bf16
+ *   cross: w_bf16 [H*64, d_model] q rows; proj_bf16 [B*Tq, H*64] (= core.q); core.k / core.v: the projected encoder-side keys / values */
+typedef struct vlt5_dec_attn_desc {
+    const void* xn_bf16;      /* [B*Tq, d_model] bf16: the normalised sublayer input */
+    const void* w_bf16;
+    const void* wo_bf16;      /* [d_model, H*64] bf16 output projection */
+    void* proj_bf16;
+    float* o_slabs;           /* out: H slabs of [B*Tq, d_model] f32; slab h = ctx_h . Wo[:, h*64 .. h*64+63]^T */
+    long long slab_stride;    /* elements between slabs (>= B*Tq*d_model, multiple of 4) */
+    int d_model;              /* multiple of 64 */
+    vlt5_attn_desc core;
+} vlt5_dec_attn_desc;
+int vlt5_dec_self_attn_fwd(const vlt5_dec_attn_desc* d, void* stream);
+int vlt5_cross_attn_fwd(const vlt5_dec_attn_desc* d, void* stream);
+/* 1 if both kernels serve answers of T tokens against Tk_cross encoder-side keys at this head / model width */
+int vlt5_dec_attn_fused_ok(int T, int Tk_cross, int d_kv, int d_model);
 /* the whole sublayer: x_out = x + dropout(o(attention(LN(x)))) -- HF T5LayerSelfAttention.forward; norm + fused kernel + output
  * projection (dropout + residual in its epilogue); xn / rstd / qkv / ctx / lse are left for the backward */
 typedef struct {

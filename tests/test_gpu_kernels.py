@@ -593,6 +593,52 @@ def test_fused_qkv_attention_equals_the_unfused_kernels(dev, B, S, H, d, Lb, dro
         close(ctx1, ref, 2e-2, 2e-2, "fused context vs f32 reference")
 
 
+@pytest.mark.parametrize("B,T,Tk,H,d,drop", [(80, 5, 58, 12, 768, 0.1), (7, 5, 58, 12, 768, 0.0), (5, 6, 41, 3, 128, 0.1), (3, 10, 64, 2, 256, 0.0),
+                                               (4, 16, 9, 2, 1024, 0.1), (33, 1, 17, 4, 64, 0.0)])
+def test_fused_decoder_attention_sublayers(dev, B, T, Tk, H, d, drop):
+    """vlt5_dec_self_attn_fwd / vlt5_cross_attn_fwd (projection + core + per-head output-projection slabs in one workgroup per sample
+    group x head; HF T5LayerSelfAttention / T5LayerCrossAttention between the norms) against vlt5_gemm_bf16 + vlt5_attn_fwd +
+    vlt5_gemm_bf16 on the same inputs: projected rows, context and log-sum-exp BIT FOR BIT; the sum of the H slabs against the f32
+    output projection of the same context (summation order over heads differs); bit-stable over repeated launches."""
+    from vqacl_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + T * 7 + Tk)
+    inner = H * 64
+    xn = rnd((B * T, d), g).to(BF).to(dev)
+    wqkv = rnd((3 * inner, d), g, d ** -0.5).to(BF).to(dev)
+    wq = rnd((inner, d), g, d ** -0.5).to(BF).to(dev)
+    wo = rnd((d, inner), g, inner ** -0.5).to(BF).to(dev)
+    bias = rnd((H, T, T), g).to(dev)
+    # self-attention: causal, relative-position bias block
+    qkv0 = ops.gemm(xn, wqkv, B * T, 3 * inner, d).view(B, T, 3 * inner)
+    ctx0, lse0 = ops.attn_fwd(qkv0[:, :, :inner], qkv0[:, :, inner:2 * inner], qkv0[:, :, 2 * inner:], H, 64, bias=bias, causal=True,
+                              drop_p=drop, drop_seed=7)
+    o0 = ops.gemm(ctx0.view(B * T, inner), wo, B * T, d, inner, out_f32=True)
+    qkv1, ctx1, lse1, slabs = ops.dec_attn_fused(xn, wqkv, wo, B, T, H, bias=bias, drop_p=drop, drop_seed=7)
+    assert torch.equal(qkv1, qkv0), float((qkv1.float() - qkv0.float()).abs().max())
+    assert torch.equal(lse1, lse0), float((lse1 - lse0).abs().max())
+    assert torch.equal(ctx1, ctx0), float((ctx1.float() - ctx0.float()).abs().max())
+    close(slabs.sum(0), o0, 1e-4, 1e-4, "self: sum of head slabs vs output projection")
+    again = ops.dec_attn_fused(xn, wqkv, wo, B, T, H, bias=bias, drop_p=drop, drop_seed=7)
+    assert all(torch.equal(a, b) for a, b in zip(again, (qkv1, ctx1, lse1, slabs)))
+    # cross-attention: keys / values of ALL layers side by side (the engine's layout: row stride = layers * 2 * inner), key mask
+    layers = 3
+    kv = rnd((B, Tk, layers * 2 * inner), g).to(BF).to(dev)
+    k, v = kv[:, :, 2 * inner:3 * inner], kv[:, :, 3 * inner:4 * inner]                  # layer 1
+    km = (torch.rand(B, Tk, generator=g) > 0.2).float()
+    km[:, 0] = 1.0
+    km = km.to(dev)
+    q0 = ops.gemm(xn, wq, B * T, inner, d).view(B, T, inner)
+    cctx0, clse0 = ops.attn_fwd(q0, k, v, H, 64, key_mask=km, mask_value=-1e9, drop_p=drop, drop_seed=11)
+    co0 = ops.gemm(cctx0.view(B * T, inner), wo, B * T, d, inner, out_f32=True)
+    q1, cctx1, clse1, cslabs = ops.dec_attn_fused(xn, wq, wo, B, T, H, k=k, v=v, key_mask=km, mask_value=-1e9, drop_p=drop, drop_seed=11)
+    assert torch.equal(q1, q0), float((q1.float() - q0.float()).abs().max())
+    assert torch.equal(clse1, clse0), float((clse1 - clse0).abs().max())
+    assert torch.equal(cctx1, cctx0), float((cctx1.float() - cctx0.float()).abs().max())
+    close(cslabs.sum(0), co0, 1e-4, 1e-4, "cross: sum of head slabs vs output projection")
+    again = ops.dec_attn_fused(xn, wq, wo, B, T, H, k=k, v=v, key_mask=km, mask_value=-1e9, drop_p=drop, drop_seed=11)
+    assert all(torch.equal(a, b) for a, b in zip(again, (q1, cctx1, clse1, cslabs)))
+
+
 @pytest.mark.parametrize("B,S,H,d,Lb", [(3, 24, 2, 128, 9), (2, 56, 12, 768, 20)])
 def test_encoder_attention_sublayer_entry_points_vs_oracle(dev, B, S, H, d, Lb):
     """vlt5_enc_attn_fwd / vlt5_enc_attn_bwd: x + o(attention(LN(x))) and all its gradients against the oracle's

@@ -1138,9 +1138,11 @@ def test_unfolded_norm_path_still_matches_the_oracle():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # the default folds the encoder's norms only: (off, off) is the plain path, (on, on) also folds the decoder's cross / FFN norms
-    for enc, dec in (("0", "0"), ("1", "1")):
-        env = dict(os.environ, VLT5_FOLD_NORM=enc, VLT5_FOLD_NORM_DEC=dec)
+    # a third child runs the decoder's attention sublayers through the fused kernels (csrc/dec_attn.hip: an option, measured level with
+    # the three launches each replaces)
+    for enc, dec, fused in (("0", "0", "0"), ("1", "1", "0"), ("1", "0", "1")):
+        env = dict(os.environ, VLT5_FOLD_NORM=enc, VLT5_FOLD_NORM_DEC=dec, VLT5_DEC_FUSED=fused)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_model.py"), "-m", "gpu", "-q", "-x", "-k",
                             "tiny_model_against_golden_fixture or base_model_forward_backward_vs_oracle"], env=env, cwd=root,
                            capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0 and "2 passed" in r.stdout, (enc, dec, r.stdout[-2000:] + r.stderr[-2000:])
+        assert r.returncode == 0 and "2 passed" in r.stdout, (enc, dec, fused, r.stdout[-2000:] + r.stderr[-2000:])

@@ -40,6 +40,11 @@ class AttnDesc(C.Structure):
                 ("dbias", vp)]
 
 
+class DecAttnDesc(C.Structure):
+    _fields_ = [("xn_bf16", vp), ("w_bf16", vp), ("wo_bf16", vp), ("proj_bf16", vp), ("o_slabs", vp), ("slab_stride", c_ll),
+                ("d_model", c_i), ("core", AttnDesc)]
+
+
 class EncAttnDesc(C.Structure):
     _fields_ = [("x", vp), ("ln_w", vp), ("wqkv_bf16", vp), ("wo_bf16", vp), ("x_out", vp), ("xn_bf16", vp), ("rstd", vp),
                 ("qkv_bf16", vp), ("ctx_bf16", vp), ("lse", vp), ("bias", vp), ("bias_q", c_i), ("bias_k", c_i), ("key_mask", vp),
@@ -112,6 +117,9 @@ PROTOTYPES = {
     "vlt5_attn_fwd": (c_i, [C.POINTER(AttnDesc), vp]),
     "vlt5_qkv_attn_fwd": (c_i, [vp, vp, vp, C.POINTER(AttnDesc), c_i, vp]),
     "vlt5_qkv_attn_fwd_norm": (c_i, [vp, vp, vp, C.POINTER(AttnDesc), c_i, vp, c_i, c_f, vp, vp]),
+    "vlt5_dec_self_attn_fwd": (c_i, [C.POINTER(DecAttnDesc), vp]),
+    "vlt5_cross_attn_fwd": (c_i, [C.POINTER(DecAttnDesc), vp]),
+    "vlt5_dec_attn_fused_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "vlt5_enc_attn_fwd": (c_i, [C.POINTER(EncAttnDesc), vp]),
     "vlt5_enc_attn_bwd_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i]),
     "vlt5_enc_attn_bwd": (c_i, [C.POINTER(EncAttnDesc), C.POINTER(EncAttnGrads), vp, vp]),

@@ -175,9 +175,16 @@ __device__ __forceinline__ float quad_lane_max(float v) {
 // share every K and V^T fragment read and are independent MFMA / VALU chains in one basic block (the fused encoder kernel runs
 // NB = 2: half the LDS reads per row and two chains to interleave); per block the arithmetic and its order are those of NB = 1.
 struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
-template <bool DK64, int NB, class Stamp = NoStamp>
-__device__ __forceinline__ void attn_fwd_blocks(const AttnArgs& p, const bf16_t* Qs, const bf16_t* Ks, const bf16_t* Vs, int b, int h,
-                                                int i0, int lane, const float (&add)[NB][4][4], Stamp stamp = Stamp()) {
+// where the K fragments come from (default: the staged natural tile) and an optional second destination of the ctx rows (the fused
+// decoder kernels keep them in LDS as the operand of the output projection)
+struct KFromLds {
+    const bf16_t* Ks; int lr, g;
+    __device__ __forceinline__ bf16x8_t operator()(int jb, int ks) const { return lds_frag(Ks, jb * 16 + lr, ks * 4 + g); }
+};
+struct NoSink { __device__ __forceinline__ void operator()(int, int, uint2) const {} };
+template <bool DK64, int NB, class KF, class Sink, class Stamp = NoStamp>
+__device__ __forceinline__ void attn_fwd_blocks_ex(const AttnArgs& p, const bf16_t* Qs, const KF kf, const bf16_t* Vs, int b, int h,
+                                                   int i0, int lane, const float (&add)[NB][4][4], const Sink sink, Stamp stamp = Stamp()) {
     const int lr = lane & 15, g = lane >> 4;
     f32x4_t acc[NB][4];
 #pragma unroll
@@ -190,7 +197,7 @@ __device__ __forceinline__ void attn_fwd_blocks(const AttnArgs& p, const bf16_t*
         if (ks >= nks) break;
         bf16x8_t fk[4];
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) fk[jb] = lds_frag(Ks, jb * 16 + lr, ks * 4 + g);
+        for (int jb = 0; jb < 4; ++jb) fk[jb] = kf(jb, ks);
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
             const bf16x8_t fq = lds_frag(Qs, i0 + n * 16 + lr, ks * 4 + g);
@@ -266,9 +273,15 @@ __device__ __forceinline__ void attn_fwd_blocks(const AttnArgs& p, const bf16_t*
                 pk.x = pack_bf16x2(o[n][0], o[n][1]);
                 pk.y = pack_bf16x2(o[n][2], o[n][3]);
                 *reinterpret_cast<uint2*>(p.ctx + b * p.o_sb + (long long)i * p.o_st + (long long)h * p.dk + d) = pk;
+                sink(i, d, pk);
             }
         }
     }
+}
+template <bool DK64, int NB, class Stamp = NoStamp>
+__device__ __forceinline__ void attn_fwd_blocks(const AttnArgs& p, const bf16_t* Qs, const bf16_t* Ks, const bf16_t* Vs, int b, int h,
+                                                int i0, int lane, const float (&add)[NB][4][4], Stamp stamp = Stamp()) {
+    attn_fwd_blocks_ex<DK64, NB>(p, Qs, KFromLds{Ks, lane & 15, lane >> 4}, Vs, b, h, i0, lane, add, NoSink(), stamp);
 }
 template <bool DK64>
 __device__ __forceinline__ void attn_fwd_rows(const AttnArgs& p, const bf16_t* Qs, const bf16_t* Ks, const bf16_t* Vs, int b, int h,

@@ -493,6 +493,35 @@ bool fused_attn_ok(const Ctx& k) {
     return !off && k.c.d_kv == 64 && k.p.S <= 64 && (k.d & 63) == 0;
 }
 
+// the fused decoder attention sublayers (csrc/dec_attn.hip: projection + core + per-head output-projection slabs in one launch instead of
+// three): built and bit-checked, measured level with the three launches they replace -- VLT5_DEC_FUSED=1 selects them
+bool dec_fused_ok(const Ctx& k) {
+    static const bool on = getenv("VLT5_DEC_FUSED") && atoi(getenv("VLT5_DEC_FUSED")) != 0;
+    return on && !k.fold_dec() && vlt5_dec_attn_fused_ok(k.s.T, k.p.Sx, k.c.d_kv, k.d) &&
+           (size_t)k.H * k.p.Md * k.d * sizeof(float) <= k.p.slab_bytes;
+}
+// one fused decoder attention sublayer: leaves H slabs in the slab scratch for the norm that follows
+int dec_attn_fused(const Ctx& k, bool cross, const bf16_t* xn, const bf16_t* w, const bf16_t* wo, bf16_t* proj, const bf16_t* kk,
+                   const bf16_t* v, long long kv_sb, long long kv_st, bf16_t* ctx, float* lse, const float* bias, const float* kmask,
+                   float mval, int Tk, uint32_t dseed) {
+    const int T = k.s.T, inner = k.inner;
+    vlt5_dec_attn_desc e;
+    memset(&e, 0, sizeof e);
+    e.xn_bf16 = xn; e.w_bf16 = w; e.wo_bf16 = wo; e.proj_bf16 = proj; e.o_slabs = k.w<float>(k.p.slab);
+    e.slab_stride = (long long)k.p.Md * k.d; e.d_model = k.d;
+    vlt5_attn_desc& a = e.core;
+    if (cross) {
+        a.q = proj; a.q_sb = (long long)T * inner; a.q_st = inner; a.k = kk; a.v = v; a.k_sb = a.v_sb = kv_sb; a.k_st = a.v_st = kv_st;
+    } else {
+        a.q = proj; a.k = proj + inner; a.v = proj + 2 * inner;
+        a.q_sb = a.k_sb = a.v_sb = (long long)T * 3 * inner; a.q_st = a.k_st = a.v_st = 3 * inner;
+    }
+    a.ctx = ctx; a.o_sb = (long long)T * inner; a.o_st = inner; a.lse = lse;
+    a.bias = bias; a.bias_q = bias ? T : 0; a.bias_k = bias ? T : 0; a.key_mask = kmask; a.mask_value = mval; a.causal = cross ? 0 : 1;
+    a.B = k.s.B; a.H = k.H; a.Tq = T; a.Tk = Tk; a.dk = 64; a.drop_p = k.pdrop; a.drop_seed = dseed;
+    return cross ? vlt5_cross_attn_fwd(&e, k.st) : vlt5_dec_self_attn_fwd(&e, k.st);
+}
+
 int encoder_fwd(const Ctx& k) {
     const Plan& p = k.p; const Layout& L = k.lay; const vlt5_config& c = k.c; const vlt5_step& s = k.s;
     const int d = k.d, inner = k.inner, ff = k.ff, M = p.M, S = p.S, Sx = p.Sx, B = s.B;
@@ -612,6 +641,21 @@ int decoder_fwd(const Ctx& k) {
         bf16_t* kv = k.w<bf16_t>(p.kv_all) + (size_t)l * 2 * inner;
         RC(k.ln_fwd_pending(pending, y0, l > 0 ? k.w<float>(p.y[3 * l - 1]) : nullptr, k.pdrop, k.seed(sb - 8 + D_FFN_OUT), D.ln_s,
                             k.w<void>(p.yn_a[l]), nullptr, k.w<float>(p.yr[3 * l]), Md, 0.f, 0, 0, 0));
+        if (dec_fused_ok(k)) {
+            // three launches per attention sublayer in one: the H slabs of each output projection are summed by the norm behind it
+            RC(dec_attn_fused(k, false, k.w<bf16_t>(p.yn_a[l]), k.Pb + D.sqkv, k.Pb + D.so, qkv, nullptr, nullptr, 0, 0, k.w<bf16_t>(p.ctx_s[l]),
+                              k.w<float>(p.lse_s[l]), k.w<float>(p.dec_bias), nullptr, 0.f, T, k.seed(sb + D_SPROBS)));
+            RC(k.ln_fwd_pending(k.H, y1, y0, k.pdrop, k.seed(sb + D_SOUT), D.ln_c, k.w<void>(p.yn_c[l]), nullptr,
+                                k.w<float>(p.yr[3 * l + 1]), Md, 0.f, 0, 0, 0));
+            RC(dec_attn_fused(k, true, k.w<bf16_t>(p.yn_c[l]), k.Pb + D.cq, k.Pb + D.co, k.w<bf16_t>(p.qc[l]), kv, kv + inner,
+                              (long long)Sx * kvw, kvw, k.w<bf16_t>(p.ctx_c[l]), k.w<float>(p.lse_c[l]), nullptr, k.w<float>(p.mask_ext), -1e9f,
+                              Sx, k.seed(sb + D_CPROBS)));
+            RC(k.ln_fwd_pending(k.H, y2, y1, k.pdrop, k.seed(sb + D_COUT), D.ln_f, k.w<void>(p.yn_f[l]), nullptr,
+                                k.w<float>(p.yr[3 * l + 2]), Md, 0.f, 0, 0, 0));
+            RC(k.ffn_hidden(k.w<bf16_t>(p.yn_f[l]), D.wi, k.w<bf16_t>(p.ud[l]), k.w<bf16_t>(p.hd[l]), Md, k.pdrop, k.seed(sb + D_FFN_H)));
+            RC(k.lin_fwd_for_norm(k.w<bf16_t>(p.hd[l]), k.Pb + D.wo, y3, Md, d, ff, k.pdrop, k.seed(sb + D_FFN_OUT), y2, &pending));
+            continue;
+        }
         RC(k.lin_fwd(k.w<bf16_t>(p.yn_a[l]), k.Pb + D.sqkv, qkv, Md, 3 * inner, d, 0));
         RC(attn_call(k, false, qkv, (long long)T * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)T * 3 * inner,
                      3 * inner, k.w<bf16_t>(p.ctx_s[l]), k.w<float>(p.lse_s[l]), k.w<float>(p.dec_bias), T, T, nullptr, 0.f, 1, T, T,

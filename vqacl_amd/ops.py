@@ -276,6 +276,34 @@ def qkv_attn_fwd(xn, wqkv, B, S, H, bias=None, key_mask=None, mask_value=-10000.
     return qkv, ctx, lse
 
 
+def dec_attn_fused(xn, w, wo, B, T, H, k=None, v=None, bias=None, key_mask=None, mask_value=-10000.0, drop_p=0.0, drop_seed=0):
+    """Fused decoder attention sublayer between the norms (csrc/dec_attn.hip).  Self-attention (k is None): w = [3*H*64, d] q|k|v rows,
+    causal; cross-attention: w = [H*64, d] q rows, k / v = projected encoder-side keys / values [B, Tk, H*64] (any batch / token strides).
+    xn bf16 [B*T, d], wo bf16 [d, H*64] -> (proj bf16 [B, T, 3*H*64] or [B, T, H*64], ctx bf16 [B, T, H*64], lse f32 [B, H, T],
+    slabs f32 [H, B*T, d]: slab h = that head's share of the output projection)."""
+    from ._lib import DecAttnDesc
+    d = xn.shape[1]
+    inner = H * 64
+    dev = xn.device
+    cross = k is not None
+    proj = torch.empty(B, T, inner if cross else 3 * inner, device=dev, dtype=BF16)
+    if cross:
+        a = _attn_desc(proj, k, v, H, 64, bias, key_mask, mask_value, False, drop_p, drop_seed)
+    else:
+        a = _attn_desc(proj[:, :, :inner], proj[:, :, inner:2 * inner], proj[:, :, 2 * inner:], H, 64, bias, key_mask, mask_value, True,
+                       drop_p, drop_seed)
+    ctx = torch.empty(B, T, inner, device=dev, dtype=BF16)
+    lse = torch.empty(B, H, T, device=dev, dtype=torch.float32)
+    slabs = torch.empty(H, B * T, d, device=dev, dtype=torch.float32)
+    a.ctx, a.o_sb, a.o_st, a.lse = ptr(ctx), ctx.stride(0), ctx.stride(1), ptr(lse)
+    e = DecAttnDesc()
+    e.xn_bf16, e.w_bf16, e.wo_bf16, e.proj_bf16 = ptr(_need(xn, BF16)), ptr(_need(w, BF16)), ptr(_need(wo, BF16)), ptr(proj)
+    e.o_slabs, e.slab_stride, e.d_model, e.core = ptr(slabs), B * T * d, d, a
+    fn = lib().vlt5_cross_attn_fwd if cross else lib().vlt5_dec_self_attn_fwd
+    check(fn(C.byref(e), stream_ptr()), "vlt5_cross_attn_fwd" if cross else "vlt5_dec_self_attn_fwd")
+    return proj, ctx, lse, slabs
+
+
 def enc_attn_sublayer(x, ln_w, wqkv, wo, B, S, H, bias=None, key_mask=None, mask_value=-10000.0, eps=1e-6, drop_p=0.0, seeds=(0, 0)):
     """Forward of the whole encoder self-attention sublayer through `vlt5_enc_attn_fwd` (norm, fused q|k|v projection + core, output
     projection with dropout + residual).  x f32 [B*S, d]; wqkv bf16 [3*H*64, d]; wo bf16 [d, H*64].  Returns (x_out, saved) where
