@@ -57,10 +57,11 @@ class VLT5VQA(VLT5):
         key/value cache (`vlt5_decoder_step`)."""
         from ._lib import Vlt5Error
         if getattr(self.cfg, "classifier", False):
-            # vqa_model.py:81-108: a discriminative `answer_head` over the decoder state -- no launch script of the reference
-            # enables it (`--classifier` is never passed) and the engine has no such head
-            raise NotImplementedError("config.classifier=True (answer_head classification) is not part of the engine; "
-                                      "the reference's scripts use the generative path")
+            # vqa_model.py:81-108 applies `self.answer_head` to the last decoder state -- a module the reference never DEFINES
+            # (the only two mentions in its tree are the calls at vqa_model.py:102 and nextqa/vqa_model_nextqa.py:103), so the
+            # branch raises AttributeError there; no launch script passes `--classifier`.  Same outcome here, said plainly.
+            raise NotImplementedError("config.classifier=True: the reference's own branch calls an undefined `answer_head` "
+                                      "(vqa_model.py:102); its scripts use the generative path")
         # the reference forwards **kwargs to HF `generate`; the engine decodes greedily and says so instead of dropping options
         allowed = {"max_length", "num_beams", "eos_token_id", "use_cache", "do_sample", "early_stopping"}
         unknown = set(kwargs) - allowed
