@@ -299,7 +299,7 @@ def trace_roofline(gflop_per_step):
             steps = int(m.group(1))
         if line.startswith("#") or line.startswith("kernel "):
             continue
-        if any(k in line for k in ("gemm_kernel<", "qkv_attn_fwd_kernel", "skinny_kernel<", "dec_attn_fwd_kernel")):
+        if any(k in line for k in ("gemm_kernel<", "qkv_attn_fwd", "skinny_kernel<", "dec_attn_fwd_kernel")):
             f = line.split()
             nums = [x for x in f if re.fullmatch(r"[0-9.]+", x)]
             fam_ms += float(nums[-5])                   # columns: calls total_ms avg_us min_us max_us %
@@ -471,7 +471,7 @@ def main():
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03*_pmc_hbm_traffic.json"))) or \
             sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_hbm_traffic.json")))
         if pmcs:          # HBM bytes per GEMM launch from the committed PMC passes of THIS round's build (tagged; not measured in this run)
-            g = [r for r in json.load(open(pmcs[-1])) if any(k in r["kernel"] for k in ("gemm_kernel", "skinny_kernel", "qkv_attn_fwd_kernel", "dec_attn_fwd_kernel"))]
+            g = [r for r in json.load(open(pmcs[-1])) if any(k in r["kernel"] for k in ("gemm_kernel", "skinny_kernel", "qkv_attn_fwd", "dec_attn_fwd_kernel"))]
             if g:
                 out["roofline"]["traffic"] = round(sum(r["calls"] * r["hbm_mb"] for r in g) / sum(r["calls"] for r in g) * 1e6)
                 out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(pmcs[-1])} (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"
