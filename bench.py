@@ -235,7 +235,7 @@ def parity_vs_oracle(model, dev, B):
         res["logits_rel_max_err"] = round(res["logits_rel_max_err"], 5)
         res["loss_tok_abs_err"] = round(res["loss_tok_abs_err"], 5)
         res["loss_abs_err"] = round(res["loss_abs_err"], 6)
-        res["tolerance"] = "logits 3e-2 rel, loss 2e-2 abs, grad cos >= 0.97, indices exact where the top-2 margin > 1e-2"
+        res["tolerance"] = "logits 3e-2 rel, loss 2e-2 abs, grad cos >= 0.99, indices exact where the top-2 margin > 1e-2"
         return res
     finally:
         for p in model.parameters():
