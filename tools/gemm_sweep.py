@@ -67,7 +67,9 @@ def main():
         Bm = torch.randn((K, N) if bkm else (N, K), device=dev).to(BF)
         out = torch.empty(M, N, device=dev, dtype=torch.float32 if of32 else BF)
         row = dict(M=M, N=N, K=K, akm=akm, bkm=bkm, count=count, gflop=2.0 * M * N * K / 1e9, t={})
-        for tile in (((0, 0),) if auto_only else ((0, 0), (256, 256), (224, 256), (160, 256), (128, 128), (128, 64), (64, 128), (64, 64))):
+        # (the heuristic's own choice is timed LAST: the first timing of a shape also pays the first touch of a freshly allocated output --
+        # +9 us on the 171 MB output of the stacked cross-K/V projection)
+        for tile in (((0, 0),) if auto_only else ((256, 256), (224, 256), (160, 256), (128, 128), (128, 64), (64, 128), (64, 64), (0, 0))):
             if akm and tile[0] in (224, 160):
                 continue
             splits = (1, 2, 4, 8) if (akm and bkm and of32 and M * N % 1 == 0 and K >= 1024) else (1,)
