@@ -137,7 +137,13 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
             // flop (sweep r01_f: 26.0 vs 27.5 us on 4480x768x2304, 171.6 vs 182.3 on 4640x768x18432)
             if (!d->a_kmajor && d->b_kmajor) { bm = 128; bn = 64; } else { bm = 64; bn = 128; }
         }
-        else { bm = 64; bn = 64; }                                     // small-M (decoder) problems: most workgroups
+        else {
+            bm = 64; bn = 64;                                          // small-M (decoder) problems: most workgroups
+            // ... except a wide input gradient (decoder FFN-out dgrad 400 x 3072 x 768 with its ReLU gate): 192 tiles of 128 x 64 read
+            // the transpose-read weight operand half as often (replay 8.0 against 9.5 us; VLT5_GEMM_DEC_TALL=0: the 64 x 64 tiles)
+            static const int tall = getenv("VLT5_GEMM_DEC_TALL") ? atoi(getenv("VLT5_GEMM_DEC_TALL")) : 1;
+            if (tall && !d->a_kmajor && d->b_kmajor && d->N >= 2048 && tiles(128, 64) >= 160) { bm = 128; bn = 64; }
+        }
     }
     if (emit && bn > 128) { bm = 64; bn = 128; }     // (the norm-emitting epilogue lives in the 4-wave tiles: two column slices per tile)
     if (!(((bm == 128 || bm == 64) && (bn == 128 || bn == 64)) || ((bm == 256 || bm == 224 || bm == 160) && bn == 256))) return VLT5_ERR_ARG;
