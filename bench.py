@@ -26,6 +26,134 @@ import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # this pool's driver only supports dmabuf IPC (RCCL across processes)
 
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=80)
+    ap.add_argument("--store-images", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-side-values", action="store_true", help="skip the resident-batch / PCIe / feed-kernel / warm-replay side figures")
+    ap.add_argument("--eager-baseline", action="store_true", help="also time the torch-eager restatement on the GPU (SURVEY 8d)")
+    ap.add_argument("--overlap-optimizer", action="store_true", help="run the optimizer update on a second stream (see FusedAdamW)")
+    ap.add_argument("--dp-algo", default=os.environ.get("VQACL_DP_ALGO", "auto"), help="gradient exchange of the DP wrapper (parallel.py)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run through the rank launcher and the data-parallel wrapper (RCCL) even with --gpus 1")
+    ap.add_argument("--dry-launch", action="store_true", help="print the environment and command of every rank the launcher would start, start nothing")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="seconds before the launcher gives up on its ranks")
+    return ap.parse_args(argv)
+
+
+# ---- rank launcher ----------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` (no WORLD_SIZE in the environment) has to BE an N-rank job: this parent process starts N copies of
+# itself, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what `python -m torch.distributed.run` would export),
+# relays rank 0's JSON line as its own last stdout line and fails if any rank fails.  It runs before torch is imported and never
+# touches the GPU (a process that initialised HIP must not exec or fork workers on this pool).  Under torch.distributed.run the
+# environment already carries WORLD_SIZE: then this process is a rank and --gpus must agree with it.
+RANK_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "VQACL_FORCE_DIST")
+
+
+def launch_plan(args, argv, environ=None, port=None):
+    """None when this process is itself a rank (or a plain single-process run); otherwise the list of (env additions, command)
+    of the ranks to start.  Raises SystemExit when --gpus contradicts an inherited WORLD_SIZE."""
+    environ = os.environ if environ is None else environ
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    inherited = environ.get("WORLD_SIZE")
+    if inherited is not None:
+        if int(inherited) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={inherited} in the environment: the launcher that set "
+                             f"WORLD_SIZE started {inherited} ranks; pass --gpus {inherited} or unset WORLD_SIZE")
+        return None                                        # a rank of somebody else's launcher (torch.distributed.run)
+    if args.gpus == 1 and not (args.force_dist or environ.get("VQACL_FORCE_DIST") == "1"):
+        return None                                        # the plain single-process run
+    if port is None:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    child_argv = [a for a in argv if a not in ("--dry-launch",)]
+    plan = []
+    for r in range(args.gpus):
+        env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+        if args.gpus == 1:
+            env["VQACL_FORCE_DIST"] = "1"
+        plan.append((env, [sys.executable, os.path.abspath(__file__)] + child_argv))
+    return plan
+
+
+def run_launcher(args, argv):
+    """Start the ranks of launch_plan(), wait, relay.  Returns the exit code of the job."""
+    import subprocess
+    import threading
+    plan = launch_plan(args, argv)
+    if plan is None:
+        return None
+    if args.dry_launch:
+        for env, cmd in plan:
+            print(json.dumps({"env": env, "cmd": cmd}), flush=True)
+        return 0
+    procs, lines = [], []
+
+    def pump(rank, stream):            # every rank's stdout: rank 0's last JSON object is the bench line, the rest goes to stderr
+        for raw in stream:
+            line = raw.rstrip("\n")
+            if rank == 0 and line.startswith("{") and '"metric"' in line:
+                lines.append(line)
+            else:
+                print(f"[rank {rank}] {line}", file=sys.stderr, flush=True)
+    threads = []
+    for r, (env, cmd) in enumerate(plan):
+        p = subprocess.Popen(cmd, env={**os.environ, **env}, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+        procs.append(p)
+        t = threading.Thread(target=pump, args=(r, p.stdout), daemon=True)
+        t.start()
+        threads.append(t)
+    deadline = time.time() + args.launch_timeout
+    rc, alive = 0, set(range(len(procs)))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is not None:
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py launcher: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+        if (rc != 0 or time.time() > deadline) and alive:
+            if rc == 0:
+                rc = 124
+                print("bench.py launcher: timed out waiting for the ranks", file=sys.stderr, flush=True)
+            for r in alive:                                # exactly the processes started above
+                procs[r].terminate()
+            for r in alive:
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            alive.clear()
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5)
+    if rc == 0 and not lines:
+        print("bench.py launcher: rank 0 printed no JSON line", file=sys.stderr, flush=True)
+        rc = 1
+    if lines:
+        sys.stderr.flush()
+        print(lines[-1], flush=True)
+    return rc
+
+
+if __name__ == "__main__":
+    _rc = run_launcher(parse_args(), sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
+
 import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -283,31 +411,49 @@ def cpu_baseline(budget_s=30.0):
                         f"{time.time() - t_all:.0f} s of CPU work in all"))
 
 
-def trace_roofline(gflop_per_step):
-    """`frac` recomputed from the committed rocprofv3 kernel trace of this round's build (profiles/r03*_kernel_stats_bench_b80.txt, the
-    same bench command under --kernel-trace): time of the GEMM family per optimizer step from the trace, FLOPs per step from the
-    in-situ records of this run (same launches).  The event-timed `frac` perturbs the step it measures; this one does not."""
+def committed_profile(pattern):
+    """The newest committed profile file matching `pattern` (profiles/rNN_x_<pattern>), rounds newest first."""
     import glob
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{rnd}*_{pattern}")))
+        if files:
+            return files[-1]
+    return None
+
+
+def trace_roofline(gflop_per_step):
+    """`frac` recomputed from the committed rocprofv3 kernel trace (profiles/rNN*_kernel_stats_bench_b80.txt, the same bench command
+    under --kernel-trace): time of the GEMM family per optimizer step from the trace, FLOPs per step from the in-situ records of this
+    run (same launches).  The event-timed `frac` perturbs the step it measures; this one does not.  Only quoted when the trace was
+    taken with THIS build: the stats file carries the hash of the kernel sources (tools/rocpd_stats.py), a trace of another build is
+    named with `trace_stale` and no figure."""
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03*_kernel_stats_bench_b80.txt")))
-    if not files:
+    from vqacl_amd.build import source_hash
+    f = committed_profile("kernel_stats_bench_b80.txt")
+    if not f:
         return None
-    steps, fam_ms = None, 0.0
-    for line in open(files[-1]):
+    steps, fam_ms, sha, col = None, 0.0, None, None
+    for line in open(f):
         m = re.match(r"# (\d+) optimizer steps in the trace", line)
         if m:
             steps = int(m.group(1))
-        if line.startswith("#") or line.startswith("kernel "):
+        m = re.match(r"# source_sha16 (\w+)", line)
+        if m:
+            sha = m.group(1)
+        if line.startswith("kernel "):
+            col = line.split().index("total_ms") - len(line.split())        # column of total_ms counted from the end of the row
+            continue
+        if line.startswith("#") or col is None:
             continue
         if any(k in line for k in ("gemm_kernel<", "qkv_attn_fwd", "skinny_kernel<", "dec_attn_fwd_kernel")):
-            f = line.split()
-            nums = [x for x in f if re.fullmatch(r"[0-9.]+", x)]
-            fam_ms += float(nums[-5])                   # columns: calls total_ms avg_us min_us max_us %
+            fam_ms += float(line.split()[col])
+    src = f"profiles/{os.path.basename(f)}"
+    if sha != source_hash():
+        return dict(trace_stale=True, trace_source=src, trace_note="kernel trace of another build (source hash differs): no frac_trace quoted")
     if not steps or fam_ms <= 0:
         return None
     ms = fam_ms / steps
-    return dict(frac_trace=round(gflop_per_step / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), gemm_ms_per_step_trace=round(ms, 3),
-                trace_source=f"profiles/{os.path.basename(files[-1])}")
+    return dict(frac_trace=round(gflop_per_step / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), gemm_ms_per_step_trace=round(ms, 3), trace_source=src)
 
 
 def eager_gpu_baseline(dev, B=80, steps=5):
@@ -347,25 +493,13 @@ def eager_gpu_baseline(dev, B=80, steps=5):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=80)
-    ap.add_argument("--store-images", type=int, default=4096)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--no-side-values", action="store_true", help="skip the resident-batch / PCIe / feed-kernel / warm-replay side figures")
-    ap.add_argument("--eager-baseline", action="store_true", help="also time the torch-eager restatement on the GPU (SURVEY 8d)")
-    ap.add_argument("--overlap-optimizer", action="store_true", help="run the optimizer update on a second stream (see FusedAdamW)")
-    ap.add_argument("--dp-algo", default=os.environ.get("VQACL_DP_ALGO", "auto"), help="gradient exchange of the DP wrapper (parallel.py)")
-    args = ap.parse_args()
+    args = parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or os.environ.get("VQACL_FORCE_DIST") == "1"     # the env switch exercises the RCCL path on 1 GPU
+    assert world == args.gpus, (world, args.gpus)            # (launch_plan() refuses a WORLD_SIZE that contradicts --gpus)
+    distributed = world > 1 or args.force_dist or os.environ.get("VQACL_FORCE_DIST") == "1"   # --force-dist: the RCCL path on 1 GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if distributed:
@@ -459,22 +593,29 @@ def main():
            "step_frac_of_mfma_peak": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
     if distributed:
         out["rccl_ranks_seen"] = dist.get_world_size()
+        out["grad_exchange"] = dp_info
+        out["launcher"] = "bench.py" if os.environ.get("LOCAL_WORLD_SIZE") and "TORCHELASTIC_RUN_ID" not in os.environ else "external"
     solo = rank == 0 and world == 1 and not distributed
 
-    if solo and not args.no_roofline:
-        # in-situ roofline of the dominant kernel family: real steps, every GEMM dispatch timed
-        out["roofline"] = insitu_gemm_roofline(lambda i: step_store(n_total + i), 8)
-        import glob
+    if not args.no_roofline:
+        # in-situ roofline of the dominant kernel family: real steps, every GEMM dispatch timed.  Under data parallelism EVERY rank
+        # runs the same extra steps (their collectives have to pair up); rank 0's records are the ones reported
+        roof = insitu_gemm_roofline(lambda i: step_store(n_total + i), 8)
+        if rank == 0:
+            out["roofline"] = roof
+    if solo and "roofline" in out:
         tr = trace_roofline(out["roofline"]["gflop_per_launch"] * out["roofline"]["launches_per_step"])
         if tr:
             out["roofline"].update(tr)
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03*_pmc_hbm_traffic.json"))) or \
-            sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_hbm_traffic.json")))
-        if pmcs:          # HBM bytes per GEMM launch from the committed PMC passes of THIS round's build (tagged; not measured in this run)
-            g = [r for r in json.load(open(pmcs[-1])) if any(k in r["kernel"] for k in ("gemm_kernel", "skinny_kernel", "qkv_attn_fwd", "dec_attn_fwd_kernel"))]
+        pmc = committed_profile("pmc_hbm_traffic.json")
+        if pmc:           # HBM bytes per GEMM launch from the committed PMC passes (tagged with the build they were taken with; not measured in this run)
+            g = [r for r in json.load(open(pmc)) if any(k in r.get("kernel", "") for k in ("gemm_kernel", "skinny_kernel", "qkv_attn_fwd", "dec_attn_fwd_kernel"))]
+            meta = [r for r in json.load(open(pmc)) if "source_sha16" in r]
+            from vqacl_amd.build import source_hash
             if g:
                 out["roofline"]["traffic"] = round(sum(r["calls"] * r["hbm_mb"] for r in g) / sum(r["calls"] for r in g) * 1e6)
-                out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(pmcs[-1])} (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"
+                out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"
+                out["roofline"]["traffic_build_matches"] = bool(meta and meta[0]["source_sha16"] == source_hash())
 
     if solo and not args.no_side_values:
         resident = {k: v.to(dev) for k, v in synthetic_batch(B, L, V, T, seed=66666).items()}

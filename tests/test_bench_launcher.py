@@ -1,0 +1,96 @@
+"""bench.py's rank launcher on CPU: `python bench.py --gpus N` without WORLD_SIZE has to start N ranks itself (before torch is
+imported, without touching a GPU), relay rank 0's JSON line as its last stdout line and fail when a rank fails; under an external
+launcher (WORLD_SIZE set) it must be a rank, and a --gpus that contradicts WORLD_SIZE is an error, not a silent 1-rank number."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                          "VQACL_FORCE_DIST")}
+    env.update(extra)
+    return env
+
+
+@pytest.mark.parametrize("n", [1, 2, 8])
+def test_dry_launch_prints_one_rank_environment_per_gpu(n):
+    flags = ["--gpus", str(n), "--steps", "3", "--warmup", "1", "--dry-launch"] + (["--force-dist"] if n == 1 else [])
+    res = subprocess.run([sys.executable, BENCH] + flags, env=_clean_env(), capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    plans = [json.loads(line) for line in res.stdout.strip().splitlines()]
+    assert len(plans) == n
+    ports = {p["env"]["MASTER_PORT"] for p in plans}
+    assert len(ports) == 1 and 1024 < int(ports.pop()) < 65536
+    for r, p in enumerate(plans):
+        e = p["env"]
+        assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["LOCAL_WORLD_SIZE"]) == (str(r), str(r), str(n), str(n))
+        assert e["MASTER_ADDR"] == "127.0.0.1" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        assert (e.get("VQACL_FORCE_DIST") == "1") == (n == 1)
+        assert p["cmd"][1] == BENCH and "--dry-launch" not in p["cmd"]
+        assert p["cmd"][2:4] == ["--gpus", str(n)] and "--steps" in p["cmd"]
+
+
+def test_plain_single_gpu_run_and_external_launcher_are_not_relaunched():
+    sys.path.insert(0, ROOT)
+    import bench
+    args = bench.parse_args(["--gpus", "1"])
+    assert bench.launch_plan(args, ["--gpus", "1"], environ={}) is None                       # the driver's 1-GPU call: one process
+    args = bench.parse_args(["--gpus", "4"])
+    assert bench.launch_plan(args, ["--gpus", "4"], environ={"WORLD_SIZE": "4", "RANK": "2"}) is None     # a rank of torch.distributed.run
+    assert len(bench.launch_plan(args, ["--gpus", "4"], environ={}, port=29999)) == 4
+    with pytest.raises(SystemExit) as ei:                                                  # --gpus 8 under a 1-rank WORLD_SIZE: refuse
+        bench.launch_plan(bench.parse_args(["--gpus", "8"]), ["--gpus", "8"], environ={"WORLD_SIZE": "1"})
+    assert "WORLD_SIZE=1" in str(ei.value)
+    # VQACL_FORCE_DIST=1 (the old switch) still goes through the launcher
+    one = bench.launch_plan(bench.parse_args(["--gpus", "1"]), ["--gpus", "1"], environ={"VQACL_FORCE_DIST": "1"}, port=29999)
+    assert len(one) == 1 and one[0][0]["WORLD_SIZE"] == "1" and one[0][0]["VQACL_FORCE_DIST"] == "1"
+
+
+def test_gpus_contradicting_world_size_fails_loudly():
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-launch"], env=_clean_env(WORLD_SIZE="2"), capture_output=True, text=True,
+                         timeout=120)
+    assert res.returncode != 0 and "--gpus 8 but WORLD_SIZE=2" in (res.stderr + res.stdout)
+
+
+def _stub_plan(monkeypatch, bodies):
+    import bench
+    plan = [({"RANK": str(r), "WORLD_SIZE": str(len(bodies))}, [sys.executable, "-c", body]) for r, body in enumerate(bodies)]
+    monkeypatch.setattr(bench, "launch_plan", lambda args, argv, environ=None, port=None: plan)
+    return bench
+
+
+def test_launcher_relays_rank0_line_last(monkeypatch, capfd):
+    line = json.dumps({"metric": "vqa_train_samples_per_sec", "value": 1.0, "n_gpus": 2, "rccl_ranks_seen": 2})
+    sys.path.insert(0, ROOT)
+    bench = _stub_plan(monkeypatch, [
+        f"import sys; print('RCCL version banner'); print({line!r}); print('trailing noise', file=sys.stderr)",
+        "import time; time.sleep(0.3); print('rank 1 chatter')"])
+    rc = bench.run_launcher(bench.parse_args(["--gpus", "2"]), ["--gpus", "2"])
+    out, err = capfd.readouterr()
+    assert rc == 0
+    assert out.strip().splitlines()[-1] == line and out.count('"metric"') == 1       # the line, once, last on stdout
+    assert "RCCL version banner" in err and "rank 1 chatter" in err                        # everything else goes to stderr
+
+
+def test_launcher_fails_when_a_rank_fails_and_stops_the_others(monkeypatch, capfd):
+    sys.path.insert(0, ROOT)
+    bench = _stub_plan(monkeypatch, ["import time; time.sleep(120)", "import sys; sys.exit(3)"])
+    t0 = time.time()
+    rc = bench.run_launcher(bench.parse_args(["--gpus", "2"]), ["--gpus", "2"])
+    assert rc == 3 and time.time() - t0 < 60, "the surviving rank is terminated, not waited for"
+    out, err = capfd.readouterr()
+    assert '"metric"' not in out and "rank 1 exited with 3" in err
+
+
+def test_launcher_needs_a_json_line(monkeypatch, capfd):
+    sys.path.insert(0, ROOT)
+    bench = _stub_plan(monkeypatch, ["print('no line here')"])
+    assert bench.run_launcher(bench.parse_args(["--gpus", "1", "--force-dist"]), ["--gpus", "1", "--force-dist"]) == 1

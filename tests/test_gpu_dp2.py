@@ -74,7 +74,14 @@ def _worker(rank, world, port, q, grad_dtype, algo="allreduce", backend="gloo"):
             assert dp.shards_valid == (algo == "zero1")
             if it == 0:
                 torch.cuda.synchronize()
-                grads0 = model.flat_grads().clone()       # (zero1: all-gathers the reduced chunks -- collective; the step below is still the sharded one)
+                if algo == "zero1" and world > 1:       # a silent collective behind a gradient read would hang a rank-0-only caller: it raises
+                    from vqacl_amd._lib import Vlt5Error
+                    try:
+                        model.flat_grads()
+                        raise AssertionError("flat_grads() under zero1 must refuse to start a hidden collective")
+                    except Vlt5Error:
+                        pass
+                grads0 = model.flat_grads(collective=True).clone()       # (zero1: all-gathers the reduced chunks -- collective; the step below is still the sharded one)
                 assert dp.shards_valid == (algo == "zero1")
             opt.step()
             assert dp.params_sharded == (lazy and world > 1)

@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd (.db) kernel trace: per-kernel calls / total / average / share, like `--stats`.
 usage: python tools/rocpd_stats.py results.db [--steps N] > profiles/summary.txt   (steps default: counted from the trace)"""
+import os
 import re
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vqacl_amd.build import source_hash  # noqa: E402
 
 
 def main():
@@ -19,6 +23,7 @@ def main():
     rows = list(cur.execute(q))
     total = sum(r[2] for r in rows)
     span = list(cur.execute("select min(start), max(end) from rocpd_kernel_dispatch"))[0]
+    print(f"# source_sha16 {source_hash()}   (vqacl_amd.build.source_hash() of the tree this trace was taken with)")
     print(f"# kernels: {sum(r[1] for r in rows)} dispatches, {total / 1e6:.3f} ms busy, span {(span[1] - span[0]) / 1e6:.3f} ms")
     if steps is None:                                   # one "final" reduction of the gradient norm per optimizer step (either path)
         steps = sum(r[1] for r in rows if "gnorm_final_kernel" in r[0] or "sqnorm_final_kernel" in r[0]) or None

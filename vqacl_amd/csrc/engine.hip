@@ -136,7 +136,7 @@ struct Plan {
     size_t dec_out, logits, lse_ce, loss_tok, row_w, loss;
     size_t ssq_e[2 * MAXL + 1], ssq_d[3 * MAXL + 1];      // per-norm partial sums of squares of the residual stream (norm folded around its GEMMs)
     // backward scratch
-    size_t dx, tmp, dctx, dkv_all, d_enc_ext, dS_enc, dS_dec, dlogits, slab, ln_partial, vis_partial, rel_scratch, vis_dG, small, slab2;
+    size_t dx, tmp, embed_scratch, dctx, dkv_all, d_enc_ext, dS_enc, dS_dec, dlogits, slab, ln_partial, vis_partial, rel_scratch, vis_dG, small, slab2;
     // per-layer gradient operands kept until the end of the phase: the weight-gradient GEMMs of all layers run as ONE
     // batched launch per weight kind (grid.z = layer)
     size_t e_dyd_f[MAXL], e_dh[MAXL], e_dyd_a[MAXL], e_dqkv[MAXL];
@@ -188,6 +188,7 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     const size_t Mmax = Mx > Md ? Mx : Md;
     p.dx = take(Mmax * d * 4);
     p.tmp = take(Mmax * d * 4);
+    p.embed_scratch = take((size_t)vlt5_embed_bwd_scratch_bytes(B, L > T ? L : T, (int)d));   // (its own range: larger than tmp when V is tiny)
     p.dctx = take(Mmax * (inner > (c.gated_act ? ff : 0) ? inner : ff) * 2);     // (gated FFN: also the hidden-gradient scratch [M, ff])
     for (int l = 0; l < Le; ++l) {
         p.e_dyd_f[l] = take(M * d * 2); p.e_dh[l] = take(M * ffw * 2); p.e_dyd_a[l] = take(M * d * 2);
@@ -868,7 +869,8 @@ int decoder_bwd(const Ctx& k) {
         }
         for (int b = 0; b <= Ld; ++b) RC(ks.record(b));     // decoder-side gradient buckets are complete (rel-bias: before the fork)
     }
-    RC(vlt5_embed_bwd(ids, dx, (long long)T * d, d, k.Gr + L.shared, B, T, d, c.vocab, k.pdrop, k.seed(SITE_DEC_EMBED), T, 0, tmp, k.st));
+    RC(vlt5_embed_bwd(ids, dx, (long long)T * d, d, k.Gr + L.shared, B, T, d, c.vocab, k.pdrop, k.seed(SITE_DEC_EMBED), T, 0,
+                       k.w<void>(p.embed_scratch), k.st));
     RC(k.lin_dgrad(k.w<bf16_t>(p.dkv_all), k.Pb + L.cross_kv, k.w<void>(p.d_enc_ext), Mx, kvw, d, 1));
     RC(k.ln_flush());
     return VLT5_OK;
@@ -976,7 +978,8 @@ int encoder_bwd(const Ctx& k) {
                         c.rel_buckets, 0, k.st));
     RC(k.mirror_small(L.enc_rel, (long long)c.rel_buckets * k.H));
     // inputs: text rows -> shared (scatter-add), visual rows -> visual embedding parameters
-    RC(vlt5_embed_bwd(s.input_ids, dx, (long long)S * d, d, k.Gr + L.shared, B, s.L, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, 0, tmp, k.st));
+    RC(vlt5_embed_bwd(s.input_ids, dx, (long long)S * d, d, k.Gr + L.shared, B, s.L, d, c.vocab, k.pdrop, k.seed(SITE_ENC_EMBED), S, 0,
+                       k.w<void>(p.embed_scratch), k.st));
     float* vpart = k.w<float>(p.vis_partial);
     RC(vlt5_vis_embed_bwd(dx + (size_t)s.L * d, (long long)S * d, d, k.w<float>(p.visG), k.boxes(), k.P + L.vis_wp, k.P + L.vis_bp,
                           k.P + L.vis_lnf, k.P + L.vis_lnp, k.w<float>(p.vis_rf), k.w<float>(p.vis_rp), k.w<void>(p.vis_dG), vpart,

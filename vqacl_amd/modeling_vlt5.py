@@ -358,9 +358,17 @@ class VLT5(nn.Module):
         self._require_whole_master("flat_params()")
         return self._flat
 
-    def flat_grads(self):
-        if self.dp is not None and (getattr(self.dp, "g16_valid", False) or getattr(self.dp, "shards_valid", False)):
-            self.dp.materialize_grads(self)      # data parallel: the averaged gradients are still bf16 / only this rank's chunks are reduced (collective under zero1)
+    def flat_grads(self, collective=False):
+        """The flat f32 gradient buffer `.grad` views.  Data parallel: the averaged gradients may still lie in the bf16 staging
+        buffer (a local cast), or -- zero1, between backward and the optimizer step -- only this rank's chunks are reduced and the
+        rest has to be all-gathered: a COLLECTIVE every rank must enter.  That case raises unless the caller says
+        `collective=True` (a rank-0-only gradient-norm log would otherwise hang the job)."""
+        dp = self.dp
+        if dp is not None and getattr(dp, "shards_valid", False) and getattr(dp, "world", 1) > 1 and not collective:
+            raise L.Vlt5Error("flat_grads(): under DataParallelVLT5(algo='zero1') the gradients are reduce-scattered between backward "
+                              "and the optimizer step; completing them is a collective -- call flat_grads(collective=True) on EVERY rank")
+        if dp is not None and (getattr(dp, "g16_valid", False) or getattr(dp, "shards_valid", False)):
+            dp.materialize_grads(self)
         return self._flat_grad
 
     def flat_bf16(self):
@@ -380,6 +388,12 @@ class VLT5(nn.Module):
         self.sync_optimizer()
         res = super().load_state_dict(state_dict, strict=strict, **kw)
         self._bf16_version = -1
+        if self.dp is not None and getattr(self.dp, "params_sharded", False):
+            # zero1 with gather_master=False: a state dict that carries every trained tensor overwrote the whole f32 master on this
+            # rank, so parameter reads are local again (the Adam moments stay sharded: they belong to the owning rank either way)
+            missing = {k for k in getattr(res, "missing_keys", ()) if self._pinfo.get(k, (0, 0, 0, 0, 0))[4]}
+            if not missing:
+                self.dp.params_sharded = False
         return res
 
     def _lut(self, q, k, bidirectional):
@@ -554,7 +568,9 @@ class VLT5(nn.Module):
             target = self._flat_grad
         else:
             if self.dp is not None and (getattr(self.dp, "g16_valid", False) or getattr(self.dp, "shards_valid", False)):
-                self.dp.materialize_grads(self)  # accumulate onto the averaged gradients of the previous backward, not the local / partly reduced ones
+                # accumulate onto the averaged gradients of the previous backward, not the local / partly reduced ones.  (zero1: an
+                # all-gather -- fine HERE, every rank runs this backward and its other collectives at the same point anyway)
+                self.dp.materialize_grads(self)
             if self._flat_grad_tmp is None:
                 self._flat_grad_tmp = torch.zeros_like(self._flat_grad)
             target = self._flat_grad_tmp

@@ -46,6 +46,23 @@ import torch.distributed as dist
 ALGOS = ("auto", "allreduce", "rs_ag", "zero1")
 
 
+def pick_algo(world, algo="auto"):
+    """The gradient exchange a wrapper over `world` ranks uses.  Slices are multiples of 64 elements, so chunks of a slice stay
+    multiples of 8 elements (16 bytes of bf16, what the chunk kernels read) exactly when the world size divides 8: "auto" shards
+    (zero1) for those and falls back to "allreduce" otherwise; asking for rs_ag / zero1 explicitly with any other world size raises."""
+    if algo not in ALGOS:
+        raise ValueError(f"algo must be one of {ALGOS}")
+    world = int(world)
+    if world < 1:
+        raise ValueError("world size must be >= 1")
+    divides = 8 % world == 0
+    if algo == "auto":
+        return "zero1" if (world > 1 and divides) else "allreduce"
+    if algo != "allreduce" and not divides:
+        raise ValueError("rs_ag / zero1 need a world size that divides 8 (chunks of a slice must stay 16-byte aligned in bf16)")
+    return algo
+
+
 class DataParallelVLT5:
     def __init__(self, model, process_group=None, bucket_mb=128, average=True, grad_dtype=None, algo="auto", small_group=True,
                  gather_master=True):
@@ -54,18 +71,12 @@ class DataParallelVLT5:
             grad_dtype = torch.bfloat16 if model._flat.is_cuda else torch.float32
         if grad_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("grad_dtype must be torch.float32 or torch.bfloat16")
-        if algo not in ALGOS:
-            raise ValueError(f"algo must be one of {ALGOS}")
         self.grad_dtype = grad_dtype
         self._g16 = None
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
-        if algo == "auto":
-            algo = "zero1" if (self.world > 1 and 8 % self.world == 0) else "allreduce"
-        if algo != "allreduce" and 8 % self.world != 0:
-            raise ValueError("rs_ag / zero1 need a world size that divides 8 (chunks of a slice must stay 16-byte aligned in bf16)")
-        self.algo = algo
+        self.algo = pick_algo(self.world, algo)
         self.gather_master = bool(gather_master)
         self.master_ready = None            # event behind the f32-master all-gather of the last sharded step (gather_master)
         self.average = average
