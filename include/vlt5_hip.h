@@ -9,8 +9,9 @@
  *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
  *     (the engine never allocates); `stream` is a hipStream_t passed as void*.
  *   - all functions are stream-ordered and re-entrant; one stream per calling thread.  The only process state: per-kernel,
- *     per-device "large LDS enabled" flags (atomic), and two measurement / experiment hooks that the product path never turns
- *     on -- the GEMM timing recorder (vlt5_gemm_timing_*, not thread-safe) and read-once VLT5_* environment knobs for A/B runs.
+ *     per-device "large LDS enabled" flags (atomic) and one measurement hook that the product path never turns on -- the GEMM
+ *     timing recorder (vlt5_gemm_timing_*, not thread-safe).  The library reads NO environment variables: experiment switches
+ *     travel in a vlt5_tuning record the caller passes (vlt5_step.tuning, vlt5_gemm_desc.tuning; NULL = the defaults).
  *   - return 0 on success, VLT5_ERR_* for argument errors, otherwise the hipError_t of the launch.
  *     Nothing throws across the ABI.
  *   - "bf16" tensors are raw 16-bit bfloat16; contiguous (feature) dimensions must be multiples of 8.
@@ -26,9 +27,31 @@ extern "C" {
 #define VLT5_OK 0
 #define VLT5_ERR_ARG 1001
 #define VLT5_ERR_ALIGN 1002
-#define VLT5_ABI_VERSION 4
+#define VLT5_ABI_VERSION 5
 
 int vlt5_abi_version(void);
+
+/* ---- experiment switches (A/B runs, tests of the alternative paths) -------------------------------------------------------
+ * Every field: 0 = the library's default; the product path passes NULL or an all-zero record.  Read by the call that receives it,
+ * never stored -- no process state.  (The host side fills it once from VLT5_* environment variables: vqacl_amd/_lib.py.) */
+typedef struct {
+    int fold_norm;          /* 1: encoder RMS norms as stand-alone launches (unfolded); 2: folded (default) */
+    int fold_norm_dec;      /* 2: also fold the decoder's cross / FFN norms (default 1: off) */
+    int fused_attn;         /* 1: encoder q|k|v GEMM + attention core as separate launches; 2: the fused kernel (default) */
+    int fused_heads;        /* heads per workgroup of the fused encoder kernel: 1 or 2 (default 2) */
+    int dec_fused;          /* 2: fused decoder attention sublayers (csrc/dec_attn.hip) in the training forward (default 1: off) */
+    int enc_cut;            /* > 0: number of encoder layers whose weight gradients run in the late group (default num_layers / 2) */
+    int wgrad_shadow;       /* 1: decoder weight gradients as launches of their own; 2: in the shadow of the encoder's (default) */
+    int wgrad_grouped;      /* 1: the two attention weight gradients of a layer group as two launches; 2: one grouped launch (default) */
+    int gemm_t128_kmkm;     /* > 0: tile-count threshold of the 128x128 tile for k-major/k-major problems (default 100) */
+    int gemm_t256_km;       /* > 0: ... of the 256x256 tile for a k-major A operand (default 160) */
+    int gemm_t256_min;      /* > 0: ... of the 8-wave tiles for a row-major A operand (default 100) */
+    int gemm_dec_tall;      /* 1: 64x64 tiles for the wide small-M input gradients; 2: 128x64 (default) */
+    int gemm_split_kmin;    /* > 0: shortest reduction the automatic split-K cuts (default 768) */
+    int decode_fast;        /* 1: greedy decoding steps through the tiled GEMM / attention launches of the training path;
+                               2: through the decode kernels (csrc/decode.hip; default where the shapes allow) */
+    int reserved[6];
+} vlt5_tuning;
 
 /* ---- GEMM: C[M,N] = epi(alpha * sum_k A[m,k] B[n,k]) -------------------------------------------
  * replaces nn.Linear in T5Attention q/k/v/o (HF T5Attention.forward), T5DenseReluDense wi/wo,
@@ -71,11 +94,13 @@ typedef struct vlt5_gemm_desc_s {
                                                 sumsq[z * sumsq_batch_stride + t], t < tiles of the launch's tile shape (at most
                                                 ceil(M/64)*ceil(N/64)); fixed reduction order -- the optimizer's gradient norm
                                                 without a second pass over the gradients (vlt5_gnorm_finish) */
+    const vlt5_tuning* tuning;               /* optional experiment switches of the tile policy (NULL = defaults) */
 } vlt5_gemm_desc;
 int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream);     /* writes d->split_used */
 long long vlt5_gemm_workspace_bytes(int M, int ldc, int split_k);
 /* the split-K factor the engine uses for a plain f32 output [M,N] reduced over Kred (1 = no split) */
 int vlt5_gemm_auto_split(int M, int N, int Kred, long long slab_bytes);
+int vlt5_gemm_auto_split_tuned(int M, int N, int Kred, long long slab_bytes, const vlt5_tuning* tuning);
 
 /* measurement hook for bench.py's roofline (no counterpart in the reference): while enabled (max_launches > 0; 0 disables and
  * frees), every GEMM kernel dispatch carries its own start/stop HIP events; collect() waits for them and returns one record per
@@ -150,6 +175,7 @@ typedef struct {
     const void* d_ctx; long long do_sb, do_st;
     void *dq, *dk_, *dv; long long dq_sb, dq_st, dk_sb, dk_st, dv_sb, dv_st;
     float* dbias;                            /* f32 [B,H,bias_q,bias_k] (per-sample dS block) or NULL */
+    int fused_heads;                         /* vlt5_qkv_attn_fwd* only: heads per workgroup, 0 = default (vlt5_tuning.fused_heads) */
 } vlt5_attn_desc;
 int vlt5_attn_fwd(const vlt5_attn_desc* d, void* stream);
 int vlt5_attn_bwd(const vlt5_attn_desc* d, void* stream);
@@ -432,6 +458,7 @@ typedef struct {
      * second problem of its long weight-gradient launches (they run on the CUs those leave idle).  The decoder's weight gradients
      * are then complete only after vlt5_encoder_bwd; ignored with a side stream / gradient-bucket events (data parallelism). */
     int defer_decoder_wgrads;
+    const vlt5_tuning* tuning;     /* optional experiment switches (NULL = defaults) */
 } vlt5_step;
 /* number of slots of vlt5_step.gnorm_partials for this configuration, or 0 when it is not supported (a matrix dimension that is
  * no multiple of 64: the slot ranges of neighbouring tensors would overlap) */
@@ -451,6 +478,7 @@ int vlt5_feat_gather(const void* store_bf16, const float* box_store, const long 
 /* vlt5_encoder_bwd completes the weight gradients of the encoder in two groups (events of vlt5_step.events): layers
  * [late, num_layers) mid-phase, layers [0, late) at the end; returns `late` */
 int vlt5_encoder_late_layers(int num_layers);
+int vlt5_encoder_late_layers_tuned(int num_layers, const vlt5_tuning* tuning);   /* with vlt5_tuning.enc_cut */
 /* a lowest-priority stream for vlt5_step.side_stream (hipStreamCreateWithPriority); the caller destroys it */
 int vlt5_side_stream_create(void** stream);
 int vlt5_side_stream_destroy(void* stream);
@@ -488,6 +516,52 @@ int vlt5_decoder_fwd(const vlt5_config* c, const vlt5_step* s, void* stream);
  * encoder output of the same step state (vlt5_encoder_fwd + prototype rows must have been written to the workspace). */
 int vlt5_decoder_step(const vlt5_config* c, const vlt5_step* s, const long long* tokens, int t, void* kv_cache, float* logits,
                       long long* next_ids, void* stream);
+/* The same step with HF generate's greedy-search loop body (vqa_model.py:112-116 -> GenerationMixin.greedy_search) on the device,
+ * so that the host only enqueues steps: after the vocabulary projection the emitted token of row b is argmax(logits_b), or pad_id
+ * once the row has produced eos_id; it is written to out_tokens[b*out_ld + t + 1], done[b] is updated, and the input embedding row
+ * and relative-position bias row of step t + 1 are prepared in the workspace -- `tokens` is only read at t == 0, steps must be
+ * issued in order t = 0, 1, ... on one workspace.  logits / next_ids may be NULL. */
+typedef struct {
+    const long long* tokens;       /* [B] decoder input at position 0 (decoder_start_token_id) */
+    int t;
+    void* kv_cache;                /* as for vlt5_decoder_step */
+    float* logits;                 /* [B, vocab] out, or NULL */
+    long long* next_ids;           /* [B] out: argmax of the logits (before the pad rule), or NULL */
+    long long* out_tokens; long long out_ld;    /* [B, out_ld >= T]: column t + 1 receives the emitted token */
+    int* done;                     /* [B] in/out: 1 once the row has emitted eos_id */
+    int eos_id, pad_id;
+} vlt5_greedy_desc;
+int vlt5_decoder_step_greedy(const vlt5_config* c, const vlt5_step* s, const vlt5_greedy_desc* g, void* stream);
+/* 1 if this configuration / shape / tuning record decodes through the decode kernels (vlt5_decoder_step_greedy is then available;
+ * vlt5_decoder_step uses them as well) */
+int vlt5_decode_fast_supported(const vlt5_config* c, const vlt5_step* s);
+
+/* ---- the kernels of a decoding step on their own (csrc/decode.hip) ---------------------------------------------------------
+ * vlt5_decode_linear: out[m, n] = act(rowscale[m] * alpha * sum_k A[m, k] W[n, k] (+ resid[m, n])) for a FEW rows (a decoding batch)
+ * against a bf16 weight [N, K] -- nn.Linear of T5Attention q/k/v/o, T5DenseReluDense wi/wo, lm_head on one token per sample.  A is
+ * bf16 (x_bf16), or the f32 residual stream (x_f32) with the T5LayerNorm in front of the projection folded in: operand
+ * bf16(x * norm_w), rows scaled by rsqrt(mean(x^2) + norm_eps).  Outputs: f32 (out_f32) and / or bf16 (out_bf16; columns >=
+ * split_col are routed to out_bf16_2 -- the k | v columns of a fused q|k|v projection straight into a cache slot).  K % 32 == 0 and
+ * K / 32 = KS * NW with KS in {1, 2, 6, 8 (, 12, 16 for bf16 A)}, NW in {1, 2, 4, 8} (vlt5_decode_linear_supported); N % 4 == 0.
+ * argmax_val / argmax_idx (optional, [rows][vlt5_decode_linear_tiles(...)]): first maximum of every row inside every column tile. */
+typedef struct {
+    const float* x_f32; const void* x_bf16; long long ldx;
+    const float* norm_w; float norm_eps;
+    const void* w_bf16; int rows, N, K;
+    float alpha;                                   /* 0 = 1 */
+    void* out_bf16; long long ld_out_bf16; int split_col; void* out_bf16_2; long long ld_out_bf16_2;
+    float* out_f32; long long ld_out_f32;
+    const float* resid; long long ld_resid;
+    int relu;
+    float* argmax_val; int* argmax_idx;
+} vlt5_decode_linear_desc;
+int vlt5_decode_linear(const vlt5_decode_linear_desc* d, void* stream);
+int vlt5_decode_linear_supported(int K, int norm_folded);
+int vlt5_decode_linear_tiles(int rows, int N, int K, int norm_folded);
+/* attention core for ONE query per (sample, head) (Tq == 1, no dropout, no causal mask: every cached key is visible): softmax in
+ * f32 over <= 64 keys, d_kv in {16, 32, 64}; vlt5_attn_desc as for vlt5_attn_fwd with q_sb the sample stride of q, k_sb == v_sb,
+ * k_st == v_st, bias [H][1][bias_k] (bias_q == 1), key_mask [B][Tk]; lse is not written. */
+int vlt5_decode_attn(const vlt5_attn_desc* d, void* stream);
 int vlt5_decoder_bwd(const vlt5_config* c, const vlt5_step* s, void* stream);
 int vlt5_encoder_bwd(const vlt5_config* c, const vlt5_step* s, void* stream);
 

@@ -146,12 +146,20 @@ def check_grads(model, oracle_grads, min_cos=0.99, skip=(), norm_tol=0.03):
     return worst
 
 
-def test_tiny_model_against_golden_fixture(dev):
+def set_tuning(model, tuning):
+    """Experiment switches of the engine for this model (vlt5_tuning, vqacl_amd/_lib.py make_tuning): in-process, no environment."""
+    if tuning:
+        from vqacl_amd._lib import make_tuning
+        model.tuning = make_tuning(**tuning)
+    return model
+
+
+def test_tiny_model_against_golden_fixture(dev, tuning=None):
     """3 scripted train steps (tasks 0,0,1; ragged L) of the committed tiny-model fixture."""
     from oracle import ref_cpu as R
     G = load_golden("g6_tiny_model")
     ocfg = R.tiny_cfg()
-    model = make_model(ocfg, un(G, "p__"), dev)
+    model = set_tuning(make_model(ocfg, un(G, "p__"), dev), tuning)
     model.train()
     for step, task in enumerate((0, 0, 1)):
         batch = {k[len(f"s{step}_in_"):]: v for k, v in G.items() if k.startswith(f"s{step}_in_")}
@@ -207,12 +215,12 @@ def _base_case(dev, B, seed, dropout=0.0, L=20, T=5):
     return ocfg, params, batch
 
 
-def test_base_model_forward_backward_vs_oracle(dev):
+def test_base_model_forward_backward_vs_oracle(dev, tuning=None):
     """VL-T5-base, B=4 (BASELINE config 1 shape), dropout off: logits / loss / every gradient vs the fp32 CPU oracle."""
     from oracle import ref_cpu as R
     torch.set_num_threads(8)
     ocfg, params, batch = _base_case(dev, B=4, seed=1234)
-    model = make_model(ocfg, params, dev)
+    model = set_tuning(make_model(ocfg, params, dev), tuning)
     model.train()
     oracle = R.OracleModel(ocfg, params)
     o = oracle.train_step(batch, 0, 0.5, 0.3, training=True)
@@ -569,9 +577,11 @@ def test_loading_weights_after_an_optimizer_step_refreshes_the_bf16_shadow(dev, 
     assert fwd_err(pa) < 3e-2
 
 
-def test_incremental_decoder_step_matches_full_decoder_logits(dev):
+@pytest.mark.parametrize("fast", [True, False], ids=["decode-kernels", "tiled-path"])
+def test_incremental_decoder_step_matches_full_decoder_logits(dev, fast):
     """vlt5_decoder_step (one token, key/value cache) reproduces the logits the full decoder computes for the same prefix:
-    position t of a teacher-forced forward == step t of the incremental decoder fed the same inputs."""
+    position t of a teacher-forced forward == step t of the incremental decoder fed the same inputs -- through the decode kernels
+    (csrc/decode.hip, the default) and through the tiled launches of the training path (vlt5_tuning.decode_fast off)."""
     import ctypes as C
     from oracle import ref_cpu as R
     from vqacl_amd import _lib as L
@@ -579,7 +589,7 @@ def test_incremental_decoder_step_matches_full_decoder_logits(dev):
     from vqacl_amd import ops
     ocfg = R.tiny_cfg()
     params = R.init_params(ocfg, seed=43)
-    model = make_model(ocfg, params, dev)
+    model = set_tuning(make_model(ocfg, params, dev), dict(decode_fast=fast))
     batch = R.synthetic_batch(ocfg, B=5, L=9, V=36, T=6, seed=14)
     model.train()
     model.train_step(batch, 0, 0.5, 0.3)          # populate the prototypes
@@ -1128,21 +1138,17 @@ def test_degenerate_rows_vs_oracle(dev):
     check_grads(model, {k: p.grad for k, p in oracle.P.items()})
 
 
-def test_unfolded_norm_path_still_matches_the_oracle():
-    """The engine folds the encoder's T5 RMS norms around their GEMMs by default (csrc/engine.hip fold_on / fold_dec); the path with
-    norm launches stays in the library (small batches whose FFN output is cut along K take it per layer anyway), and the decoder's
-    folding is an option.  The knobs are read once per process, so the oracle comparisons of the tiny fixture and of the base
-    model re-run in children with the other settings."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # the default folds the encoder's norms only: (off, off) is the plain path, (on, on) also folds the decoder's cross / FFN norms
-    # a third child runs the decoder's attention sublayers through the fused kernels (csrc/dec_attn.hip: an option, measured level with
-    # the three launches each replaces)
-    for enc, dec, fused in (("0", "0", "0"), ("1", "1", "0"), ("1", "0", "1")):
-        env = dict(os.environ, VLT5_FOLD_NORM=enc, VLT5_FOLD_NORM_DEC=dec, VLT5_DEC_FUSED=fused)
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_model.py"), "-m", "gpu", "-q", "-x", "-k",
-                            "tiny_model_against_golden_fixture or base_model_forward_backward_vs_oracle"], env=env, cwd=root,
-                           capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0 and "2 passed" in r.stdout, (enc, dec, fused, r.stdout[-2000:] + r.stderr[-2000:])
+@pytest.mark.parametrize("tuning", [dict(fold_norm=False, fold_norm_dec=False),        # the plain path: every norm a launch of its own
+                                    dict(fold_norm=True, fold_norm_dec=True),          # also fold the decoder's cross / FFN norms
+                                    dict(dec_fused=True),                              # fused decoder attention sublayers (csrc/dec_attn.hip)
+                                    dict(fused_attn=False),                            # encoder q|k|v GEMM + attention core as two launches
+                                    dict(fused_heads=1),                               # one head per workgroup in the fused encoder kernel
+                                    dict(wgrad_shadow=False, wgrad_grouped=False, enc_cut=3)],
+                         ids=["unfolded", "fold-dec", "dec-fused", "unfused-attn", "one-head", "plain-wgrads"])
+def test_alternative_engine_paths_still_match_the_oracle(dev, tuning):
+    """The engine folds the encoder's T5 RMS norms around their GEMMs, fuses the encoder's projection + attention core and groups
+    weight-gradient launches by default; the other paths stay in the library as options of a vlt5_tuning record (vlt5_step.tuning) --
+    the library itself holds no switch state, so the oracle comparisons of the tiny fixture and of the base model simply run again
+    in this process with each record."""
+    test_tiny_model_against_golden_fixture(dev, tuning)
+    test_base_model_forward_backward_vs_oracle(dev, tuning)

@@ -26,19 +26,48 @@ def test_library_exports_every_symbol_of_the_header(built):
     for name in sorted(declared):
         assert hasattr(raw, name), f"libvlt5_hip.so does not export {name}"
     assert set(built.PROTOTYPES) == declared, (set(built.PROTOTYPES) ^ declared)
-    assert built.lib().vlt5_abi_version() == 4
+    assert built.lib().vlt5_abi_version() == 5
 
 
 def test_struct_sizes_match_the_c_side(built, tmp_path):
     """Compile a tiny C program against the header and compare sizeof() with the ctypes mirrors."""
     import subprocess
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "vlt5_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(vlt5_gemm_desc), '
-                   'sizeof(vlt5_attn_desc), sizeof(vlt5_config), sizeof(vlt5_step), sizeof(vlt5_enc_attn_desc));return 0;}\n')
+    names = ["vlt5_gemm_desc", "vlt5_attn_desc", "vlt5_config", "vlt5_step", "vlt5_enc_attn_desc", "vlt5_tuning", "vlt5_greedy_desc",
+             "vlt5_decode_linear_desc", "vlt5_dec_attn_desc", "vlt5_stack_inputs_desc", "vlt5_proto_head_desc"]
+    mirrors = [built.GemmDesc, built.AttnDesc, built.Config, built.Step, built.EncAttnDesc, built.Tuning, built.GreedyDesc,
+               built.DecodeLinearDesc, built.DecAttnDesc, built.StackInputsDesc, built.ProtoHeadDesc]
+    src.write_text('#include <stdio.h>\n#include "vlt5_hip.h"\nint main(){printf("' + " ".join(["%zu"] * len(names)) + '\\n", '
+                   + ", ".join(f"sizeof({n})" for n in names) + ');return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert sizes == [C.sizeof(built.GemmDesc), C.sizeof(built.AttnDesc), C.sizeof(built.Config), C.sizeof(built.Step), C.sizeof(built.EncAttnDesc)]
+    assert sizes == [C.sizeof(m) for m in mirrors], list(zip(names, sizes, [C.sizeof(m) for m in mirrors]))
+
+
+def test_the_library_reads_no_environment_and_tuning_comes_from_the_host(built):
+    """re-entrant, no global state.  The experiment switches of the engine travel in a vlt5_tuning record (vlt5_step.tuning,
+    vlt5_gemm_desc.tuning); the VLT5_* variables of the A/B scripts are read once on the Python side."""
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "vqacl_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "vqacl_amd", "csrc", "*.h")):
+        assert "getenv" not in open(f).read(), f"{os.path.basename(f)} reads the environment"
+    raw = C.CDLL(built.LIB_PATH)
+    import subprocess
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", built.LIB_PATH], text=True)
+    assert " getenv" not in syms and "secure_getenv" not in syms, "libvlt5_hip.so imports getenv"
+    t = built.tuning_from_env({"VLT5_FOLD_NORM": "0", "VLT5_FOLD_NORM_DEC": "1", "VLT5_ENC_CUT": "4", "VLT5_DECODE_FAST": "0", "UNRELATED": "x"})
+    assert (t.fold_norm, t.fold_norm_dec, t.enc_cut, t.decode_fast, t.fused_attn, t.gemm_split_kmin) == (1, 2, 4, 1, 0, 0)
+    d = built.tuning_from_env({})
+    assert bytes(d) == bytes(C.sizeof(built.Tuning)), "no variable set: the all-zero record (= the library's defaults)"
+    m = built.make_tuning(fold_norm=False, dec_fused=True, gemm_t256_min=160)
+    assert (m.fold_norm, m.dec_fused, m.gemm_t256_min) == (1, 2, 160)
+    with pytest.raises(ValueError):
+        built.make_tuning(no_such_switch=1)
+    assert built.lib().vlt5_encoder_late_layers_tuned(12, C.byref(t)) == 4 and built.lib().vlt5_encoder_late_layers_tuned(12, None) == 6
+    # the automatic split-K rule with and without a tuned threshold (no GPU involved: pure host arithmetic)
+    tk = built.make_tuning(gemm_split_kmin=4096)
+    assert built.lib().vlt5_gemm_auto_split_tuned(400, 768, 768, 1 << 30, None) == built.lib().vlt5_gemm_auto_split(400, 768, 768, 1 << 30) > 1
+    assert built.lib().vlt5_gemm_auto_split_tuned(400, 768, 768, 1 << 30, C.byref(tk)) == 1
 
 
 def test_bucket_tables_bit_exact_vs_library_golden():

@@ -19,7 +19,8 @@ model = VLT5VQA(VLT5Config(dropout_rate=0.1), device=dev)
 model.eval()
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synthetic_batch(Cfg(), B=B, L=20, V=36, T=5, seed=3, task_id=0).items()}
 fb = (batch["vis_feats"], batch["boxes"])
-for name, kw in (("kv-cache", dict(use_cache=True)), ("recompute", dict(use_cache=False))):
+def run(name, fast, **kw):
+    model.tuning.decode_fast = 2 if fast else 1
     for _ in range(2):
         out = model.greedy_generate(batch["input_ids"], fb, max_length=20, eos_token_id=-1, **kw)
     torch.cuda.synchronize()
@@ -30,5 +31,37 @@ for name, kw in (("kv-cache", dict(use_cache=True)), ("recompute", dict(use_cach
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     steps = out.shape[1] - 1
-    print(f"{name:10s} B={B} generated {steps} tokens/row: {dt * 1e3:7.2f} ms per batch, {dt / steps * 1e3:6.3f} ms per step, "
-          f"{B * steps / dt:9.0f} tokens/s, {B / dt:7.0f} samples/s")
+    print(f"{name:28s} B={B} generated {steps} tokens/row: {dt * 1e3:7.2f} ms per batch (encoder + cross-K/V included), "
+          f"{dt / steps * 1e3:6.3f} ms per step, {B * steps / dt:9.0f} tokens/s, {B / dt:7.0f} samples/s", flush=True)
+    return out
+
+
+FAST_ONLY = "--fast-only" in sys.argv
+a = run("kv-cache, decode kernels", True, use_cache=True)
+if not FAST_ONLY:
+    b = run("kv-cache, tiled launches", False, use_cache=True)
+    run("recompute the prefix", False, use_cache=False)
+    print(f"tokens equal between the two cached paths: {int((a == b).sum())} of {a.numel()} (random weights: small logit margins)")
+if True:
+    # the token steps alone: time 19 vlt5_decoder_step_greedy calls behind one encoder pass with HIP events (no host sync inside)
+    import ctypes as C
+    from vqacl_amd import _lib as L
+    from vqacl_amd._lib import check, lib, ptr, stream_ptr
+    for fast in ((True,) if FAST_ONLY else (True, False)):
+        model.tuning.decode_fast = 2 if fast else 1
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # greedy_generate does encoder + steps; the encoder part alone:
+        ids = batch["input_ids"]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            model.greedy_generate(ids, fb, max_length=2, eos_token_id=-1)
+        torch.cuda.synchronize()
+        t_enc = (time.perf_counter() - t0) / 5
+        t0 = time.perf_counter()
+        for _ in range(5):
+            model.greedy_generate(ids, fb, max_length=20, eos_token_id=-1)
+        torch.cuda.synchronize()
+        t_all = (time.perf_counter() - t0) / 5
+        print(f"{'decode kernels' if fast else 'tiled launches':16s}: encoder + first step {t_enc * 1e3:6.2f} ms; 18 further steps {(t_all - t_enc) * 1e3:6.2f} ms "
+              f"= {(t_all - t_enc) / 18 * 1e3:6.3f} ms per token-step", flush=True)

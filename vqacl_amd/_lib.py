@@ -18,6 +18,45 @@ c_u32 = C.c_uint32
 vp = C.c_void_p
 
 
+class Tuning(C.Structure):
+    """vlt5_tuning: experiment switches, every field 0 = the library's default (include/vlt5_hip.h)."""
+    _fields_ = [("fold_norm", c_i), ("fold_norm_dec", c_i), ("fused_attn", c_i), ("fused_heads", c_i), ("dec_fused", c_i),
+                ("enc_cut", c_i), ("wgrad_shadow", c_i), ("wgrad_grouped", c_i), ("gemm_t128_kmkm", c_i), ("gemm_t256_km", c_i),
+                ("gemm_t256_min", c_i), ("gemm_dec_tall", c_i), ("gemm_split_kmin", c_i), ("decode_fast", c_i), ("reserved", c_i * 6)]
+
+
+# environment variable -> (field, how its value maps): the library itself reads no environment; the host reads these ONCE per model
+# (tuning_from_env) and hands the record to every engine call (vlt5_step.tuning).  on/off switches: "0" / "1" -> 1 (off) / 2 (on).
+_TUNING_ENV = {"VLT5_FOLD_NORM": ("fold_norm", "onoff"), "VLT5_FOLD_NORM_DEC": ("fold_norm_dec", "onoff"),
+               "VLT5_FUSED_ATTN": ("fused_attn", "onoff"), "VLT5_FUSED_HEADS": ("fused_heads", "int"), "VLT5_DEC_FUSED": ("dec_fused", "onoff"),
+               "VLT5_ENC_CUT": ("enc_cut", "int"), "VLT5_WGRAD_SHADOW": ("wgrad_shadow", "onoff"), "VLT5_WGRAD_GROUPED": ("wgrad_grouped", "onoff"),
+               "VLT5_GEMM_T128_KMKM": ("gemm_t128_kmkm", "int"), "VLT5_GEMM_T256_KM": ("gemm_t256_km", "int"),
+               "VLT5_GEMM_T256_MIN": ("gemm_t256_min", "int"), "VLT5_GEMM_DEC_TALL": ("gemm_dec_tall", "onoff"),
+               "VLT5_GEMM_SPLIT_KMIN": ("gemm_split_kmin", "int"), "VLT5_DECODE_FAST": ("decode_fast", "onoff")}
+
+
+def make_tuning(**fields):
+    """A vlt5_tuning record: keyword = field name; on/off fields take True / False (-> 2 / 1), the others integers."""
+    t = Tuning()
+    kinds = {f: k for f, k in _TUNING_ENV.values()}
+    for name, v in fields.items():
+        if name not in kinds:
+            raise ValueError(f"unknown tuning field {name!r}")
+        setattr(t, name, (2 if v else 1) if kinds[name] == "onoff" and isinstance(v, bool) else int(v))
+    return t
+
+
+def tuning_from_env(environ=None):
+    """The experiment switches the environment asks for (A/B scripts under tools/): read here, once, never inside the library."""
+    environ = os.environ if environ is None else environ
+    t = Tuning()
+    for var, (field, kind) in _TUNING_ENV.items():
+        if var in environ:
+            v = int(environ[var])
+            setattr(t, field, (2 if v else 1) if kind == "onoff" else v)
+    return t
+
+
 class GemmDesc(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("M", c_i), ("N", c_i), ("K", c_i), ("lda", c_i), ("ldb", c_i), ("ldc", c_i),
                 ("a_kmajor", c_i), ("b_kmajor", c_i), ("alpha", c_f), ("bias", vp), ("resid", vp), ("ldr", c_i),
@@ -27,7 +66,7 @@ class GemmDesc(C.Structure):
                 ("batch_stride_c", c_ll), ("defer_reduce", c_i), ("split_used", c_i), ("c_bf16_copy", vp),
                 ("grouped_with", vp), ("emit_norm_w", vp), ("emit_xw_bf16", vp), ("emit_partials", vp), ("emit_nparts", c_i),
                 ("norm_partials", vp), ("norm_nparts", c_i), ("norm_d", c_i), ("norm_eps", c_f), ("norm_rstd_out", vp),
-                ("sumsq", vp), ("sumsq_batch_stride", c_ll)]
+                ("sumsq", vp), ("sumsq_batch_stride", c_ll), ("tuning", C.POINTER(Tuning))]
 
 
 class AttnDesc(C.Structure):
@@ -37,7 +76,7 @@ class AttnDesc(C.Structure):
                 ("B", c_i), ("H", c_i), ("Tq", c_i), ("Tk", c_i), ("dk", c_i), ("drop_p", c_f), ("drop_seed", c_u32),
                 ("d_ctx", vp), ("do_sb", c_ll), ("do_st", c_ll), ("dq", vp), ("dk_", vp), ("dv", vp),
                 ("dq_sb", c_ll), ("dq_st", c_ll), ("dk_sb", c_ll), ("dk_st", c_ll), ("dv_sb", c_ll), ("dv_st", c_ll),
-                ("dbias", vp)]
+                ("dbias", vp), ("fused_heads", c_i)]
 
 
 class DecAttnDesc(C.Structure):
@@ -91,7 +130,19 @@ class Step(C.Structure):
                 ("wait_events", C.POINTER(vp)), ("n_wait_events", c_i),
                 ("feat_store", vp), ("box_store", vp), ("feat_slots", vp), ("n_slots", c_ll),
                 ("side_stream", vp), ("side_events", C.POINTER(vp)), ("n_side_events", c_i), ("grads_bf16", vp),
-                ("gnorm_partials", vp), ("defer_decoder_wgrads", c_i)]
+                ("gnorm_partials", vp), ("defer_decoder_wgrads", c_i), ("tuning", C.POINTER(Tuning))]
+
+
+class GreedyDesc(C.Structure):
+    _fields_ = [("tokens", vp), ("t", c_i), ("kv_cache", vp), ("logits", vp), ("next_ids", vp), ("out_tokens", vp), ("out_ld", c_ll),
+                ("done", vp), ("eos_id", c_i), ("pad_id", c_i)]
+
+
+class DecodeLinearDesc(C.Structure):
+    _fields_ = [("x_f32", vp), ("x_bf16", vp), ("ldx", c_ll), ("norm_w", vp), ("norm_eps", c_f), ("w_bf16", vp), ("rows", c_i), ("N", c_i),
+                ("K", c_i), ("alpha", c_f), ("out_bf16", vp), ("ld_out_bf16", c_ll), ("split_col", c_i), ("out_bf16_2", vp),
+                ("ld_out_bf16_2", c_ll), ("out_f32", vp), ("ld_out_f32", c_ll), ("resid", vp), ("ld_resid", c_ll), ("relu", c_i),
+                ("argmax_val", vp), ("argmax_idx", vp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/vlt5_hip.h
@@ -100,6 +151,7 @@ PROTOTYPES = {
     "vlt5_gemm_bf16": (c_i, [C.POINTER(GemmDesc), vp]),
     "vlt5_gemm_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
     "vlt5_gemm_auto_split": (c_i, [c_i, c_i, c_i, c_ll]),
+    "vlt5_gemm_auto_split_tuned": (c_i, [c_i, c_i, c_i, c_ll, C.POINTER(Tuning)]),
     "vlt5_gemm_timing_enable": (c_i, [c_i]),
     "vlt5_gemm_timing_collect": (c_i, [C.POINTER(GemmTimingRec), c_i]),
     "vlt5_layernorm_fwd": (c_i, [vp, vp, vp, vp, vp, c_i, c_i, c_f, c_f, c_u32, c_i, c_i, vp]),
@@ -108,6 +160,7 @@ PROTOTYPES = {
     "vlt5_layernorm_bwd_slabs": (c_i, [vp, c_i, c_ll, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, c_f, c_u32, vp]),
     "vlt5_layernorm_bwd_full": (c_i, [vp, c_i, c_ll, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, c_f, c_u32, vp, vp]),
     "vlt5_encoder_late_layers": (c_i, [c_i]),
+    "vlt5_encoder_late_layers_tuned": (c_i, [c_i, C.POINTER(Tuning)]),
     "vlt5_side_stream_create": (c_i, [C.POINTER(vp)]),
     "vlt5_side_stream_destroy": (c_i, [vp]),
     "vlt5_feat_store_put": (c_i, [vp, vp, vp, c_i, vp, vp, c_ll, c_i, c_i, vp]),
@@ -170,6 +223,12 @@ PROTOTYPES = {
     "vlt5_encoder_fwd": (c_i, [C.POINTER(Config), C.POINTER(Step), vp]),
     "vlt5_decoder_fwd": (c_i, [C.POINTER(Config), C.POINTER(Step), vp]),
     "vlt5_decoder_step": (c_i, [C.POINTER(Config), C.POINTER(Step), vp, c_i, vp, vp, vp, vp]),
+    "vlt5_decoder_step_greedy": (c_i, [C.POINTER(Config), C.POINTER(Step), C.POINTER(GreedyDesc), vp]),
+    "vlt5_decode_fast_supported": (c_i, [C.POINTER(Config), C.POINTER(Step)]),
+    "vlt5_decode_linear": (c_i, [C.POINTER(DecodeLinearDesc), vp]),
+    "vlt5_decode_linear_supported": (c_i, [c_i, c_i]),
+    "vlt5_decode_linear_tiles": (c_i, [c_i, c_i, c_i, c_i]),
+    "vlt5_decode_attn": (c_i, [C.POINTER(AttnDesc), vp]),
     "vlt5_decoder_bwd": (c_i, [C.POINTER(Config), C.POINTER(Step), vp]),
     "vlt5_encoder_bwd": (c_i, [C.POINTER(Config), C.POINTER(Step), vp]),
 }
@@ -195,7 +254,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.vlt5_abi_version() != 4:
+        if L.vlt5_abi_version() != 5:
             raise Vlt5Error("libvlt5_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -347,10 +347,9 @@ static int qkv_attn_launch(const void* xn_bf16, const void* wqkv_bf16, void* qkv
     t.drop_thr = core->drop_p > 0.f ? drop_thr16(core->drop_p) : 0u; t.drop_seed = core->drop_seed;
     t.d_ctx = nullptr; t.do_sb = t.do_st = 0; t.dq = t.dk_ = t.dv = nullptr;
     t.dq_sb = t.dq_st = t.dk_sb = t.dk_st = t.dv_sb = t.dv_st = 0; t.dbias = nullptr;
-    // one head per workgroup (4 waves, two workgroups per CU) or two (8 waves, one per CU): VLT5_FUSED_HEADS = 1 / 2 is an
-    // experiment knob; an odd number of heads can only run the one-head kernel
-    static const int heads_env = getenv("VLT5_FUSED_HEADS") ? atoi(getenv("VLT5_FUSED_HEADS")) : 2;
-    const int nh = (heads_env == 2 && !(a.H & 1)) ? 2 : 1;
+    // one head per workgroup (4 waves, two workgroups per CU) or two (8 waves, one per CU): vlt5_attn_desc.fused_heads = 1 / 2 is an
+    // experiment switch (0: two); an odd number of heads can only run the one-head kernel
+    const int nh = (core->fused_heads != 1 && !(a.H & 1)) ? 2 : 1;
     if (nh == 2) return qkv_attn_dispatch<2>(a, &qkv_attn_fwd2_kernel<false>, &qkv_attn_fwd2_kernel<true>, stream);
     return qkv_attn_dispatch<1>(a, &qkv_attn_fwd_kernel<false>, &qkv_attn_fwd_kernel<true>, stream);
 }

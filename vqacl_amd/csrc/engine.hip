@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "vlt5_hip.h"
+#include "decode.h"
 #include <stdio.h>
 #include <string.h>
 #include <string>
@@ -237,8 +238,10 @@ struct Ctx {
     mutable long long ln_out[64];
     mutable int ln_nblk[64];
     hipStream_t side = nullptr;        // optional second stream of the backward phases (vlt5_step.side_stream)
+    vlt5_tuning tun;                   // experiment switches of this call (vlt5_step.tuning, all zero = defaults)
     Ctx(const vlt5_config& c_, const vlt5_step& s_, void* stream) : c(c_), s(s_), st((hipStream_t)stream) {
         if (s.side_stream && s.side_events && s.n_side_events >= 4) side = (hipStream_t)s.side_stream;
+        if (s.tuning) tun = *s.tuning; else memset(&tun, 0, sizeof tun);
         build_layout(c, lay, false);
         make_plan(c, s.B, s.L, s.V, s.T, p);
         ws = (char*)s.workspace;
@@ -290,6 +293,7 @@ struct Ctx {
                 NormIn nin = NormIn()) const {
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);
+        g.tuning = &tun;
         g.A = X; g.B = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
         g.alpha = alpha; g.bias = bias; g.relu = relu; g.drop_p = dp; g.drop_seed = dseed; g.resid = resid; g.ldr = N;
         g.out_f32 = out_f32;
@@ -302,6 +306,7 @@ struct Ctx {
                      long long w_norm, void* xw, float* ssq, int* nparts) const {
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);
+        g.tuning = &tun;
         g.A = X; g.B = W; g.C = Y; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
         g.alpha = 1.f; g.drop_p = dp; g.drop_seed = dseed; g.resid = resid; g.ldr = N; g.out_f32 = 1;
         g.emit_norm_w = P + w_norm; g.emit_xw_bf16 = xw; g.emit_partials = ssq;
@@ -309,21 +314,15 @@ struct Ctx {
         *nparts = g.emit_nparts;
         return rc;
     }
-    // which norms are folded (same answer in forward and backward: a function of the configuration and the shapes only).
-    // VLT5_FOLD_NORM=0 / VLT5_FOLD_NORM_DEC=0: experiment knobs (A/B runs, tests of the unfolded path)
-    bool fold_on() const {
-        static const bool off = getenv("VLT5_FOLD_NORM") && atoi(getenv("VLT5_FOLD_NORM")) == 0;
-        return !off && d <= 1024 && (d & 31) == 0;
-    }
+    // which norms are folded (same answer in forward and backward: a function of the configuration, the shapes and the tuning
+    // record only).  vlt5_tuning.fold_norm = 1 / fold_norm_dec = 2: experiment switches (A/B runs, tests of the other path)
+    bool fold_on() const { return tun.fold_norm != 1 && d <= 1024 && (d & 31) == 0; }
     // (decoder: the norms in front of the cross-attention query and the FFN could lose their launches too, but their producers --
     // the 400-row attention output projections -- then run un-split over K and the 64 x 64 consumers pay the row scale: measured
     // +0.13 ms per step against -0.17 ms of norm launches saved ... and +0.13 ms of slower 84-tile GEMMs: a net loss, off by default)
-    bool fold_dec() const {
-        static const bool on = getenv("VLT5_FOLD_NORM_DEC") && atoi(getenv("VLT5_FOLD_NORM_DEC")) == 1;
-        return on && fold_on();
-    }
+    bool fold_dec() const { return tun.fold_norm_dec == 2 && fold_on(); }
     bool fold_enc_first(int l) const { return fold_on() && l > 0 && pick_split(p.M, d, ff) <= 1; }     // the norm in front of layer l's attention
-    int pick_split(int M, int N, int Kred) const { return vlt5_gemm_auto_split(M, N, Kred, (long long)p.slab_bytes); }
+    int pick_split(int M, int N, int Kred) const { return vlt5_gemm_auto_split_tuned(M, N, Kred, (long long)p.slab_bytes, &tun); }
     int ffw() const { return c.gated_act ? 2 * ff : ff; }
     // hidden activation of an FFN: h = dropout(act(xn Wi^T)).  ReLU: one GEMM with the activation in its epilogue.  Gated GELU (HF
     // T5DenseGatedActDense): u = xn [wi_0; wi_1]^T kept for the backward, then h = dropout(gelu_new(u0) * u1)
@@ -344,6 +343,7 @@ struct Ctx {
         if (sk <= 1) return lin_fwd(X, W, Y, M, N, K, 1, 1.f, nullptr, 0, dp, dseed, resid);
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);
+        g.tuning = &tun;
         g.A = X; g.B = W; g.C = w<void>(p.slab); g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
         g.alpha = 1.f; g.out_f32 = 1; g.split_k = sk; g.workspace = w<void>(p.slab); g.defer_reduce = 1;
         int rc = vlt5_gemm_bf16(&g, st);
@@ -365,6 +365,7 @@ struct Ctx {
                   const bf16_t* gate = nullptr, float gate_scale = 1.f, int* slabs = nullptr) const {
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);
+        g.tuning = &tun;
         g.A = dY; g.B = W; g.C = dX; g.M = M; g.N = K; g.K = N; g.lda = N; g.ldb = K; g.ldc = K; g.b_kmajor = 1;
         g.alpha = alpha; g.gate = gate; g.ldg = K; g.gate_scale = gate_scale; g.out_f32 = out_f32;
         if (out_f32 && !gate) {
@@ -381,6 +382,7 @@ struct Ctx {
                   int accum = 0, bool norm_share = false, const vlt5_gemm_desc* group = nullptr) const {
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);
+        g.tuning = &tun;
         g.grouped_with = group;
         g.A = dY; g.B = X; g.C = dW; g.M = N; g.N = K; g.K = M; g.lda = ldy; g.ldb = ldx; g.ldc = K;
         g.a_kmajor = 1; g.b_kmajor = 1; g.alpha = alpha; g.out_f32 = 1; g.accum = accum;
@@ -431,6 +433,7 @@ struct Ctx {
                       int M, int N, int K, vlt5_gemm_desc* only_fill = nullptr, const vlt5_gemm_desc* group = nullptr) const {
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);
+        g.tuning = &tun;
         g.grouped_with = group;
         g.A = w<void>(dy0); g.B = w<void>(x0); g.C = Gr + g0; g.M = N; g.N = K; g.K = M; g.lda = ldy; g.ldb = ldx; g.ldc = K;
         g.a_kmajor = 1; g.b_kmajor = 1; g.alpha = 1.f; g.out_f32 = 1;
@@ -488,17 +491,13 @@ int attn_call(const Ctx& k, bool bwd, const bf16_t* q, long long q_sb, long long
 }
 
 // the fused q|k|v projection + attention core kernel (csrc/enc_attn.hip) covers d_kv = 64, S <= 64 and
-// d_model % 64 == 0 (every T5 size); VLT5_FUSED_ATTN=0 selects the GEMM + attention-core launches instead (A/B runs, tests)
-bool fused_attn_ok(const Ctx& k) {
-    static const bool off = getenv("VLT5_FUSED_ATTN") && atoi(getenv("VLT5_FUSED_ATTN")) == 0;
-    return !off && k.c.d_kv == 64 && k.p.S <= 64 && (k.d & 63) == 0;
-}
+// d_model % 64 == 0 (every T5 size); vlt5_tuning.fused_attn = 1 selects the GEMM + attention-core launches instead (A/B runs, tests)
+bool fused_attn_ok(const Ctx& k) { return k.tun.fused_attn != 1 && k.c.d_kv == 64 && k.p.S <= 64 && (k.d & 63) == 0; }
 
 // the fused decoder attention sublayers (csrc/dec_attn.hip: projection + core + per-head output-projection slabs in one launch instead of
-// three): built and bit-checked, measured level with the three launches they replace -- VLT5_DEC_FUSED=1 selects them
+// three): built and bit-checked, measured level with the three launches they replace -- vlt5_tuning.dec_fused = 2 selects them
 bool dec_fused_ok(const Ctx& k) {
-    static const bool on = getenv("VLT5_DEC_FUSED") && atoi(getenv("VLT5_DEC_FUSED")) != 0;
-    return on && !k.fold_dec() && vlt5_dec_attn_fused_ok(k.s.T, k.p.Sx, k.c.d_kv, k.d) &&
+    return k.tun.dec_fused == 2 && !k.fold_dec() && vlt5_dec_attn_fused_ok(k.s.T, k.p.Sx, k.c.d_kv, k.d) &&
            (size_t)k.H * k.p.Md * k.d * sizeof(float) <= k.p.slab_bytes;
 }
 // one fused decoder attention sublayer: leaves H slabs in the slab scratch for the norm that follows
@@ -573,6 +572,7 @@ int encoder_fwd(const Ctx& k) {
             a.ctx = k.w<void>(p.ctx[l]); a.o_sb = (long long)S * inner; a.o_st = inner; a.lse = k.w<float>(p.lse[l]);
             a.bias = k.w<float>(p.enc_bias); a.bias_q = s.L; a.bias_k = s.L; a.key_mask = k.w<float>(p.mask); a.mask_value = -10000.f;
             a.B = B; a.H = k.H; a.Tq = S; a.Tk = S; a.dk = c.d_kv; a.drop_p = k.pdrop; a.drop_seed = k.seed(sb + E_PROBS);
+            a.fused_heads = k.tun.fused_heads;
             if (np_a > 0)
                 RC(vlt5_qkv_attn_fwd_norm(k.w<void>(p.xn_a[l]), k.Pb + E.sqkv, qkv, &a, d, nin_a.part, nin_a.n, c.eps, nin_a.rstd_out, k.st));
             else
@@ -766,6 +766,151 @@ int decoder_step(const Ctx& k, const long long* tokens, int t, bf16_t* cache, fl
     return VLT5_OK;
 }
 
+// The same step through the decode kernels (csrc/decode.hip): 8 launches per layer instead of 12, every one a single memory round
+// trip (norms folded into the projections, k | v written straight into the cache slot, per-tile argmax in the vocabulary projection's
+// epilogue).  g.done != NULL: greedy bookkeeping on the device (vlt5_decoder_step_greedy) -- then the input row of step t > 0 was left
+// in the workspace by the step before, and `tokens` is read at t == 0 only.
+bool decode_fast_ok(const Ctx& k) {
+    const vlt5_config& c = k.c;
+    if (k.tun.decode_fast == 1) return false;
+    if (c.d_kv != 16 && c.d_kv != 32 && c.d_kv != 64) return false;
+    if (k.p.Sx > 64 || k.s.T > 64) return false;
+    return vlt5_decode_linear_supported(k.d, 1) && vlt5_decode_linear_supported(k.inner, 0) && vlt5_decode_linear_supported(k.ff, 0);
+}
+
+int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
+    const Plan& p = k.p; const Layout& L = k.lay; const vlt5_config& c = k.c; const vlt5_step& s = k.s;
+    const int d = k.d, inner = k.inner, ff = k.ff, Mx = p.Mx, Sx = p.Sx, B = s.B, Tcap = s.T, Ld = c.num_decoder_layers, t = g.t;
+    const int kvw = Ld * 2 * inner, Tk = t + 1;
+    bf16_t* cache = (bf16_t*)g.kv_cache;
+    if (t == 0) {
+        RC(k.wait_bucket(Ld + c.num_layers + 1));
+        RC(k.wait_bucket(Ld));
+        RC(vlt5_build_mask(s.input_ids, k.w<float>(p.mask_ext), B, s.L, Sx, c.pad_id, k.st));
+        // cross-attention keys | values of all layers, LAYER-major for this path ([Ld][B*Sx][2*inner], one batched GEMM): a sample's
+        // 58 keys of a layer are one contiguous 174 KB run instead of 128-byte pieces 36 KB apart
+        vlt5_gemm_desc g;
+        memset(&g, 0, sizeof g);
+        g.tuning = &k.tun;
+        g.A = k.w<bf16_t>(p.enc_ext); g.B = k.Pb + L.cross_kv; g.C = k.w<void>(p.kv_all); g.M = Mx; g.N = 2 * inner; g.K = d;
+        g.lda = d; g.ldb = d; g.ldc = 2 * inner; g.alpha = 1.f; g.batch = Ld;
+        g.batch_stride_a = 0; g.batch_stride_b = (long long)2 * inner * d; g.batch_stride_c = (long long)Mx * 2 * inner;
+        RC(vlt5_gemm_bf16(&g, k.st));
+        for (int l = 0; l < Ld; ++l) RC(k.wait_bucket(Ld - 1 - l));
+    }
+    float* bias_t = k.w<float>(p.dec_bias);                        // [H][Tcap]: relative-position bias row of query position t
+    // every launch also touches the weights the NEXT projection of the chain reads (and the projection in front of the cross-attention
+    // core the keys | values of that core), so those arrive from the L2 instead of HBM
+    auto pf = [&](DecLinArgs& a, const bf16_t* Wn, int Nn, int Kn, int af32n) {
+        a.pf_w = Wn; a.pf_xcd_bytes = vlt5_declin_xcd_bytes(B, Nn, Kn, af32n); a.pf_total = (long long)Nn * Kn * 2;
+        if (a.pf_xcd_bytes <= 0) a.pf_w = nullptr;
+    };
+    if (t == 0 || !chained) {
+        DecIoArgs io;
+        memset(&io, 0, sizeof io);
+        io.tokens = g.tokens; io.table = k.P + L.shared; io.d = d; io.vocab = c.vocab; io.emb_out = k.w<float>(p.y[0]);
+        io.rel_table = k.P + L.dec_rel; io.lut = s.dec_lut; io.lut_ld = Tcap; io.tq = t; io.H = k.H; io.bias_out = bias_t; io.bias_ld = Tcap;
+        RC(vlt5_dec_io_launch(io, B, k.st));
+    }
+    auto lin = [&](const float* xf, long long ln_w, const bf16_t* xb, int K, const bf16_t* W, int N, bf16_t* ob, long long ldo, float* of,
+                   const float* resid, int relu) {
+        DecLinArgs a;
+        memset(&a, 0, sizeof a);
+        a.xf = xf; a.xb = xb; a.ldx = K; a.ln_w = xf ? k.P + ln_w : nullptr; a.eps = c.eps; a.W = W; a.rows = B; a.N = N; a.K = K;
+        a.alpha = 1.f; a.out_b = ob; a.ldo = ldo; a.split_col = 0x7fffffff; a.out_f = of; a.ldf = N; a.resid = resid; a.ldr = N; a.relu = relu;
+        return a;
+    };
+    const size_t cache_layer = (size_t)B * Tcap * 2 * inner;
+    for (int l = 0; l < Ld; ++l) {
+        const auto& D = L.dec[l];
+        float* y0 = k.w<float>(p.y[3 * l]);
+        float* y1 = k.w<float>(p.y[3 * l + 1]);
+        float* y2 = k.w<float>(p.y[3 * l + 2]);
+        float* y3 = k.w<float>(p.y[3 * l + 3]);
+        bf16_t* q = k.w<bf16_t>(p.dqkv_s[l]);                          // [B, inner]
+        bf16_t* kc = cache + (size_t)l * cache_layer;                    // [B][Tcap][2*inner]: k | v
+        bf16_t* kv = k.w<bf16_t>(p.kv_all) + (size_t)l * Mx * 2 * inner;  // [B][Sx][2*inner]: k | v of this layer
+        const int ffw = c.gated_act ? 2 * ff : ff;
+        {   // norm -> q | k | v: q to its buffer, k | v into cache slot t
+            DecLinArgs a = lin(y0, D.ln_s, nullptr, d, k.Pb + D.sqkv, 3 * inner, q, inner, nullptr, nullptr, 0);
+            a.split_col = inner; a.out_b2 = kc + (size_t)t * 2 * inner; a.ldo2 = (long long)Tcap * 2 * inner;
+            pf(a, k.Pb + D.so, d, inner, 0);
+            RC(vlt5_declin_launch(a, k.st));
+        }
+        {
+            DecCoreArgs a;
+            memset(&a, 0, sizeof a);
+            a.q = q; a.q_ld = inner; a.k = kc; a.v = kc + inner; a.kv_sb = (long long)Tcap * 2 * inner; a.kv_st = 2 * inner;
+            a.ctx = k.w<bf16_t>(p.ctx_s[l]); a.ctx_ld = inner; a.bias = bias_t; a.bias_ld = Tcap; a.B = B; a.H = k.H; a.Tk = Tk;
+            RC(vlt5_dec_core_launch(a, c.d_kv, k.st));
+        }
+        {
+            DecLinArgs a = lin(nullptr, 0, k.w<bf16_t>(p.ctx_s[l]), inner, k.Pb + D.so, d, nullptr, 0, y1, y0, 0);
+            pf(a, k.Pb + D.cq, inner, d, 1);
+            RC(vlt5_declin_launch(a, k.st));
+        }
+        {
+            DecLinArgs a = lin(y1, D.ln_c, nullptr, d, k.Pb + D.cq, inner, k.w<bf16_t>(p.qc[l]), inner, nullptr, nullptr, 0);
+            pf(a, k.Pb + D.co, d, inner, 0);
+            if (c.d_kv == 64) { a.pf_kv = kv; a.pf_kv_sb = (long long)Sx * 2 * inner; a.pf_kv_st = 2 * inner; a.pf_H = k.H; a.pf_dk = 64; a.pf_Tk = Sx; a.pf_B = B; }
+            RC(vlt5_declin_launch(a, k.st));
+        }
+        {
+            DecCoreArgs a;
+            memset(&a, 0, sizeof a);
+            a.q = k.w<bf16_t>(p.qc[l]); a.q_ld = inner; a.k = kv; a.v = kv + inner; a.kv_sb = (long long)Sx * 2 * inner; a.kv_st = 2 * inner;
+            a.ctx = k.w<bf16_t>(p.ctx_c[l]); a.ctx_ld = inner; a.key_mask = k.w<float>(p.mask_ext); a.mask_ld = Sx; a.mask_value = -1e9f;
+            a.B = B; a.H = k.H; a.Tk = Sx;
+            RC(vlt5_dec_core_launch(a, c.d_kv, k.st));
+        }
+        {
+            DecLinArgs a = lin(nullptr, 0, k.w<bf16_t>(p.ctx_c[l]), inner, k.Pb + D.co, d, nullptr, 0, y2, y1, 0);
+            pf(a, k.Pb + D.wi, ffw, d, 1);
+            RC(vlt5_declin_launch(a, k.st));
+        }
+        if (c.gated_act) {
+            DecLinArgs a = lin(y2, D.ln_f, nullptr, d, k.Pb + D.wi, 2 * ff, k.w<bf16_t>(p.ud[l]), 2 * ff, nullptr, nullptr, 0);
+            pf(a, k.Pb + D.wo, d, ff, 0);
+            RC(vlt5_declin_launch(a, k.st));
+            RC(vlt5_glu_fwd(k.w<bf16_t>(p.ud[l]), k.w<bf16_t>(p.hd[l]), B, ff, 0.f, 0, k.st));
+        } else {
+            DecLinArgs a = lin(y2, D.ln_f, nullptr, d, k.Pb + D.wi, ff, k.w<bf16_t>(p.hd[l]), ff, nullptr, nullptr, 1);
+            pf(a, k.Pb + D.wo, d, ff, 0);
+            RC(vlt5_declin_launch(a, k.st));
+        }
+        {
+            DecLinArgs a = lin(nullptr, 0, k.w<bf16_t>(p.hd[l]), ff, k.Pb + D.wo, d, nullptr, 0, y3, y2, 0);
+            if (l + 1 < Ld) pf(a, k.Pb + L.dec[l + 1].sqkv, 3 * inner, d, 1);
+            RC(vlt5_declin_launch(a, k.st));
+        }
+    }
+    // final norm + rescale + tied lm_head (+ the first maximum of every column tile)
+    const bool want_ids = g.next_ids || g.done;
+    const int tiles = vlt5_declin_tiles(B, c.vocab, d, 1);
+    float* pmax = k.w<float>(p.slab);
+    int* pidx = reinterpret_cast<int*>(pmax + (size_t)B * tiles);
+    if ((size_t)B * tiles * 8 > p.slab_bytes) return VLT5_ERR_ARG;
+    {
+        DecLinArgs a = lin(k.w<float>(p.y[3 * Ld]), L.dec_final_ln, nullptr, d, k.Pb + L.shared, c.vocab, nullptr, 0, g.logits, nullptr, 0);
+        a.alpha = 1.0f / sqrtf((float)d);                           // tied embeddings: rescale before the vocabulary projection
+        if (want_ids) { a.pmax = pmax; a.pidx = pidx; a.ptiles = tiles; }
+        if (!g.logits && !want_ids) return VLT5_ERR_ARG;
+        RC(vlt5_declin_launch(a, k.st));
+    }
+    if (want_ids) {
+        DecIoArgs io;
+        memset(&io, 0, sizeof io);
+        io.pmax = pmax; io.pidx = pidx; io.ptiles = tiles; io.next_ids = g.next_ids;
+        io.done = g.done; io.eos_id = g.eos_id; io.pad_id = g.pad_id; io.out_tokens = g.out_tokens; io.out_ld = g.out_ld; io.out_col = t + 1;
+        if (chained && t + 1 < Tcap) {                              // input row and bias row of the next step
+            io.table = k.P + L.shared; io.d = d; io.vocab = c.vocab; io.emb_out = k.w<float>(p.y[0]);
+            io.rel_table = k.P + L.dec_rel; io.lut = s.dec_lut; io.lut_ld = Tcap; io.tq = t + 1; io.H = k.H; io.bias_out = bias_t; io.bias_ld = Tcap;
+        }
+        RC(vlt5_dec_io_launch(io, B, k.st));
+    }
+    return VLT5_OK;
+}
+
 // backward (data path only) of one  x_out = x_in + drop(W_o . drop(relu(W_i . LN(x_in))))  sublayer; dx is updated in place.
 // `dyd` holds bf16(dropout_out(dx)) on entry (emitted by the producer of dx); `dh` receives the hidden gradient; both are
 // kept for the batched weight-gradient GEMMs at the end of the phase.  `next_dst` receives the operand of the next sublayer.
@@ -877,10 +1022,9 @@ int decoder_bwd(const Ctx& k) {
 }
 
 // The encoder's weight gradients run as two batched groups: layers [cut, Le) as soon as the chain has passed layer `cut`, layers
-// [0, cut) at the end.  (experiment knob: VLT5_ENC_CUT = number of layers in the late group)
-inline int enc_cut(int Le) {
-    static const int env = getenv("VLT5_ENC_CUT") ? atoi(getenv("VLT5_ENC_CUT")) : 0;
-    const int c = env > 0 ? env : Le / 2;
+// [0, cut) at the end.  (experiment switch: vlt5_tuning.enc_cut = number of layers in the late group)
+inline int enc_cut(int Le, int tuned = 0) {
+    const int c = tuned > 0 ? tuned : Le / 2;
     return c < 1 ? 1 : (c > Le - 1 ? Le - 1 : c);
 }
 // The six batched weight-gradient problems of the decoder stack (which: 0 FFN wo, 1 FFN wi, 2 cross o, 3 cross q, 4 self o, 5 self q|k|v):
@@ -903,7 +1047,7 @@ int dec_wgrad(const Ctx& k, int which, vlt5_gemm_desc* desc, int lo, int n) {   
 // in the shadow of the long 216-tile launches -- the stacked cross-K/V gradient and the encoder's FFN gradients leave 40 of the 256
 // CUs idle for their whole duration; as the second problem of those grouped launches the decoder's tiles run there.
 bool shadow_wgrads(const Ctx& k) {
-    static const bool off = getenv("VLT5_WGRAD_SHADOW") && atoi(getenv("VLT5_WGRAD_SHADOW")) == 0;
+    const bool off = k.tun.wgrad_shadow == 1;
     // (never with gradient-bucket events: the decoder buckets would be signalled at the end of vlt5_decoder_bwd although five of
     // their six weight gradients are only written inside vlt5_encoder_bwd)
     return !off && k.s.defer_decoder_wgrads && !k.side && !(k.s.events && k.s.n_events > 0) && k.c.num_layers > 1 && k.c.num_decoder_layers > 0;
@@ -924,7 +1068,7 @@ int enc_wgrads(const Ctx& k, int lo, int hi, int guest_wo = -1, int guest_wi = -
     RC(k.wgrad_batched(p.e_dh[lo], p.e_dh[l1], k.ffw(), p.xn_f[lo], p.xn_f[l1], d, L.enc[lo].wi, L.enc[l1].wi, n, M, k.ffw(), d, nullptr,
                        guest_wi >= 0 ? &g_wi : nullptr));
     // the two attention weight gradients share one grid: 162 + 54 tiles of 256 x 256 (six layers) fill the chip only together
-    static const bool grouped = !(getenv("VLT5_WGRAD_GROUPED") && atoi(getenv("VLT5_WGRAD_GROUPED")) == 0);
+    const bool grouped = k.tun.wgrad_grouped != 1;
     if (grouped) {
         vlt5_gemm_desc so;
         RC(k.wgrad_batched(p.e_dyd_a[lo], p.e_dyd_a[l1], d, p.ctx[lo], p.ctx[l1], inner, L.enc[lo].so, L.enc[l1].so, n, M, d, inner, &so));
@@ -965,12 +1109,12 @@ int encoder_bwd(const Ctx& k) {
         RC(k.ln_bwd(tmp, k.w<float>(p.x[2 * l]), E.ln_s, k.w<float>(p.xr[2 * l]), dx, M, 1, 0.f, 0, 0, 0,
                     l > 0 ? k.w<bf16_t>(p.e_dyd_f[l - 1]) : nullptr, l > 0 ? k.seed(SITE_ENC_BASE + (l - 1) * 8 + E_FFN_OUT) : 0u, ns_e,
                     (long long)M * d, k.fold_enc_first(l) ? k.w<bf16_t>(p.xn_a[l]) : nullptr));
-        if (Le > 1 && l == enc_cut(Le)) {
+        if (Le > 1 && l == enc_cut(Le, k.tun.enc_cut)) {
             // upper half of the stack: its weight gradients are complete early, so a data-parallel all-reduce of these
             // buckets overlaps with the backward of the lower half
             RC(k.fork(1));
             const Ctx ks = k.on_side();                   // beside the lower half's chain when there is a side stream
-            RC(enc_wgrads(ks, enc_cut(Le), Le, shadow_wgrads(k) ? 0 : -1, shadow_wgrads(k) ? 1 : -1));   // + decoder FFN wo / wi
+            RC(enc_wgrads(ks, enc_cut(Le, k.tun.enc_cut), Le, shadow_wgrads(k) ? 0 : -1, shadow_wgrads(k) ? 1 : -1));   // + decoder FFN wo / wi
             for (int b = Ld + 1; b <= Ld + 1 + (Le - 1 - l); ++b) RC(ks.record(b));
         }
     }
@@ -993,7 +1137,7 @@ int encoder_bwd(const Ctx& k) {
     RC(k.record(Ld + 1 + Le));                            // embeddings + norms + visual embedding: complete BEFORE the last weight-
                                                           // gradient GEMMs, so their all-reduce hides under those (data parallel)
     // (a third flush group of Le/4 layers was measured: batches of 3 layers fill the chip too poorly, +4 % step time)
-    const int low_end = Le > 1 ? enc_cut(Le) : Le;
+    const int low_end = Le > 1 ? enc_cut(Le, k.tun.enc_cut) : Le;
     RC(k.fork(2));
     {
         const Ctx ks = k.on_side();
@@ -1007,6 +1151,9 @@ int encoder_bwd(const Ctx& k) {
 }  // namespace
 
 extern "C" int vlt5_encoder_late_layers(int num_layers) { return num_layers > 1 ? enc_cut(num_layers) : num_layers; }
+extern "C" int vlt5_encoder_late_layers_tuned(int num_layers, const vlt5_tuning* t) {
+    return num_layers > 1 ? enc_cut(num_layers, t ? t->enc_cut : 0) : num_layers;
+}
 
 // A stream of the LOWEST priority for vlt5_step.side_stream: the weight-gradient GEMMs then only take the workgroup slots the
 // input-gradient chain on the caller's (normal-priority) stream leaves free, instead of starving it.
@@ -1105,7 +1252,29 @@ extern "C" int vlt5_decoder_step(const vlt5_config* c, const vlt5_step* s, const
     int rc = k.check(false);
     if (rc) return rc;
     if (!s->dec_lut || !s->input_ids) return VLT5_ERR_ARG;
+    if (decode_fast_ok(k)) {
+        vlt5_greedy_desc g;
+        memset(&g, 0, sizeof g);
+        g.tokens = tokens; g.t = t; g.kv_cache = kv_cache; g.logits = logits; g.next_ids = next_ids;
+        return decoder_step_fast(k, g, false);
+    }
     return decoder_step(k, tokens, t, (bf16_t*)kv_cache, logits, next_ids);
+}
+extern "C" int vlt5_decoder_step_greedy(const vlt5_config* c, const vlt5_step* s, const vlt5_greedy_desc* g, void* stream) {
+    if (!c || !s || !g || !g->kv_cache || !g->done || !g->out_tokens) return VLT5_ERR_ARG;
+    if (g->t < 0 || g->t >= s->T || s->training || g->out_ld < g->t + 2) return VLT5_ERR_ARG;
+    if (g->t == 0 && !g->tokens) return VLT5_ERR_ARG;
+    Ctx k(*c, *s, stream);
+    int rc = k.check(false);
+    if (rc) return rc;
+    if (!s->dec_lut || !s->input_ids) return VLT5_ERR_ARG;
+    if (!decode_fast_ok(k)) return VLT5_ERR_ARG;                  // (the caller falls back to vlt5_decoder_step + its own bookkeeping)
+    return decoder_step_fast(k, *g, true);
+}
+extern "C" int vlt5_decode_fast_supported(const vlt5_config* c, const vlt5_step* s) {
+    if (!c || !s) return 0;
+    Ctx k(*c, *s, nullptr);
+    return k.check(false) == VLT5_OK && decode_fast_ok(k) ? 1 : 0;
 }
 ENGINE_ENTRY(encoder_fwd, false)
 ENGINE_ENTRY(decoder_fwd, false)

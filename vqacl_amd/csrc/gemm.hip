@@ -110,11 +110,12 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         // issued as assembly (gemm_kernel.h lds_dma16) their prefetch ring works, and the larger tiles win -- in situ, B = 80:
         // 768x3072x4480 x6 layers 168 -> 151 us and the stacked cross-K/V 18432x768x4640 170 -> 160 us with 256 x 256 (a long
         // reduction only: at K = 400, the decoder, its prologue / epilogue dominate); 2304x768x4480 x6 159 -> 148 us and
-        // 768x768x400 x12 24 -> 18 us with 128 x 128 instead of 64 x 128.  (experiment knobs: VLT5_GEMM_T128_KMKM, VLT5_GEMM_T256_KM)
-        static const int t128_kmkm = getenv("VLT5_GEMM_T128_KMKM") ? atoi(getenv("VLT5_GEMM_T128_KMKM")) : 100;
-        static const int t256_km = getenv("VLT5_GEMM_T256_KM") ? atoi(getenv("VLT5_GEMM_T256_KM")) : 160;
+        // 768x768x400 x12 24 -> 18 us with 128 x 128 instead of 64 x 128.  (experiment switches: vlt5_tuning.gemm_t128_kmkm, gemm_t256_km)
+        const vlt5_tuning* tn = d->tuning;
+        const int t128_kmkm = tn && tn->gemm_t128_kmkm > 0 ? tn->gemm_t128_kmkm : 100;
+        const int t256_km = tn && tn->gemm_t256_km > 0 ? tn->gemm_t256_km : 160;
         const int t128 = (d->a_kmajor && d->b_kmajor) ? t128_kmkm : 768;
-        static const int t256_min = getenv("VLT5_GEMM_T256_MIN") ? atoi(getenv("VLT5_GEMM_T256_MIN")) : 100;   // (160 until the t5-large shapes were measured: 1792 x 4096 x 1024 as 192 tiles of 160 x 256, +3 % on that step)
+        const int t256_min = tn && tn->gemm_t256_min > 0 ? tn->gemm_t256_min : 100;   // (160 until the t5-large shapes were measured: 1792 x 4096 x 1024 as 192 tiles of 160 x 256, +3 % on that step)
         if (d->a_kmajor && d->K >= 1024 && tiles(256, 256) >= t256_km) { bm = 256; bn = 256; }
         else if (!d->a_kmajor && (tiles(256, 256) >= t256_min || (d->K >= 8192 && d->split_k > 1 && tiles(256, 256) >= 128))) {
             // 8-wave kernel; its tile HEIGHT is chosen to fill the 256 CUs: a launch costs about (fixed part + k-steps x height/256)
@@ -140,8 +141,8 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         else {
             bm = 64; bn = 64;                                          // small-M (decoder) problems: most workgroups
             // ... except a wide input gradient (decoder FFN-out dgrad 400 x 3072 x 768 with its ReLU gate): 192 tiles of 128 x 64 read
-            // the transpose-read weight operand half as often (replay 8.0 against 9.5 us; VLT5_GEMM_DEC_TALL=0: the 64 x 64 tiles)
-            static const int tall = getenv("VLT5_GEMM_DEC_TALL") ? atoi(getenv("VLT5_GEMM_DEC_TALL")) : 1;
+            // the transpose-read weight operand half as often (replay 8.0 against 9.5 us; vlt5_tuning.gemm_dec_tall = 1: the 64 x 64 tiles)
+            const int tall = !(tn && tn->gemm_dec_tall == 1);
             if (tall && !d->a_kmajor && d->b_kmajor && d->N >= 2048 && tiles(128, 64) >= 160) { bm = 128; bn = 64; }
         }
     }
@@ -209,6 +210,9 @@ extern "C" int vlt5_gemm_timing_collect(vlt5_gemm_timing_rec* out, int cap) {
 // 256 x 256 kernel), keep >= 4 (8) k-steps of 64 per slice, and stay inside the caller's slab scratch.  Only valid for
 // plain f32 outputs.
 extern "C" int vlt5_gemm_auto_split(int M, int N, int Kred, long long slab_bytes) {
+    return vlt5_gemm_auto_split_tuned(M, N, Kred, slab_bytes, nullptr);
+}
+extern "C" int vlt5_gemm_auto_split_tuned(int M, int N, int Kred, long long slab_bytes, const vlt5_tuning* tuning) {
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const int ksteps = (Kred + 63) / 64;
@@ -221,8 +225,8 @@ extern "C" int vlt5_gemm_auto_split(int M, int N, int Kred, long long slab_bytes
         if (sk > ksteps / 8) sk = ksteps / 8;
     } else {
         // (K >= 768: the decoder's 400 x 768 x 768 projections whose consumer is a norm -- 84 tiles -> 3 x 84 workgroups of 4 k-steps:
-        // 8.3 -> 4.6 us per launch against +1.8 us in the norm that sums the slabs; VLT5_GEMM_SPLIT_KMIN: experiment knob)
-        static const int kmin = getenv("VLT5_GEMM_SPLIT_KMIN") ? atoi(getenv("VLT5_GEMM_SPLIT_KMIN")) : 768;
+        // 8.3 -> 4.6 us per launch against +1.8 us in the norm that sums the slabs; vlt5_tuning.gemm_split_kmin: experiment switch)
+        const int kmin = tuning && tuning->gemm_split_kmin > 0 ? tuning->gemm_split_kmin : 768;
         if (Kred < kmin || tiles >= 128) return 1;
         sk = (int)((512 + tiles / 2) / tiles);
         if (sk > 8) sk = 8;

@@ -160,6 +160,7 @@ class VLT5(nn.Module):
         self._step_count = 0
         self.base_seed = 0x5EED
         self.dp = None                       # set by parallel.DataParallelVLT5
+        self.tuning = L.tuning_from_env()       # experiment switches (vlt5_tuning): the environment is read HERE, once, never in the library
         self.side_stream_enabled = os.environ.get("VQACL_SIDE_STREAM", "0") == "1"    # weight gradients on a second stream (measured: no gain)
         self._side = None
         self._side_events = None
@@ -431,6 +432,7 @@ class VLT5(nn.Module):
             s.feat_store, s.box_store = ptr(ref.store.feats), ptr(ref.store.boxes)
             s.feat_slots, s.n_slots = ptr(ref.slots), ref.store.capacity
         s.enc_lut, s.dec_lut = ptr(st["enc_lut"]), ptr(st["dec_lut"])
+        s.tuning = C.pointer(self.tuning)
         if self._opt_events is not None:
             # an optimizer is (possibly still) updating the parameters on its own stream: the engine waits bucket by bucket
             arr = (L.vp * len(self._opt_events))(*[L.vp(e.cuda_event) for e in self._opt_events])
@@ -600,7 +602,7 @@ class VLT5(nn.Module):
             # only the events the wrapper waits for (the last bucket of every merged slice) are recorded: a marker in the chain's
             # queue is not free, and 26 of them per backward bought nothing
             Ld_, Le_, nb_ = self.cfg.num_decoder_layers, self.cfg.num_layers, self._nbuckets
-            cut_ = Ld_ + 1 + (Le_ - lib().vlt5_encoder_late_layers(Le_)) if Le_ > 1 else Ld_ + 1
+            cut_ = Ld_ + 1 + (Le_ - lib().vlt5_encoder_late_layers_tuned(Le_, C.byref(self.tuning))) if Le_ > 1 else Ld_ + 1
             need = set()
             for lo_, hi_ in ((0, Ld_ + 1), (Ld_ + 1, cut_), (nb_ - 1, nb_), (cut_, nb_ - 1)):
                 need.update(last for _, _, _, last in self.dp.slices_of(lo_, hi_))
@@ -634,7 +636,7 @@ class VLT5(nn.Module):
             # norms + visual embedding (released BEFORE the last weight-gradient GEMMs: their all-reduce hides under those),
             # then the lower half of the encoder -- the only group whose all-reduce stays exposed
             Ld, Le, nb = self.cfg.num_decoder_layers, self.cfg.num_layers, self._nbuckets
-            cut = Ld + 1 + (Le - lib().vlt5_encoder_late_layers(Le)) if Le > 1 else Ld + 1
+            cut = Ld + 1 + (Le - lib().vlt5_encoder_late_layers_tuned(Le, C.byref(self.tuning))) if Le > 1 else Ld + 1
             self.dp.reduce_range(self, events, Ld + 1, cut, mirrored=mirrored)
             self.dp.reduce_range(self, events, nb - 1, nb)                      # embeddings / norms: no GEMM output, cast as before
             self.dp.reduce_range(self, events, cut, nb - 1, final=True, mirrored=mirrored)

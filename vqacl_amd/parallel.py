@@ -110,9 +110,10 @@ class DataParallelVLT5:
         # the ranges the engine releases gradients in (VLT5._engine_backward): decoder + cross k/v, upper half of the encoder,
         # the last bucket (embeddings / norms), lower half of the encoder -- the slice plan, and with it the chunk every rank
         # owns under zero1, only depends on these
+        import ctypes as C
         from ._lib import lib
         Ld, Le, nb = model.cfg.num_decoder_layers, model.cfg.num_layers, len(self.bucket_end)
-        cut = Ld + 1 + (Le - lib().vlt5_encoder_late_layers(Le)) if Le > 1 else Ld + 1
+        cut = Ld + 1 + (Le - lib().vlt5_encoder_late_layers_tuned(Le, C.byref(model.tuning))) if Le > 1 else Ld + 1
         self.release_ranges = ((0, Ld + 1), (Ld + 1, cut), (nb - 1, nb), (cut, nb - 1))
         # identical initial weights on every rank (what DDP's constructor would do)
         dist.broadcast(model._flat, src=0, group=process_group)

@@ -119,18 +119,36 @@ class VLT5VQA(VLT5):
         logits = torch.empty(B, self.cfg.vocab_size, device=dev, dtype=torch.float32)
         nxt = torch.empty(B, dtype=torch.long, device=dev)
         cur = torch.full((B,), start, dtype=torch.long, device=dev)
-        done = torch.zeros(B, dtype=torch.bool, device=dev)
-        padv = torch.full((B,), pad, dtype=torch.long, device=dev)
-        tokens = [cur]
-        for t in range(Tcap - 1):
-            check(lib().vlt5_decoder_step(C.byref(c), C.byref(cs), ptr(cur), t, ptr(cache), ptr(logits), ptr(nxt), stream),
-                  "vlt5_decoder_step")
-            cur = torch.where(done, padv, nxt)
-            tokens.append(cur)
-            done = done | (cur == eos_token_id)
-            if (t & 3) == 3 and bool(done.all()):                     # one host sync every 4 tokens
-                break
-        out = torch.stack(tokens, dim=1)
+        if lib().vlt5_decode_fast_supported(C.byref(c), C.byref(cs)) == 1:
+            # the decode kernels: HF's loop body (argmax -> pad after EOS -> done flags -> next input row) runs on the device inside the
+            # step, the host only enqueues steps and looks at the done flags every 8 tokens
+            out = torch.full((B, Tcap), pad, dtype=torch.long, device=dev)
+            out[:, 0] = start
+            done = torch.zeros(B, dtype=torch.int32, device=dev)
+            g = L.GreedyDesc()
+            g.tokens, g.kv_cache, g.out_tokens, g.out_ld, g.done = ptr(cur), ptr(cache), ptr(out), Tcap, ptr(done)
+            g.eos_id, g.pad_id = int(eos_token_id), int(pad)
+            steps = 0
+            for t in range(Tcap - 1):
+                g.t = t
+                check(lib().vlt5_decoder_step_greedy(C.byref(c), C.byref(cs), C.byref(g), stream), "vlt5_decoder_step_greedy")
+                steps = t + 1
+                if (t & 7) == 7 and bool(done.all()):
+                    break
+            out = out[:, :steps + 1]
+        else:
+            done = torch.zeros(B, dtype=torch.bool, device=dev)
+            padv = torch.full((B,), pad, dtype=torch.long, device=dev)
+            tokens = [cur]
+            for t in range(Tcap - 1):
+                check(lib().vlt5_decoder_step(C.byref(c), C.byref(cs), ptr(cur), t, ptr(cache), ptr(logits), ptr(nxt), stream),
+                      "vlt5_decoder_step")
+                cur = torch.where(done, padv, nxt)
+                tokens.append(cur)
+                done = done | (cur == eos_token_id)
+                if (t & 3) == 3 and bool(done.all()):                     # one host sync every 4 tokens
+                    break
+            out = torch.stack(tokens, dim=1)
         # trim what was decoded after every row had finished (the reference stops at that token)
         alive = (out != eos_token_id).long().cumprod(dim=1)               # 1 until (excluding) a row's first EOS
         length = int(alive.sum(dim=1).max()) + 1                      # longest row incl. its EOS
