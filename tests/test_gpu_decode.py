@@ -34,7 +34,13 @@ def rel_max_err(a, b):
     (80, 3072, 768, "norm_relu"),        # norm -> wi + ReLU
     (80, 768, 3072, "bf16_resid"),       # wo + residual (reduction over 8 waves)
     (80, 32200, 768, "norm_argmax"),     # final norm -> rescale -> tied lm_head, per-tile first maximum
-    (4, 32200, 768, "norm_argmax"),      # BASELINE configs[0] batch
+    (4, 32200, 768, "norm_argmax"),      # BASELINE configs[0] batch: one ragged row block, narrow column tiles
+    (4, 2304, 768, "norm_split"),
+    (4, 768, 768, "bf16_resid"),
+    (4, 768, 768, "norm_relu"),
+    (4, 3072, 768, "norm_relu"),
+    (4, 768, 3072, "bf16_resid"),
+    (80, 768, 768, "norm_relu"),         # norm -> cross-attention q (one fragment per column tile)
     (80, 1024, 4096, "bf16_resid"),      # t5-large wo
     (32, 4096, 1024, "norm_relu"),       # t5-large wi
     (5, 192, 64, "norm_split"),          # tiny configuration, ragged row block
@@ -129,9 +135,9 @@ def test_decode_linear_rejects_bad_arguments(dev):
     o = torch.zeros(8, 64, device=dev)
     d = L.DecodeLinearDesc()
     d.x_bf16, d.ldx, d.w_bf16, d.rows, d.N, d.K, d.out_f32, d.ld_out_f32 = ptr(x), 96, ptr(W), 8, 64, 96, ptr(o), 64
-    assert lib().vlt5_decode_linear_supported(96, 0) == 0 and lib().vlt5_decode_linear(C.byref(d), stream_ptr()) == 1001    # 3 k-steps: no split
-    assert lib().vlt5_decode_linear_supported(80, 0) == 0                                                             # K % 32 != 0
-    assert lib().vlt5_decode_linear_supported(3072, 1) == 0 and lib().vlt5_decode_linear_supported(3072, 0) == 1        # wide norm-folded K: not built
+    assert lib().vlt5_decode_linear_supported(96, 0) == 0 and lib().vlt5_decode_linear(C.byref(d), stream_ptr()) in (1001, 1002)   # K % 64 != 0
+    assert lib().vlt5_decode_linear_supported(80, 0) == 0
+    assert all(lib().vlt5_decode_linear_supported(K, f) == 1 for K in (64, 128, 512, 768, 1024, 2048, 3072, 4096) for f in (0, 1))
     d.K, d.ldx = 64, 64
     d.out_f32 = None
     assert lib().vlt5_decode_linear(C.byref(d), stream_ptr()) == 1001                                                  # no output
@@ -195,7 +201,7 @@ def test_decode_attention_core_vs_f32_reference(dev, B, H, dk, Tk, kind):
     assert lib().vlt5_decode_attn(C.byref(a), stream_ptr()) == 1001
 
 
-def _base_model(dev, seed, B, L=20, T=5):
+def _base_model(dev, seed, B, L=20, T=5, boost=1.0):
     from oracle import ref_cpu as R
     from test_gpu_model import make_model
     ocfg = R.Cfg(dropout=0.0)
@@ -204,6 +210,10 @@ def _base_model(dev, seed, B, L=20, T=5):
     for k in params:
         if params[k].dim() == 1:
             params[k] = params[k] + 0.1 * torch.randn(params[k].shape, generator=g)
+        elif boost != 1.0 and k.startswith("decoder.") and (k.endswith(".o.weight") or k.endswith(".wo.weight")):
+            # a freshly initialised tied-embedding model just echoes its input token (the embedding in the residual stream dominates the
+            # logits): stronger sublayer outputs make the decoded tokens vary, so that the integer checks below have something to bite on
+            params[k] = params[k] * boost
     batch = R.synthetic_batch(ocfg, B=B, L=L, V=36, T=T, seed=seed + 2, task_id=0)
     return R, ocfg, params, batch, make_model(ocfg, params, dev)
 
@@ -280,7 +290,7 @@ def test_greedy_generate_base_model_vs_oracle_and_bookkeeping(dev):
     """test_step / greedy_generate through the decode kernels at VL-T5-base size against the oracle's greedy loop (tokens exact under the
     top-2 margin rule), against the tiled path, and HF's bookkeeping on the device: a row that emitted EOS keeps emitting pad."""
     from test_gpu_model import check_greedy_tokens, oracle_greedy, parity_log
-    R, ocfg, params, batch, model = _base_model(dev, 77, 4, L=12)
+    R, ocfg, params, batch, model = _base_model(dev, 77, 4, L=12, boost=8.0)
     model.train()
     model.train_step(batch, 0, 0.5, 0.3)          # populate the prototypes
     model.eval()
@@ -302,7 +312,9 @@ def test_greedy_generate_base_model_vs_oracle_and_bookkeeping(dev):
     assert ca >= 4
     # bookkeeping: take a token some row emits early as EOS -> that row is pad from the next step on, the other rows are unaffected until
     # they emit it themselves; identical to the host-side loop of the tiled path (torch.where / done flags)
-    r0, t0 = next((r, t) for t in (2, 1, 3, 4, 5) for r in range(4) if int(a[r, t]) != model.cfg.pad_token_id)
+    cands = [(r, t) for t in (2, 1, 3, 4, 5) for r in range(4) if int(a[r, t]) != model.cfg.pad_token_id]
+    assert cands, f"no non-pad token emitted: {a.tolist()}"
+    r0, t0 = cands[0]
     eos = int(a[r0, t0])
     model.tuning.decode_fast = 2
     fa = model.greedy_generate(batch["input_ids"], fb, max_length=steps + 1, eos_token_id=eos)

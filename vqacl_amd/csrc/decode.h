@@ -20,15 +20,10 @@ struct DecLinArgs {
     int relu;
     float* pmax; int* pidx; int ptiles;       // per (row, column tile) first maximum and its column: [rows][CT]
     const int* t_ptr; long long t_stride2;    // optional device-side step index (for out_b2)
-    // optional prefetch for the kernels that FOLLOW in the chain (speed only: block b is observed to run on XCD b % 8, so the lines
-    // land in the L2 the consumer will read them from; every lane touches one 128-byte line with a 4-byte load, nothing is stored):
-    const void* pf_w; long long pf_xcd_bytes, pf_total;      // weight slice of a later declin launch: XCD x takes [x*pf_xcd_bytes, +pf_xcd_bytes)
-    const bf16_t* pf_kv; long long pf_kv_sb, pf_kv_st; int pf_H, pf_dk, pf_Tk, pf_B;   // keys | values the next dec_core launch reads
     int RB, CT, ct_per_xcd;                   // filled by vlt5_declin_launch
     long long* tl;                            // -DDECLIN_TIMELINE builds: [workgroup][8] shader-clock stamps of wave 0 (tools/declin_timeline.py)
 };
-// bytes of W[N, K] that one XCD's workgroups of the declin launch (rows, N, K, af32) read: the slice a predecessor should prefetch per XCD
-long long vlt5_declin_xcd_bytes(int rows, int N, int K, int af32);
+
 int vlt5_declin_launch(DecLinArgs a, hipStream_t st);
 int vlt5_declin_tiles(int rows, int N, int K, int af32);
 extern "C" int vlt5_decode_linear_supported(int K, int norm_folded);

@@ -24,14 +24,9 @@
 #include "common.h"
 #include "decode.h"
 
-#ifndef DECLIN_PF
-#define DECLIN_PF 1                // prefetch for the following launches (A/B: -DDECLIN_PF=0)
-#endif
-#define DECLIN_PF_W 3              // lines per lane of the next weight slice (<= 96 KB per 256-thread workgroup)
-#define DECLIN_PF_KV 2             // lines per lane of the next attention core's keys | values (4 x 58 x 2 lines per workgroup)
 #ifndef DECLIN_WT
-#define DECLIN_WT 1                // outputs written through the L2 (A/B: -DDECLIN_WT=0 plain stores)
-#endif
+#define DECLIN_WT 0                // 1: outputs written through the L2 (sc0 sc1) as the GEMM does; measured 1 % slower on these 245 KB
+#endif                             // outputs than plain stores (profiles/r04_d_ab_decode.txt), so plain is the default
 
 #ifdef DECLIN_TIMELINE
 #define TLS(i) do { if (a.tl && threadIdx.x == 0) a.tl[(size_t)blockIdx.x * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -59,15 +54,19 @@ __device__ __forceinline__ void dl_store8(void* dst, uint2 v) {
 // ------------------------------------------------------------------------------------------------------------------------------
 // declin: out[m, n] = epi(rowscale[m] * alpha * sum_k A[m, k] W[n, k])
 // ------------------------------------------------------------------------------------------------------------------------------
-template <bool AF32, int KS, int NFRAG>
-__global__ __launch_bounds__(512) void declin_kernel(const DecLinArgs a) {
-    // LDS: per-wave norm-weight staging (AF32), partial tiles of every wave, per-wave partial sums of squares, argmax exchange
-    __shared__ float4 red[8][NFRAG][64];
-    __shared__ float wst[AF32 ? 8 : 1][AF32 ? 256 : 4];
-    __shared__ float ssq_s[8][16];
-    __shared__ float amax_s[NFRAG][16];
-    __shared__ int aidx_s[NFRAG][16];
+// Operand staging.  Fragment-shaped loads straight into VGPRs (16 rows x 64 bytes per wave instruction) kept the texture-address unit
+// busy 52 cycles per instruction (PMC: TA_BUSY = half the kernel, 64 cache accesses per instruction; profiles/r04_f_decode_pmc.txt),
+// i.e. ~17 bytes per clock and CU -- the kernel was bound by that, not by HBM.  So the weight slice (and a bf16 activation operand)
+// now arrive by LDS-DMA in whole 128-byte lines: a piece = 8 rows x 128 bytes per wave instruction, lane l fetches chunk
+// (l & 7) ^ (row & 7) of row l >> 3 into the linear LDS slot l, so that a row's chunk c sits in slot c ^ (row & 7) and the
+// ds_read_b128 of a fragment (16 rows, same chunk) spreads over the banks.  Every wave stages only ITS k-range (the reduction is still
+// split over the waves): no workgroup barrier before the MFMAs, one counted wait per wave.  An f32 activation operand (norm folded in)
+// stays on the register path: its values are multiplied by the norm weight and squared on the way.
+typedef __attribute__((address_space(3))) void* dl_lds_ptr_t;
 
+template <bool AF32, int KT, int NFRAG>
+__global__ __launch_bounds__(512) void declin_kernel(const DecLinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dl_smem[];
     TLS(0);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
     // workgroup -> (column tile, row block): the row blocks of a column tile share an XCD (block b runs on XCD b % 8), so the tile's
@@ -78,133 +77,129 @@ __global__ __launch_bounds__(512) void declin_kernel(const DecLinArgs a) {
     const int r16 = lane & 15, kq = lane >> 4;
     const int m = rb * 16 + r16;
     const int mc = m < a.rows ? m : a.rows - 1;                  // rows past the end read the last row (never stored)
-    const int kbase = w * (KS * 32) + kq * 8;
     const int n_tile = ct * (16 * NFRAG);
+    // LDS carve: [per wave: weight tiles KT x (NFRAG*16 rows x 128 B) | bf16 activation tiles KT x (16 x 128 B)] | partial tiles |
+    // norm-weight strips | partial sums of squares | argmax exchange
+    constexpr int WT_BYTES = NFRAG * 16 * 128, XT_BYTES = AF32 ? 0 : 16 * 128, WAVE_BYTES = KT * (WT_BYTES + XT_BYTES);
+    char* stage = dl_smem + (size_t)w * WAVE_BYTES;
+    float4* red = reinterpret_cast<float4*>(dl_smem + (size_t)NW * WAVE_BYTES);           // [NW][NFRAG][64]
+    float* wst = reinterpret_cast<float*>(red + (size_t)NW * NFRAG * 64);                 // [NW][256] (AF32)
+    float* ssq_s = wst + (AF32 ? NW * 256 : 0);                                          // [NW][16]
+    float* amax_s = ssq_s + NW * 16;                                                     // [NFRAG][16]
+    int* aidx_s = reinterpret_cast<int*>(amax_s + NFRAG * 16);                           // [NFRAG][16]
 
-    // ---- every load of this wave in one burst, in the order they are needed: norm weights, activation rows, weight slice, residual ----
-    // (loads return in order: the activation rows are converted while the weight slice is still on its way.  The scheduling barrier
-    // keeps the compiler from sinking loads between the MFMAs to save registers -- that would turn one round trip into KS of them.)
-    float4 xa[AF32 ? KS : 1][2];
-    uint4 xb[AF32 ? 1 : KS];
-    float4 wl = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (AF32) {
-        // the wave's KS*32 norm weights: one coalesced 16-byte load per lane, handed round through the wave's LDS strip
-        if (lane * 4 < KS * 32) wl = *reinterpret_cast<const float4*>(a.ln_w + w * (KS * 32) + lane * 4);
-        const float* xp = a.xf + (size_t)mc * a.ldx + kbase;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            xa[ks][0] = *reinterpret_cast<const float4*>(xp + ks * 32);
-            xa[ks][1] = *reinterpret_cast<const float4*>(xp + ks * 32 + 4);
-        }
-    } else {
-        const bf16_t* xp = a.xb + (size_t)mc * a.ldx + kbase;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) xb[ks] = *reinterpret_cast<const uint4*>(xp + ks * 32);
-    }
-    uint4 bw[KS][NFRAG];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-        for (int f = 0; f < NFRAG; ++f) {
-            int n = n_tile + f * 16 + r16;
-            n = n < a.N ? n : a.N - 1;
-            bw[ks][f] = *reinterpret_cast<const uint4*>(a.W + (size_t)n * a.K + kbase + ks * 32);
-        }
-    }
-    // the residual quad of the fragment this wave finishes (wave f finishes fragment f)
+    // the residual quad of the fragment this wave finishes (wave f finishes fragment f): requested first, needed last
     float4 rpre = make_float4(0.f, 0.f, 0.f, 0.f);
     {
         const int n0 = n_tile + w * 16 + kq * 4;
         if (a.resid && w < NFRAG && m < a.rows && n0 < a.N) rpre = *reinterpret_cast<const float4*>(a.resid + (size_t)m * a.ldr + n0);
     }
     const int t_step = a.t_ptr ? *a.t_ptr : 0;
-    // touch what the next kernels of the chain will read: one 4-byte load per 128-byte line, a fixed number of them per lane so that no
-    // load waits for another (the values are consumed by nobody; the registers are named at the end of the kernel)
-    unsigned pf[DECLIN_PF_W + DECLIN_PF_KV];
-#pragma unroll
-    for (int i = 0; i < DECLIN_PF_W + DECLIN_PF_KV; ++i) pf[i] = 0;
-#if DECLIN_PF
-    if (a.pf_w) {
-        const long long nj = gridDim.x >> 3;
-        const long long chunk = ((a.pf_xcd_bytes + nj - 1) / nj + 127) & ~127ll;
-        const long long lo = (long long)xcd * a.pf_xcd_bytes + (long long)j * chunk;
-        const long long hi_x = (long long)(xcd + 1) * a.pf_xcd_bytes;
-        long long hi = lo + chunk < hi_x ? lo + chunk : hi_x;
-        hi = hi < a.pf_total ? hi : a.pf_total;
-#pragma unroll
-        for (int i = 0; i < DECLIN_PF_W; ++i) {
-            const long long o = lo + ((long long)i * blockDim.x + threadIdx.x) * 128;
-            if (o < hi) pf[i] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(a.pf_w) + o);
-        }
-    }
-    if (a.pf_kv) {
-        // dec_core workgroup x serves (sample, head) pairs 4x .. 4x+3: their Tk keys and values, one 128-byte line each (d_kv = 64)
-        const int per = 2 * a.pf_Tk;
-#pragma unroll
-        for (int u = 0; u < DECLIN_PF_KV; ++u) {
-            const int i = u * blockDim.x + threadIdx.x;
-            const int gw = blockIdx.x * 4 + i / per, r = i % per;
-            if (i < 4 * per && gw < a.pf_B * a.pf_H) {
-                const int b = gw / a.pf_H, h = gw % a.pf_H, key = r >> 1, part = r & 1;
-                pf[DECLIN_PF_W + u] = *reinterpret_cast<const unsigned*>(a.pf_kv + (size_t)b * a.pf_kv_sb + (size_t)key * a.pf_kv_st +
-                                                                         part * (a.pf_H * a.pf_dk) + h * a.pf_dk);
-            }
-        }
-    }
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-    TLS(1);
-
     f32x4_t acc[NFRAG];
 #pragma unroll
     for (int f = 0; f < NFRAG; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float ssq = 0.f;
-    if constexpr (AF32) {
-        if (lane * 4 < KS * 32) *reinterpret_cast<float4*>(&wst[w][lane * 4]) = wl;
-        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): the strip is this wave's own, no barrier
-        __builtin_amdgcn_wave_barrier();
-        TLS(2);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        bf16x8_t fx;
+    const int prow = lane >> 3, pchunk = (lane & 7) ^ (lane >> 3);           // this lane's (row within a piece, source chunk)
+    const int phases = a.K / (64 * KT * NW);
+    for (int ph = 0; ph < phases; ++ph) {
+        const int k0 = (ph * NW + w) * (KT * 64);                            // this wave's k-range of the phase: KT tiles of 64
+        // ---- requests of the phase, in the order they are consumed: norm weights + f32 rows (registers), then the DMA pieces ----
+        float4 xa[AF32 ? KT * 2 : 1][2];
+        float4 wl = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (AF32) {
-            const float4 w0 = *reinterpret_cast<const float4*>(&wst[w][ks * 32 + kq * 8]);
-            const float4 w1 = *reinterpret_cast<const float4*>(&wst[w][ks * 32 + kq * 8 + 4]);
-            const float4 x0 = xa[ks][0], x1 = xa[ks][1];
-            ssq += x0.x * x0.x + x0.y * x0.y + x0.z * x0.z + x0.w * x0.w + x1.x * x1.x + x1.y * x1.y + x1.z * x1.z + x1.w * x1.w;
-            const uint4 pk = make_uint4(pack_bf16x2(x0.x * w0.x, x0.y * w0.y), pack_bf16x2(x0.z * w0.z, x0.w * w0.w),
-                                        pack_bf16x2(x1.x * w1.x, x1.y * w1.y), pack_bf16x2(x1.z * w1.z, x1.w * w1.w));
-            fx = __builtin_bit_cast(bf16x8_t, pk);
-        } else {
-            fx = __builtin_bit_cast(bf16x8_t, xb[ks]);
+            if (lane * 4 < KT * 64) wl = *reinterpret_cast<const float4*>(a.ln_w + k0 + lane * 4);
+            const float* xp = a.xf + (size_t)mc * a.ldx + k0 + kq * 8;
+#pragma unroll
+            for (int ks = 0; ks < KT * 2; ++ks) {
+                xa[ks][0] = *reinterpret_cast<const float4*>(xp + ks * 32);
+                xa[ks][1] = *reinterpret_cast<const float4*>(xp + ks * 32 + 4);
+            }
+        }
+        if (ph > 0) {                                                        // the stage is reused: every read of the phase before is done
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
-        for (int f = 0; f < NFRAG; ++f)        // weight fragment as the A operand: lane (r16, kq) ends up with out[m = r16][n = kq*4 .. +3]
-            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bw[ks][f]), fx, acc[f], 0, 0, 0);
+        for (int kt = 0; kt < KT; ++kt) {
+            if constexpr (!AF32) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    int mr = rb * 16 + i * 8 + prow;
+                    mr = mr < a.rows ? mr : a.rows - 1;
+                    __builtin_amdgcn_global_load_lds(a.xb + (size_t)mr * a.ldx + k0 + kt * 64 + pchunk * 8,
+                                                     (dl_lds_ptr_t)(stage + KT * WT_BYTES + kt * XT_BYTES + i * 1024), 16, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NFRAG * 2; ++i) {
+                int n = n_tile + i * 8 + prow;
+                n = n < a.N ? n : a.N - 1;
+                __builtin_amdgcn_global_load_lds(a.W + (size_t)n * a.K + k0 + kt * 64 + pchunk * 8,
+                                                 (dl_lds_ptr_t)(stage + kt * WT_BYTES + i * 1024), 16, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph == 0) TLS(1);
+        // ---- f32 activation rows -> bf16(x * w_norm) fragments + the rows' sums of squares (while the weight pieces are on their way) ----
+        bf16x8_t fx[KT * 2];
+        if constexpr (AF32) {
+            float* strip = wst + w * 256;
+            if (lane * 4 < KT * 64) *reinterpret_cast<float4*>(strip + lane * 4) = wl;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the strip is this wave's own: no barrier)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < KT * 2; ++ks) {
+                const float4 w0 = *reinterpret_cast<const float4*>(strip + ks * 32 + kq * 8);
+                const float4 w1 = *reinterpret_cast<const float4*>(strip + ks * 32 + kq * 8 + 4);
+                const float4 x0 = xa[ks][0], x1 = xa[ks][1];
+                ssq += x0.x * x0.x + x0.y * x0.y + x0.z * x0.z + x0.w * x0.w + x1.x * x1.x + x1.y * x1.y + x1.z * x1.z + x1.w * x1.w;
+                const uint4 pk = make_uint4(pack_bf16x2(x0.x * w0.x, x0.y * w0.y), pack_bf16x2(x0.z * w0.z, x0.w * w0.w),
+                                            pack_bf16x2(x1.x * w1.x, x1.y * w1.y), pack_bf16x2(x1.z * w1.z, x1.w * w1.w));
+                fx[ks] = __builtin_bit_cast(bf16x8_t, pk);
+            }
+            if (ph == 0) TLS(2);
+        }
+        // ---- the wave's own pieces have landed: fragments out of LDS, MFMAs ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const int slot = (p2 * 4 + kq) ^ (r16 & 7);
+                bf16x8_t fa;
+                if constexpr (AF32) fa = fx[kt * 2 + p2];
+                else fa = *reinterpret_cast<const bf16x8_t*>(stage + KT * WT_BYTES + kt * XT_BYTES + r16 * 128 + slot * 16);
+#pragma unroll
+                for (int f = 0; f < NFRAG; ++f) {          // weight fragment as the A operand: lane (r16, kq) ends up with out[m = r16][n = kq*4 .. +3]
+                    const bf16x8_t fw = *reinterpret_cast<const bf16x8_t*>(stage + kt * WT_BYTES + (f * 16 + r16) * 128 + slot * 16);
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fa, acc[f], 0, 0, 0);
+                }
+            }
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     TLS(3);
     // ---- partial tiles of the NW waves meet in LDS ----------------------------------------------------------------------
 #pragma unroll
-    for (int f = 0; f < NFRAG; ++f) red[w][f][lane] = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
+    for (int f = 0; f < NFRAG; ++f) red[(w * NFRAG + f) * 64 + lane] = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
     if constexpr (AF32) {
         ssq += __shfl_xor(ssq, 16, 64);
         ssq += __shfl_xor(ssq, 32, 64);
-        if (lane < 16) ssq_s[w][lane] = ssq;
+        if (lane < 16) ssq_s[w * 16 + lane] = ssq;
     }
     __syncthreads();
     TLS(4);
     float rs = a.alpha;
     if constexpr (AF32) {
         float s = 0.f;
-        for (int ww = 0; ww < NW; ++ww) s += ssq_s[ww][r16];
+        for (int ww = 0; ww < NW; ++ww) s += ssq_s[ww * 16 + r16];
         rs *= rsqrtf(s / (float)a.K + a.eps);
     }
     for (int f = w; f < NFRAG; f += NW) {
-        float4 v = red[0][f][lane];
+        float4 v = red[f * 64 + lane];
         for (int ww = 1; ww < NW; ++ww) {
-            const float4 o = red[ww][f][lane];
+            const float4 o = red[(ww * NFRAG + f) * 64 + lane];
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
         v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
@@ -240,18 +235,18 @@ __global__ __launch_bounds__(512) void declin_kernel(const DecLinArgs a) {
                 const int oi = __shfl_xor(bi, o, 64);
                 if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
             }
-            if (lane < 16) { amax_s[f][lane] = best; aidx_s[f][lane] = bi; }
+            if (lane < 16) { amax_s[f * 16 + lane] = best; aidx_s[f * 16 + lane] = bi; }
         }
     }
     if (a.pmax) {
         __syncthreads();
         if (threadIdx.x < 16 && rb * 16 + (int)threadIdx.x < a.rows) {
-            float best = amax_s[0][threadIdx.x];
-            int bi = aidx_s[0][threadIdx.x];
+            float best = amax_s[threadIdx.x];
+            int bi = aidx_s[threadIdx.x];
 #pragma unroll
             for (int f = 1; f < NFRAG; ++f) {
-                const float ov = amax_s[f][threadIdx.x];
-                const int oi = aidx_s[f][threadIdx.x];
+                const float ov = amax_s[f * 16 + threadIdx.x];
+                const int oi = aidx_s[f * 16 + threadIdx.x];
                 if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
             }
             const size_t slot = (size_t)(rb * 16 + threadIdx.x) * a.CT + ct;
@@ -260,8 +255,6 @@ __global__ __launch_bounds__(512) void declin_kernel(const DecLinArgs a) {
         }
     }
     TLS(5);
-#pragma unroll
-    for (int i = 0; i < DECLIN_PF_W + DECLIN_PF_KV; ++i) asm volatile("" ::"v"(pf[i]));      // (keeps the prefetch loads; they landed long ago)
 #ifdef DECLIN_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TLS(6);
@@ -269,29 +262,30 @@ __global__ __launch_bounds__(512) void declin_kernel(const DecLinArgs a) {
 }
 
 typedef void (*declin_fn)(const DecLinArgs);
-template <bool AF32, int KS>
+template <bool AF32, int KT>
 declin_fn declin_pick_nfrag(int nfrag) {
     switch (nfrag) {
-        case 1: return &declin_kernel<AF32, KS, 1>;
-        case 2: return &declin_kernel<AF32, KS, 2>;
-        case 3: if constexpr (KS <= 8) return &declin_kernel<AF32, KS, 3>; else return nullptr;
-        case 4: if constexpr (KS <= 8) return &declin_kernel<AF32, KS, 4>; else return nullptr;
+        case 1: return &declin_kernel<AF32, KT, 1>;
+        case 2: return &declin_kernel<AF32, KT, 2>;
+        case 3: return &declin_kernel<AF32, KT, 3>;
+        case 4: return &declin_kernel<AF32, KT, 4>;
         default: return nullptr;
     }
 }
 template <bool AF32>
-declin_fn declin_pick(int ks, int nfrag) {
-    switch (ks) {
+declin_fn declin_pick(int kt, int nfrag) {
+    switch (kt) {
         case 1: return declin_pick_nfrag<AF32, 1>(nfrag);
         case 2: return declin_pick_nfrag<AF32, 2>(nfrag);
         case 3: return declin_pick_nfrag<AF32, 3>(nfrag);
         case 4: return declin_pick_nfrag<AF32, 4>(nfrag);
-        case 6: return declin_pick_nfrag<AF32, 6>(nfrag);
-        case 8: return declin_pick_nfrag<AF32, 8>(nfrag);
-        case 12: if constexpr (!AF32) return declin_pick_nfrag<false, 12>(nfrag); else return nullptr;
-        case 16: if constexpr (!AF32) return declin_pick_nfrag<false, 16>(nfrag); else return nullptr;
         default: return nullptr;
     }
+}
+// dynamic LDS of a launch: per-wave stages + partial tiles + norm-weight strips + sums of squares + argmax exchange
+static size_t declin_lds_bytes(bool af32, int kt, int nfrag, int nw) {
+    const size_t wave = (size_t)kt * (nfrag * 16 * 128 + (af32 ? 0 : 16 * 128));
+    return nw * wave + (size_t)nw * nfrag * 64 * 16 + (af32 ? nw * 256 * 4 : 0) + nw * 16 * 4 + nfrag * 16 * 8;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -442,45 +436,38 @@ __global__ __launch_bounds__(256) void dec_io_kernel(const DecIoArgs a) {
 
 }  // namespace
 
-// K = 32 * KS * NW with KS out of the instantiated set and NW <= 8 waves; prefers four waves
-static bool declin_split(int K, bool af32, int* ks, int* nw) {
-    if (K <= 0 || (K & 31)) return false;
-    const int steps = K / 32;
-#ifndef DECLIN_WAVES
-#define DECLIN_WAVES 4             // preferred number of waves per workgroup (A/B: -DDECLIN_WAVES=8)
-#endif
-    const int tries[4] = {DECLIN_WAVES, DECLIN_WAVES == 4 ? 8 : 4, 2, 1};
+// K = 64 * KT * NW * phases: k-tiles of 64 per wave and phase (KT <= 4, the per-wave stages must fit the LDS), NW <= 8 waves; fewest
+// phases first (each is a memory round trip), then four waves before eight
+static bool declin_split(int K, bool af32, int nfrag, int* kt, int* nw) {
+    if (K <= 0 || (K & 63)) return false;
+    const int tiles = K / 64;
+    int best_ph = 1 << 30;
+    const int tries[4] = {4, 8, 2, 1};
     for (int t = 0; t < 4; ++t) {
         const int w = tries[t];
-        if (steps % w) continue;
-        const int s = steps / w;
-        const bool ok = s == 1 || s == 2 || s == 3 || s == 4 || s == 6 || s == 8 || (!af32 && (s == 12 || s == 16));
-        if (ok) { *ks = s; *nw = w; return true; }
+        if (tiles % w) continue;
+        const int per = tiles / w;
+        for (int k = 4; k >= 1; --k) {
+            if (per % k || declin_lds_bytes(af32, k, nfrag, w) > 160 * 1024) continue;
+            if (per / k < best_ph) { best_ph = per / k; *kt = k; *nw = w; }
+            break;
+        }
     }
-    return false;
+    return best_ph < (1 << 30);
 }
 
-// the launch geometry of (rows, N, K): k-steps per wave, waves, fragments per column tile
-static bool declin_geometry(int rows, int N, int K, bool af32, int* ks, int* nw, int* nfrag) {
-    if (!declin_split(K, af32, ks, nw)) return false;
+// the launch geometry of (rows, N, K): k-tiles per wave and phase, waves, fragments per column tile
+static bool declin_geometry(int rows, int N, int K, bool af32, int* kt, int* nw, int* nfrag) {
     const int RB = (rows + 15) / 16;
-    const int fmax = *ks >= 12 ? 2 : 4;
-    for (int f = fmax; f >= 1; --f) {
+    for (int f = 4; f >= 1; --f) {          // widest column tile that still fills the chip (>= ~200 workgroups)
         const int ctf = (N + 16 * f - 1) / (16 * f);
-        if (ctf * RB >= 200 || f == 1) { *nfrag = f; return true; }
+        if (ctf * RB >= 200 || f == 1) { *nfrag = f; return declin_split(K, af32, f, kt, nw); }
     }
     return false;
 }
-long long vlt5_declin_xcd_bytes(int rows, int N, int K, int af32) {
-    int ks, nw, nfrag;
-    if (!declin_geometry(rows, N, K, af32 != 0, &ks, &nw, &nfrag)) return 0;
-    const int CT = (N + 16 * nfrag - 1) / (16 * nfrag);
-    return (long long)((CT + 7) / 8) * 16 * nfrag * K * 2;
-}
-
 extern "C" int vlt5_decode_linear_supported(int K, int af32) {
-    int ks, nw;
-    return declin_split(K, af32 != 0, &ks, &nw) ? 1 : 0;
+    int kt, nw;
+    return declin_split(K, af32 != 0, 4, &kt, &nw) ? 1 : 0;       // (true for the widest column tile: true for every narrower one)
 }
 
 #ifdef DECLIN_TIMELINE
@@ -492,21 +479,26 @@ int vlt5_declin_launch(DecLinArgs a, hipStream_t st) {
     const bool af32 = a.xf != nullptr;
     if ((!a.xf && !a.xb) || !a.W || a.rows <= 0 || a.N <= 0 || (a.N & 3)) return VLT5_ERR_ARG;
     if (af32 && !a.ln_w) return VLT5_ERR_ARG;
-    if ((a.ldx & 7) || (a.K & 31)) return VLT5_ERR_ALIGN;
-    int ks, nw, nfrag;
-    // widest column tile that still fills the chip (>= ~200 workgroups); the wide reductions (KS >= 12) only come one or two fragments wide
-    if (!declin_geometry(a.rows, a.N, a.K, af32, &ks, &nw, &nfrag)) return VLT5_ERR_ARG;
+    if ((a.ldx & 7) || (a.K & 63)) return VLT5_ERR_ALIGN;
+    int kt, nw, nfrag;
+    if (!declin_geometry(a.rows, a.N, a.K, af32, &kt, &nw, &nfrag)) return VLT5_ERR_ARG;
     a.RB = (a.rows + 15) / 16;
     a.CT = (a.N + 16 * nfrag - 1) / (16 * nfrag);
     a.ct_per_xcd = (a.CT + 7) / 8;
-    declin_fn fn = af32 ? declin_pick<true>(ks, nfrag) : declin_pick<false>(ks, nfrag);
+    declin_fn fn = af32 ? declin_pick<true>(kt, nfrag) : declin_pick<false>(kt, nfrag);
     if (!fn) return VLT5_ERR_ARG;
     if (a.pmax && a.ptiles != a.CT) return VLT5_ERR_ARG;
+    const size_t lds = declin_lds_bytes(af32, kt, nfrag, nw);
+    static std::atomic<unsigned long long> optin[2][4][4];          // per instantiation: devices with the large-LDS attribute set
+    if (lds > 64 * 1024) {
+        const int rc = vlt5_lds_optin((const void*)fn, 160 * 1024, optin[af32 ? 1 : 0][kt - 1][nfrag - 1]);
+        if (rc) return rc;
+    }
     const int grid = 8 * a.ct_per_xcd * a.RB;
 #ifdef DECLIN_TIMELINE
     if (g_declin_tl) { a.tl = g_declin_tl; g_declin_tl += g_declin_tl_stride; }
 #endif
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(nw * 64), 0, st, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(nw * 64), lds, st, a);
     LAUNCH_CHECK();
     return VLT5_OK;
 }

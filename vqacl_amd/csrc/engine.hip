@@ -799,12 +799,6 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
         for (int l = 0; l < Ld; ++l) RC(k.wait_bucket(Ld - 1 - l));
     }
     float* bias_t = k.w<float>(p.dec_bias);                        // [H][Tcap]: relative-position bias row of query position t
-    // every launch also touches the weights the NEXT projection of the chain reads (and the projection in front of the cross-attention
-    // core the keys | values of that core), so those arrive from the L2 instead of HBM
-    auto pf = [&](DecLinArgs& a, const bf16_t* Wn, int Nn, int Kn, int af32n) {
-        a.pf_w = Wn; a.pf_xcd_bytes = vlt5_declin_xcd_bytes(B, Nn, Kn, af32n); a.pf_total = (long long)Nn * Kn * 2;
-        if (a.pf_xcd_bytes <= 0) a.pf_w = nullptr;
-    };
     if (t == 0 || !chained) {
         DecIoArgs io;
         memset(&io, 0, sizeof io);
@@ -834,7 +828,6 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
         {   // norm -> q | k | v: q to its buffer, k | v into cache slot t
             DecLinArgs a = lin(y0, D.ln_s, nullptr, d, k.Pb + D.sqkv, 3 * inner, q, inner, nullptr, nullptr, 0);
             a.split_col = inner; a.out_b2 = kc + (size_t)t * 2 * inner; a.ldo2 = (long long)Tcap * 2 * inner;
-            pf(a, k.Pb + D.so, d, inner, 0);
             RC(vlt5_declin_launch(a, k.st));
         }
         {
@@ -846,13 +839,10 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
         }
         {
             DecLinArgs a = lin(nullptr, 0, k.w<bf16_t>(p.ctx_s[l]), inner, k.Pb + D.so, d, nullptr, 0, y1, y0, 0);
-            pf(a, k.Pb + D.cq, inner, d, 1);
             RC(vlt5_declin_launch(a, k.st));
         }
         {
             DecLinArgs a = lin(y1, D.ln_c, nullptr, d, k.Pb + D.cq, inner, k.w<bf16_t>(p.qc[l]), inner, nullptr, nullptr, 0);
-            pf(a, k.Pb + D.co, d, inner, 0);
-            if (c.d_kv == 64) { a.pf_kv = kv; a.pf_kv_sb = (long long)Sx * 2 * inner; a.pf_kv_st = 2 * inner; a.pf_H = k.H; a.pf_dk = 64; a.pf_Tk = Sx; a.pf_B = B; }
             RC(vlt5_declin_launch(a, k.st));
         }
         {
@@ -865,22 +855,18 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
         }
         {
             DecLinArgs a = lin(nullptr, 0, k.w<bf16_t>(p.ctx_c[l]), inner, k.Pb + D.co, d, nullptr, 0, y2, y1, 0);
-            pf(a, k.Pb + D.wi, ffw, d, 1);
             RC(vlt5_declin_launch(a, k.st));
         }
         if (c.gated_act) {
             DecLinArgs a = lin(y2, D.ln_f, nullptr, d, k.Pb + D.wi, 2 * ff, k.w<bf16_t>(p.ud[l]), 2 * ff, nullptr, nullptr, 0);
-            pf(a, k.Pb + D.wo, d, ff, 0);
             RC(vlt5_declin_launch(a, k.st));
             RC(vlt5_glu_fwd(k.w<bf16_t>(p.ud[l]), k.w<bf16_t>(p.hd[l]), B, ff, 0.f, 0, k.st));
         } else {
             DecLinArgs a = lin(y2, D.ln_f, nullptr, d, k.Pb + D.wi, ff, k.w<bf16_t>(p.hd[l]), ff, nullptr, nullptr, 1);
-            pf(a, k.Pb + D.wo, d, ff, 0);
             RC(vlt5_declin_launch(a, k.st));
         }
         {
             DecLinArgs a = lin(nullptr, 0, k.w<bf16_t>(p.hd[l]), ff, k.Pb + D.wo, d, nullptr, 0, y3, y2, 0);
-            if (l + 1 < Ld) pf(a, k.Pb + L.dec[l + 1].sqkv, 3 * inner, d, 1);
             RC(vlt5_declin_launch(a, k.st));
         }
     }
