@@ -261,6 +261,139 @@ __global__ __launch_bounds__(512) void declin_kernel(const DecLinArgs a) {
 #endif
 }
 
+// The vocabulary projection: N = 32200 columns make 504 column tiles -- enough workgroups without cutting the rows, and its 49.5 MB weight
+// is the one operand of the step that is worth reading ONCE: a workgroup stages its 64-column slice a single time and walks the row blocks
+// (the f32 rows of block rb + 1 are requested while block rb is computed).  Norm folded in as in declin_kernel<true, ...>; one phase only.
+template <int KT, int NFRAG>
+__global__ __launch_bounds__(512) void declin_rows_kernel(const DecLinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dl_smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    const int ct = blockIdx.x;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int n_tile = ct * (16 * NFRAG);
+    constexpr int WT_BYTES = NFRAG * 16 * 128, WAVE_BYTES = KT * WT_BYTES;
+    char* stage = dl_smem + (size_t)w * WAVE_BYTES;
+    float4* red = reinterpret_cast<float4*>(dl_smem + (size_t)NW * WAVE_BYTES);
+    float* wst = reinterpret_cast<float*>(red + (size_t)NW * NFRAG * 64);
+    float* ssq_s = wst + NW * 256;
+    float* amax_s = ssq_s + NW * 16;
+    int* aidx_s = reinterpret_cast<int*>(amax_s + NFRAG * 16);
+    const int prow = lane >> 3, pchunk = (lane & 7) ^ (lane >> 3);
+    const int k0 = w * (KT * 64);
+    float4 wl = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane * 4 < KT * 64) wl = *reinterpret_cast<const float4*>(a.ln_w + k0 + lane * 4);
+    auto load_rows = [&](int rb, float4 (&x)[KT * 2][2]) {
+        int mr = rb * 16 + r16;
+        mr = mr < a.rows ? mr : a.rows - 1;
+        const float* xp = a.xf + (size_t)mr * a.ldx + k0 + kq * 8;
+#pragma unroll
+        for (int ks = 0; ks < KT * 2; ++ks) {
+            x[ks][0] = *reinterpret_cast<const float4*>(xp + ks * 32);
+            x[ks][1] = *reinterpret_cast<const float4*>(xp + ks * 32 + 4);
+        }
+    };
+    float4 xa[KT * 2][2], xn[KT * 2][2];
+    load_rows(0, xa);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int i = 0; i < NFRAG * 2; ++i) {
+            int n = n_tile + i * 8 + prow;
+            n = n < a.N ? n : a.N - 1;
+            __builtin_amdgcn_global_load_lds(a.W + (size_t)n * a.K + k0 + kt * 64 + pchunk * 8, (dl_lds_ptr_t)(stage + kt * WT_BYTES + i * 1024), 16, 0, 0);
+        }
+    }
+    float* strip = wst + w * 256;
+    if (lane * 4 < KT * 64) *reinterpret_cast<float4*>(strip + lane * 4) = wl;
+    for (int rb = 0; rb < a.RB; ++rb) {
+        if (rb + 1 < a.RB) load_rows(rb + 1, xn);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8_t fx[KT * 2];
+        float ssq = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KT * 2; ++ks) {
+            const float4 w0 = *reinterpret_cast<const float4*>(strip + ks * 32 + kq * 8);
+            const float4 w1 = *reinterpret_cast<const float4*>(strip + ks * 32 + kq * 8 + 4);
+            const float4 x0 = xa[ks][0], x1 = xa[ks][1];
+            ssq += x0.x * x0.x + x0.y * x0.y + x0.z * x0.z + x0.w * x0.w + x1.x * x1.x + x1.y * x1.y + x1.z * x1.z + x1.w * x1.w;
+            const uint4 pk = make_uint4(pack_bf16x2(x0.x * w0.x, x0.y * w0.y), pack_bf16x2(x0.z * w0.z, x0.w * w0.w),
+                                        pack_bf16x2(x1.x * w1.x, x1.y * w1.y), pack_bf16x2(x1.z * w1.z, x1.w * w1.w));
+            fx[ks] = __builtin_bit_cast(bf16x8_t, pk);
+        }
+        if (rb == 0) {                                             // the wave's weight pieces (requested once) have landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        f32x4_t acc[NFRAG];
+#pragma unroll
+        for (int f = 0; f < NFRAG; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const int slot = (p2 * 4 + kq) ^ (r16 & 7);
+#pragma unroll
+                for (int f = 0; f < NFRAG; ++f) {
+                    const bf16x8_t fw = *reinterpret_cast<const bf16x8_t*>(stage + kt * WT_BYTES + (f * 16 + r16) * 128 + slot * 16);
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fx[kt * 2 + p2], acc[f], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < NFRAG; ++f) red[(w * NFRAG + f) * 64 + lane] = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
+        ssq += __shfl_xor(ssq, 16, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (lane < 16) ssq_s[w * 16 + lane] = ssq;
+        __syncthreads();
+        float s = 0.f;
+        for (int ww = 0; ww < NW; ++ww) s += ssq_s[ww * 16 + r16];
+        const float rs = a.alpha * rsqrtf(s / (float)a.K + a.eps);
+        const int m = rb * 16 + r16;
+        for (int f = w; f < NFRAG; f += NW) {
+            float4 v = red[f * 64 + lane];
+            for (int ww = 1; ww < NW; ++ww) {
+                const float4 o = red[(ww * NFRAG + f) * 64 + lane];
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
+            const int n0 = n_tile + f * 16 + kq * 4;
+            const bool ok = m < a.rows && n0 < a.N;
+            if (ok && a.out_f) dl_store16f(a.out_f + (size_t)m * a.ldf + n0, v);
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+            if (ok) {
+                best = v.x; bi = n0;
+                if (v.y > best) { best = v.y; bi = n0 + 1; }
+                if (v.z > best) { best = v.z; bi = n0 + 2; }
+                if (v.w > best) { best = v.w; bi = n0 + 3; }
+            }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ov = __shfl_xor(best, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (lane < 16) { amax_s[f * 16 + lane] = best; aidx_s[f * 16 + lane] = bi; }
+        }
+        __syncthreads();
+        if (a.pmax && threadIdx.x < 16 && rb * 16 + (int)threadIdx.x < a.rows) {
+            float best = amax_s[threadIdx.x];
+            int bi = aidx_s[threadIdx.x];
+#pragma unroll
+            for (int f = 1; f < NFRAG; ++f) {
+                const float ov = amax_s[f * 16 + threadIdx.x];
+                const int oi = aidx_s[f * 16 + threadIdx.x];
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            const size_t slot = (size_t)(rb * 16 + threadIdx.x) * a.CT + ct;
+            a.pmax[slot] = best;
+            a.pidx[slot] = bi;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KT * 2; ++ks) { xa[ks][0] = xn[ks][0]; xa[ks][1] = xn[ks][1]; }
+    }
+}
+
 typedef void (*declin_fn)(const DecLinArgs);
 template <bool AF32, int KT>
 declin_fn declin_pick_nfrag(int nfrag) {
@@ -488,6 +621,20 @@ int vlt5_declin_launch(DecLinArgs a, hipStream_t st) {
     declin_fn fn = af32 ? declin_pick<true>(kt, nfrag) : declin_pick<false>(kt, nfrag);
     if (!fn) return VLT5_ERR_ARG;
     if (a.pmax && a.ptiles != a.CT) return VLT5_ERR_ARG;
+    // the row-walking form for a wide norm-folded projection without a bf16 output (the vocabulary projection): the weight slice is
+    // staged once per column tile
+    if (af32 && nfrag == 4 && a.RB > 1 && a.CT >= 256 && a.K == 64 * kt * nw && !a.out_b && !a.resid && !a.relu && (kt == 3 || kt == 4)) {
+        const size_t lds_r = declin_lds_bytes(true, kt, 4, nw);
+        static std::atomic<unsigned long long> optin_r[2];
+        declin_fn fr = kt == 3 ? &declin_rows_kernel<3, 4> : &declin_rows_kernel<4, 4>;
+        if (lds_r > 64 * 1024) {
+            const int rc = vlt5_lds_optin((const void*)fr, 160 * 1024, optin_r[kt - 3]);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(fr, dim3(a.CT), dim3(nw * 64), lds_r, st, a);
+        LAUNCH_CHECK();
+        return VLT5_OK;
+    }
     const size_t lds = declin_lds_bytes(af32, kt, nfrag, nw);
     static std::atomic<unsigned long long> optin[2][4][4];          // per instantiation: devices with the large-LDS attribute set
     if (lds > 64 * 1024) {
