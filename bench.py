@@ -363,7 +363,7 @@ def parity_vs_oracle(model, dev, B):
         res["logits_rel_max_err"] = round(res["logits_rel_max_err"], 5)
         res["loss_tok_abs_err"] = round(res["loss_tok_abs_err"], 5)
         res["loss_abs_err"] = round(res["loss_abs_err"], 6)
-        res["tolerance"] = "logits 3e-2 rel, loss 2e-2 abs, grad cos >= 0.99, indices exact where the top-2 margin > 1e-2"
+        res["tolerance"] = "logits 1e-2 rel, per-token loss 2e-2 abs, reduced loss 1e-2 abs, grad cos >= 0.99, indices exact where the top-2 margin > 1e-2 (tests/test_gpu_model.py::test_benched_shape_b80_against_the_oracle)"
         return res
     finally:
         for p in model.parameters():

@@ -283,6 +283,8 @@ def test_decode_kernels_against_the_tiled_path_at_base_size(dev, B):
     from test_gpu_model import parity_log
     parity_log(f"decode kernels vs tiled path (base, B={B}, {T} steps): logits rel max err {worst:.4g}, {checked} of {B * T} margin-gated "
                f"next-token ids equal")
+    from test_gpu_model import check_pin
+    check_pin(f"decode kernels vs tiled path B={B}/logits", worst, "logits")
     assert checked > 0
 
 

@@ -1,11 +1,16 @@
 """GPU parity tests of the whole path: VLT5VQA.train_step (forward, backward, optimizer) on the HIP engine against
 the CPU oracle and the committed golden fixture, through the drop-in boundary the reference's Trainer uses.
 
-Tolerances (bf16 compute with fp32 accumulation against an fp32 oracle):
-  logits ....... max |err| <= 3e-2 * max |logits|  (BASELINE north_star: "answer-token logits within stated fp tol")
-  loss ......... 2e-2 absolute
-  gradients .... cosine similarity >= 0.99 per tensor and norm ratio within 3 % (measured worst cases: profiles/rNN_parity.txt)
+Tolerances (bf16 compute with fp32 accumulation against an fp32 oracle; SURVEY 8(c): "bf16 path 2e-2 rel on logits / 1e-2 abs on loss"):
+  logits ....... max |err| <= 2e-2 * max |logits| everywhere, 1e-2 for the tiny and VL-T5-base configurations (observed worst case
+                 5e-3)  (BASELINE north_star: "answer-token logits within stated fp tol")
+  loss ......... 1e-2 absolute (reduced loss); per-token loss at the benched B = 80 shape 2e-2
+  gradients .... cosine similarity >= 0.99 per tensor and norm ratio within 3 % (5 % for the 48-layer t5-large)
   integer prototype indices: bit-exact whenever the oracle's top-2 cosine margin exceeds 1e-2
+  greedy tokens: bit-exact whenever the oracle's top-2 logit margin exceeds twice the logits tolerance
+On top of the fixed tolerances every headline figure is PINNED: profiles/r04_parity_pins.json holds the worst case observed when the
+round's kernels were committed, and a run whose figure exceeds twice its pin (or the noise floor below, whichever is larger) fails --
+a regression that triples an error no longer hides under a loose bound.  Measured worst cases of a run: profiles/rNN_parity.txt.
 """
 import copy
 
@@ -60,6 +65,25 @@ def margin_ok(protos, pooled, thr=1e-2):
     sim = (b @ a.t())
     top = sim.topk(2, dim=1).values
     return (top[:, 0] - top[:, 1]) > thr
+
+
+PIN_FLOOR = {"logits": 2e-3, "loss": 2e-3, "loss_tok": 4e-3}      # below these, differences are rounding-order noise of a kernel revision
+
+
+def check_pin(key, value, kind):
+    """Fail when `value` is more than twice the committed worst case of `key` (profiles/r04_parity_pins.json); unknown keys only log."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_parity_pins.json")
+    pins = json.load(open(path)) if os.path.exists(path) else {}
+    rec = os.environ.get("VQACL_PARITY_PINS_OUT")
+    if rec:                                   # recording mode: VQACL_PARITY_PINS_OUT=<file> pytest -m gpu  -> the new table
+        cur = json.load(open(rec)) if os.path.exists(rec) else {}
+        cur[key] = max(float(value), cur.get(key, 0.0))
+        json.dump(cur, open(rec, "w"), indent=1, sort_keys=True)
+    if key in pins:
+        bound = max(2.0 * pins[key], PIN_FLOOR[kind])
+        assert value <= bound, f"{key}: {value:.4g} is more than twice the pinned worst case {pins[key]:.4g} (bound {bound:.4g})"
 
 
 def parity_log(line):
@@ -169,11 +193,16 @@ def test_tiny_model_against_golden_fixture(dev, tuning=None):
         B, T = batch["target_ids"].shape
         logits = model._ws_view(model.cfg.c_struct(), (B, batch["input_ids"].shape[1], 36, T), 2, torch.float32,
                                 (B, T, ocfg.vocab_size))
-        assert rel_max_err(logits, G[f"s{step}_logits"]) < 3e-2, f"logits step {step}"
-        assert abs(float(res["loss"]) - float(G[f"s{step}_loss"])) < 2e-2, f"loss step {step}"
-        assert rel_max_err(res["encoder_hidden_states"], G[f"s{step}_enc"]) < 3e-2, f"encoder output step {step}"
-        assert rel_max_err(model.Q_prototype, G[f"s{step}_Qproto"]) < 3e-2
-        assert rel_max_err(model.V_prototype, G[f"s{step}_Vproto"]) < 3e-2
+        e, le = rel_max_err(logits, G[f"s{step}_logits"]), abs(float(res["loss"]) - float(G[f"s{step}_loss"]))
+        assert e < 1e-2, f"logits step {step}"
+        assert le < 1e-2, f"loss step {step}"
+        if not tuning:
+            check_pin(f"tiny fixture step {step}/logits", e, "logits")
+            check_pin(f"tiny fixture step {step}/loss", le, "loss")
+            parity_log(f"tiny fixture step {step}: logits rel max err {e:.4g}, loss err {le:.3g}")
+        assert rel_max_err(res["encoder_hidden_states"], G[f"s{step}_enc"]) < 2e-2, f"encoder output step {step}"
+        assert rel_max_err(model.Q_prototype, G[f"s{step}_Qproto"]) < 2e-2
+        assert rel_max_err(model.V_prototype, G[f"s{step}_Vproto"]) < 2e-2
         if step == 0:
             res["loss"].backward()
             worst = check_grads(model, un(G, "s0_g__"))
@@ -231,9 +260,12 @@ def test_base_model_forward_backward_vs_oracle(dev, tuning=None):
     logits = model._ws_view(model.cfg.c_struct(), (B, 20, 36, T), 2, torch.float32, (B, T, ocfg.vocab_size))
     e = rel_max_err(logits, o["logits"])
     print("base logits rel max err", e, "loss", float(res["loss"]), float(o["loss"]))
-    assert e < 3e-2
-    assert abs(float(res["loss"]) - float(o["loss"])) < 2e-2
-    assert rel_max_err(res["encoder_hidden_states"], o["encoder_hidden_states"]) < 3e-2
+    assert e < 1e-2
+    assert abs(float(res["loss"]) - float(o["loss"])) < 1e-2
+    assert rel_max_err(res["encoder_hidden_states"], o["encoder_hidden_states"]) < 2e-2
+    if not tuning:
+        check_pin("base B=4/logits", e, "logits")
+        check_pin("base B=4/loss", abs(float(res["loss"]) - float(o["loss"])), "loss")
     worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()})
     parity_log(f"base B=4: logits rel max err {e:.4g}, loss err {abs(float(res['loss']) - float(o['loss'])):.3g}, "
                f"worst gradient cosine {worst[0]:.5f} ({worst[1]})")
@@ -263,7 +295,8 @@ def test_gated_gelu_model_vs_oracle(dev):
     B, T = batch["target_ids"].shape
     logits = model._ws_view(model.cfg.c_struct(), (B, 13, 36, T), 2, torch.float32, (B, T, ocfg.vocab_size))
     e = rel_max_err(logits, o["logits"])
-    assert e < 3e-2 and abs(float(res["loss"]) - float(o["loss"])) < 2e-2
+    assert e < 1e-2 and abs(float(res["loss"]) - float(o["loss"])) < 1e-2
+    check_pin("gated-gelu tiny/logits", e, "logits")
     worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()})
     parity_log(f"gated-gelu tiny: logits rel max err {e:.4g}, loss err {abs(float(res['loss']) - float(o['loss'])):.3g}, "
                f"worst gradient cosine {worst[0]:.5f} ({worst[1]})")
@@ -281,7 +314,7 @@ def test_gated_gelu_model_vs_oracle(dev):
     tok = model.test_step(batch, max_length=5)["token_ids"]
     st = R.PrototypeState(Q_prototype=model.Q_prototype.cpu().clone(), V_prototype=model.V_prototype.cpu().clone())
     ref_tok, margins = oracle_greedy(R, dict(params), st, ocfg, batch, 4)
-    check_greedy_tokens(tok, ref_tok, margins, 6e-2, what="gated-gelu greedy decode")
+    check_greedy_tokens(tok, ref_tok, margins, 2e-2, what="gated-gelu greedy decode")
 
 
 def test_second_step_and_rehearsal_batch_shapes(dev):
@@ -296,7 +329,7 @@ def test_second_step_and_rehearsal_batch_shapes(dev):
         batch = R.synthetic_batch(ocfg, B=B, L=L, V=36 if i != 3 else 16, T=T, seed=50 + i, task_id=task)
         res = model.train_step(batch, task, 0.5, 0.3)
         o = oracle.train_step(batch, task, 0.5, 0.3)
-        assert abs(float(res["loss"]) - float(o["loss"])) < 3e-2, (i, float(res["loss"]), float(o["loss"]))
+        assert abs(float(res["loss"]) - float(o["loss"])) < 1e-2, (i, float(res["loss"]), float(o["loss"]))
         assert res["BL"] == (B, T)
         assert tuple(res["encoder_attention_mask"].shape) == (B, L + (36 if i != 3 else 16) + 2)
         assert torch.equal(res["encoder_attention_mask"].cpu(), o["encoder_attention_mask"])
@@ -474,11 +507,11 @@ def test_state_dict_roundtrip_and_greedy_decode(dev):
     tok = out["token_ids"]
     assert tok.shape[0] == 4 and tok.shape[1] <= 6 and int(tok[:, 0].abs().sum()) == 0
     # oracle greedy decoding with the same prototypes; integer outputs: exact wherever the oracle's top-2 logit margin exceeds
-    # twice the stated logits tolerance (2 x 3e-2 of max |logits|)
+    # twice the stated logits tolerance (2 x 1e-2 of max |logits| for this configuration)
     st = R.PrototypeState(Q_prototype=model.Q_prototype.cpu().clone(), V_prototype=model.V_prototype.cpu().clone())
     P = {k: v for k, v in params.items()}
     ref_tok, margins = oracle_greedy(R, P, st, ocfg, batch, 11)
-    checked, cut = check_greedy_tokens(tok, ref_tok, margins, 6e-2, what="test_step vs oracle")
+    checked, cut = check_greedy_tokens(tok, ref_tok, margins, 2e-2, what="test_step vs oracle")
     parity_log(f"greedy decode (tiny, test_step): {checked} tokens bit-exact under the top-2 margin rule, {cut} rows left the band")
     assert checked >= 3
     # the key/value-cached incremental decoder (default) against re-decoding the growing prefix with the training kernels, and
@@ -489,8 +522,8 @@ def test_state_dict_roundtrip_and_greedy_decode(dev):
         a = model.greedy_generate(batch["input_ids"], fb, max_length=mlen)
         b = model.greedy_generate(batch["input_ids"], fb, max_length=mlen, use_cache=False)
         assert a.shape[1] <= mlen and b.shape[1] <= mlen
-        ca, _ = check_greedy_tokens(a, ref_tok, margins, 6e-2, what=f"cached decode, max_length {mlen}")
-        cb, _ = check_greedy_tokens(b, ref_tok, margins, 6e-2, what=f"recomputed decode, max_length {mlen}")
+        ca, _ = check_greedy_tokens(a, ref_tok, margins, 2e-2, what=f"cached decode, max_length {mlen}")
+        cb, _ = check_greedy_tokens(b, ref_tok, margins, 2e-2, what=f"recomputed decode, max_length {mlen}")
         parity_log(f"greedy decode (tiny, max_length {mlen}): cached {ca} / recomputed {cb} tokens bit-exact under the margin rule")
     # generation arguments the engine does not implement are refused, not dropped (vqa_model.py:112-116 forwards **kwargs)
     from vqacl_amd._lib import Vlt5Error
@@ -530,7 +563,7 @@ def test_output_record_fields_are_owned_and_complete(dev):
     o = R.vlt5_forward(params, st, ocfg, input_ids=b1["input_ids"], vis_feats=b1["vis_feats"], boxes=b1["boxes"],
                        labels=b1["target_ids"], proto_update=False, training=False)
     # the oracle reports the rescaled state: undo the d_model^-0.5
-    assert rel_max_err(out.decoder_last_hidden_state, o["decoder_last_hidden_state"] * ocfg.d_model ** 0.5) < 3e-2
+    assert rel_max_err(out.decoder_last_hidden_state, o["decoder_last_hidden_state"] * ocfg.d_model ** 0.5) < 2e-2
     # train_step hands on owned tensors too
     model.train()
     r1 = model.train_step(b1, 0, 0.5, 0.3)
@@ -569,12 +602,12 @@ def test_loading_weights_after_an_optimizer_step_refreshes_the_bf16_shadow(dev, 
                     proto_update=False)
         return rel_max_err(out["logits"], o["logits"])
     model.eval()
-    assert fwd_err(pb) < 3e-2, "forward after load_checkpoint must use the loaded weights"
+    assert fwd_err(pb) < 1e-2, "forward after load_checkpoint must use the loaded weights"
     # a direct in-place write through a parameter is picked up as well
     with torch.no_grad():
         for k, v in pa.items():
             dict(model.named_parameters())[k].copy_(v) if k in dict(model.named_parameters()) else None
-    assert fwd_err(pa) < 3e-2
+    assert fwd_err(pa) < 1e-2
 
 
 @pytest.mark.parametrize("fast", [True, False], ids=["decode-kernels", "tiled-path"])
@@ -627,7 +660,8 @@ def test_incremental_decoder_step_matches_full_decoder_logits(dev, fast):
             tok = dec_in[:, t].contiguous()
             check(lib().vlt5_decoder_step(C.byref(c), C.byref(cs), ptr(tok), t, ptr(cache), ptr(logits), ptr(nxt), stream_ptr()))
             err = rel_max_err(logits, ref_logits[:, t])
-            assert err < 3e-2, (t, err)
+            assert err < 1e-2, (t, err)
+            check_pin(f"incremental step ({'decode kernels' if fast else 'tiled path'})/logits", err, "logits")
             assert torch.equal(nxt, logits.argmax(dim=-1)), "argmax kernel == torch.argmax (first maximum)"
     # argument checks: training state, position beyond the cache
     st["training"] = True
@@ -756,8 +790,10 @@ def test_other_baseline_configs_vs_oracle(dev, name, kw, B, L, V, T):
     logits = model._ws_view(model.cfg.c_struct(), (B, L, V, T), 2, torch.float32, (B, T, ocfg.vocab_size))
     e = rel_max_err(logits, o["logits"])
     print(name, "logits rel max err", e, "loss", float(res["loss"]), float(o["loss"]))
-    assert e < 4e-2
-    assert abs(float(res["loss"]) - float(o["loss"])) < 3e-2
+    assert e < 2e-2
+    assert abs(float(res["loss"]) - float(o["loss"])) < 1e-2
+    check_pin(f"{name}/logits", e, "logits")
+    check_pin(f"{name}/loss", abs(float(res["loss"]) - float(o["loss"])), "loss")
     # (t5-large at B = 2: 48 layers deep on 10 answer rows -- the smallest gradient tensors sit at 2-3 % norm deviation with or
     # without the folded norms, profiles/r03_b_parity.txt)
     worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()}, norm_tol=0.05 if name == "t5-large" else 0.03)
@@ -899,8 +935,10 @@ def test_benched_shape_b80_against_the_oracle(dev):
                        labels=sub["target_ids"], proto_update=False, training=False)
     e = rel_max_err(logits, o["logits"].detach())
     le = float((loss_tok.flatten() - o["loss"].detach()).abs().max())
-    assert e < 3e-2 and le < 3e-2, (e, le)
-    assert rel_max_err(out["encoder_hidden_states"][pick], o["encoder_hidden_states"].detach()) < 3e-2
+    assert e < 1e-2 and le < 2e-2, (e, le)
+    check_pin("base B=80/logits", e, "logits")
+    check_pin("base B=80/per-token loss", le, "loss_tok")
+    assert rel_max_err(out["encoder_hidden_states"][pick], o["encoder_hidden_states"].detach()) < 2e-2
     h = o["encoder_hidden_states"].detach()
     gated = exact = 0
     for protos, pooled, mine, ref in ((oracle.state.Q_prototype, h[:, :20].mean(1), idx[0], o["max_idx_Q"]),
@@ -914,7 +952,7 @@ def test_benched_shape_b80_against_the_oracle(dev):
     res["loss_reduced"].backward()
     lo = R.train_step_loss(o["loss"], sub["target_ids"], sub["scores"])
     lo.backward()
-    assert abs(float(res["loss_reduced"]) - float(lo)) < 2e-2
+    assert abs(float(res["loss_reduced"]) - float(lo)) < 1e-2
     worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()})
     parity_log(f"base B=80 (benched shape, samples {pick}): logits rel max err {e:.4g}, per-token loss err {le:.3g}, prototype indices "
                f"{exact} of {gated} margin-gated equal; B=4 gradients worst cosine {worst[0]:.5f} ({worst[1]})")
@@ -1098,8 +1136,8 @@ def test_extreme_batch_shapes_vs_oracle(dev, B, L, V, T):
     o["loss"].backward()
     res = model.train_step(batch, 0, 0.5, 0.3)
     res["loss"].backward()
-    assert abs(float(res["loss"].detach()) - float(o["loss"].detach())) < 2e-2
-    assert rel_max_err(res["encoder_hidden_states"], o["encoder_hidden_states"]) < 3e-2
+    assert abs(float(res["loss"].detach()) - float(o["loss"].detach())) < 1e-2
+    assert rel_max_err(res["encoder_hidden_states"], o["encoder_hidden_states"]) < 2e-2
     check_grads(model, {k: p.grad for k, p in oracle.P.items()})
 
 
@@ -1134,7 +1172,7 @@ def test_degenerate_rows_vs_oracle(dev):
     o["loss"].backward()
     res = model.train_step(batch, 0, 0.5, 0.3)
     res["loss"].backward()
-    assert torch.isfinite(o["loss"].detach()) and abs(float(res["loss"].detach()) - float(o["loss"].detach())) < 2e-2
+    assert torch.isfinite(o["loss"].detach()) and abs(float(res["loss"].detach()) - float(o["loss"].detach())) < 1e-2
     check_grads(model, {k: p.grad for k, p in oracle.P.items()})
 
 
