@@ -241,6 +241,53 @@ typedef struct {
 long long vlt5_enc_attn_bwd_workspace_bytes(int B, int S, int H, int d_model);
 int vlt5_enc_attn_bwd(const vlt5_enc_attn_desc* d, const vlt5_enc_attn_grads* g, void* workspace, void* stream);
 
+/* backward of the two decoder attention sublayers above (autograd's backward of HF T5Attention inside T5LayerSelfAttention /
+ * T5LayerCrossAttention, src/vqacl.py:461), from what the forward left: xn_bf16, proj_bf16, core.ctx, core.lse (core.k / core.v for the
+ * cross sublayer).  d_out f32 [B*Tq, d_model]: gradient of the sublayer output in front of the residual (= of the sum of the H slabs;
+ * the output dropout belongs to the caller, like the slab sum).  Outputs: d_xn f32 [B*Tq, d_model] (gradient of the normalised input),
+ * d_w f32 (shape of w_bf16), d_wo f32 [d_model, H*d_kv], d_proj bf16 (shape of proj_bf16: the gradient of q | k | v, or of q), cross: dk / dv
+ * bf16 gradients of the encoder-side keys / values with sample / token strides dkv_sb / dkv_st; d_scores (optional) as for vlt5_attn_bwd.
+ * workspace: vlt5_dec_attn_bwd_workspace_bytes(...) bytes. */
+typedef struct {
+    const float* d_out; float* d_xn; float* d_w; float* d_wo; void* d_proj;
+    void* dk; void* dv; long long dkv_sb, dkv_st;
+    float* d_scores;
+} vlt5_dec_attn_grads;
+long long vlt5_dec_attn_bwd_workspace_bytes(int B, int Tq, int H, int d_kv, int d_model);
+int vlt5_dec_self_attn_bwd(const vlt5_dec_attn_desc* d, const vlt5_dec_attn_grads* g, void* workspace, void* stream);
+int vlt5_cross_attn_bwd(const vlt5_dec_attn_desc* d, const vlt5_dec_attn_grads* g, void* workspace, void* stream);
+
+/* ---- feed-forward sublayer: x_out = x + dropout(wo(dropout(act(wi(LN(x)))))) -- HF T5LayerFF.forward with T5DenseReluDense (ReLU) or,
+ * gated = 1, T5DenseGatedGeluDense (gelu_new(wi_0 x) * wi_1 x; wi_bf16 = [wi_0; wi_1] rows), as called from the encoder / decoder T5Blocks
+ * (src/modeling_t5_our.py:282-293, 641-655).  xn / rstd / h (and u for the gated form) are left for the backward. */
+typedef struct {
+    const float* x; const float* ln_w;            /* f32 [M, d_model], [d_model] */
+    const void* wi_bf16; const void* wo_bf16;     /* bf16 [d_ff (gated: 2*d_ff), d_model], [d_model, d_ff] */
+    float* x_out;                                 /* f32 [M, d_model] */
+    void* xn_bf16; float* rstd; void* h_bf16; void* u_bf16;     /* saved: [M,d_model], [M], [M,d_ff], gated: [M,2*d_ff] */
+    int M, d_model, d_ff, gated; float eps;
+    float drop_p; uint32_t seed_hidden, seed_out; /* dropout on the hidden activation / on the sublayer output */
+    const vlt5_tuning* tuning;
+} vlt5_ffn_desc;
+typedef struct { const float* dy; float* dx; float* d_wi; float* d_wo; float* d_ln_w; } vlt5_ffn_grads;   /* dx may alias dy; weight grads overwritten */
+int vlt5_ffn_fwd(const vlt5_ffn_desc* d, void* stream);
+long long vlt5_ffn_bwd_workspace_bytes(int M, int d_model, int d_ff, int gated);
+int vlt5_ffn_bwd(const vlt5_ffn_desc* d, const vlt5_ffn_grads* g, void* workspace, void* stream);
+
+/* ---- rescale + tied lm_head + cross-entropy (src/modeling_t5_our.py:661-686): logits = (x * d_model^-0.5) E^T,
+ * loss_tok = CrossEntropyLoss(ignore_index=-100, reduction='none'); backward: dlogits (bf16 scratch [rows, vocab]), d_x f32 [rows, d_model],
+ * d_emb f32 [vocab, d_model] (accum_d_emb = 1: added to, the embedding gathers contribute to the same tied tensor). */
+typedef struct {
+    const void* x_bf16; const void* emb_bf16;     /* bf16 [rows, d_model] decoder output, [vocab, d_model] shared embedding */
+    const long long* labels;                      /* [rows], -100 = ignore */
+    float* logits; float* loss_tok; float* lse;   /* out: f32 [rows, vocab], [rows], [rows] */
+    int rows, d_model, vocab;
+    const vlt5_tuning* tuning;
+} vlt5_lmhead_ce_desc;
+typedef struct { const float* d_loss_tok; void* dlogits_bf16; float* d_x; float* d_emb; int accum_d_emb; } vlt5_lmhead_ce_grads;
+int vlt5_lmhead_ce_fwd(const vlt5_lmhead_ce_desc* d, void* stream);
+int vlt5_lmhead_ce_bwd(const vlt5_lmhead_ce_desc* d, const vlt5_lmhead_ce_grads* g, void* stream);
+
 /* ---- relative position bias: HF T5Attention.compute_bias / _relative_position_bucket ---------
  * The integer bucket table lut[Lq*Lk] is computed on the host (vqacl_amd/buckets.py, bit-exact
  * with the library); the kernel gathers table[lut[i,j], h] into bias[h,i,j]. */

@@ -34,9 +34,11 @@ def test_struct_sizes_match_the_c_side(built, tmp_path):
     import subprocess
     src = tmp_path / "sz.c"
     names = ["vlt5_gemm_desc", "vlt5_attn_desc", "vlt5_config", "vlt5_step", "vlt5_enc_attn_desc", "vlt5_tuning", "vlt5_greedy_desc",
-             "vlt5_decode_linear_desc", "vlt5_dec_attn_desc", "vlt5_stack_inputs_desc", "vlt5_proto_head_desc"]
+             "vlt5_decode_linear_desc", "vlt5_dec_attn_desc", "vlt5_stack_inputs_desc", "vlt5_proto_head_desc", "vlt5_dec_attn_grads",
+             "vlt5_ffn_desc", "vlt5_ffn_grads", "vlt5_lmhead_ce_desc", "vlt5_lmhead_ce_grads"]
     mirrors = [built.GemmDesc, built.AttnDesc, built.Config, built.Step, built.EncAttnDesc, built.Tuning, built.GreedyDesc,
-               built.DecodeLinearDesc, built.DecAttnDesc, built.StackInputsDesc, built.ProtoHeadDesc]
+               built.DecodeLinearDesc, built.DecAttnDesc, built.StackInputsDesc, built.ProtoHeadDesc, built.DecAttnGrads, built.FfnDesc,
+               built.FfnGrads, built.LmheadCeDesc, built.LmheadCeGrads]
     src.write_text('#include <stdio.h>\n#include "vlt5_hip.h"\nint main(){printf("' + " ".join(["%zu"] * len(names)) + '\\n", '
                    + ", ".join(f"sizeof({n})" for n in names) + ');return 0;}\n')
     exe = tmp_path / "sz"

@@ -133,6 +133,30 @@ class Step(C.Structure):
                 ("gnorm_partials", vp), ("defer_decoder_wgrads", c_i), ("tuning", C.POINTER(Tuning))]
 
 
+class DecAttnGrads(C.Structure):
+    _fields_ = [("d_out", vp), ("d_xn", vp), ("d_w", vp), ("d_wo", vp), ("d_proj", vp), ("dk", vp), ("dv", vp), ("dkv_sb", c_ll),
+                ("dkv_st", c_ll), ("d_scores", vp)]
+
+
+class FfnDesc(C.Structure):
+    _fields_ = [("x", vp), ("ln_w", vp), ("wi_bf16", vp), ("wo_bf16", vp), ("x_out", vp), ("xn_bf16", vp), ("rstd", vp), ("h_bf16", vp),
+                ("u_bf16", vp), ("M", c_i), ("d_model", c_i), ("d_ff", c_i), ("gated", c_i), ("eps", c_f), ("drop_p", c_f),
+                ("seed_hidden", c_u32), ("seed_out", c_u32), ("tuning", C.POINTER(Tuning))]
+
+
+class FfnGrads(C.Structure):
+    _fields_ = [("dy", vp), ("dx", vp), ("d_wi", vp), ("d_wo", vp), ("d_ln_w", vp)]
+
+
+class LmheadCeDesc(C.Structure):
+    _fields_ = [("x_bf16", vp), ("emb_bf16", vp), ("labels", vp), ("logits", vp), ("loss_tok", vp), ("lse", vp), ("rows", c_i),
+                ("d_model", c_i), ("vocab", c_i), ("tuning", C.POINTER(Tuning))]
+
+
+class LmheadCeGrads(C.Structure):
+    _fields_ = [("d_loss_tok", vp), ("dlogits_bf16", vp), ("d_x", vp), ("d_emb", vp), ("accum_d_emb", c_i)]
+
+
 class GreedyDesc(C.Structure):
     _fields_ = [("tokens", vp), ("t", c_i), ("kv_cache", vp), ("logits", vp), ("next_ids", vp), ("out_tokens", vp), ("out_ld", c_ll),
                 ("done", vp), ("eos_id", c_i), ("pad_id", c_i)]
@@ -173,6 +197,14 @@ PROTOTYPES = {
     "vlt5_dec_self_attn_fwd": (c_i, [C.POINTER(DecAttnDesc), vp]),
     "vlt5_cross_attn_fwd": (c_i, [C.POINTER(DecAttnDesc), vp]),
     "vlt5_dec_attn_fused_ok": (c_i, [c_i, c_i, c_i, c_i]),
+    "vlt5_dec_attn_bwd_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i, c_i]),
+    "vlt5_dec_self_attn_bwd": (c_i, [C.POINTER(DecAttnDesc), C.POINTER(DecAttnGrads), vp, vp]),
+    "vlt5_cross_attn_bwd": (c_i, [C.POINTER(DecAttnDesc), C.POINTER(DecAttnGrads), vp, vp]),
+    "vlt5_ffn_fwd": (c_i, [C.POINTER(FfnDesc), vp]),
+    "vlt5_ffn_bwd_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i]),
+    "vlt5_ffn_bwd": (c_i, [C.POINTER(FfnDesc), C.POINTER(FfnGrads), vp, vp]),
+    "vlt5_lmhead_ce_fwd": (c_i, [C.POINTER(LmheadCeDesc), vp]),
+    "vlt5_lmhead_ce_bwd": (c_i, [C.POINTER(LmheadCeDesc), C.POINTER(LmheadCeGrads), vp]),
     "vlt5_enc_attn_fwd": (c_i, [C.POINTER(EncAttnDesc), vp]),
     "vlt5_enc_attn_bwd_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i]),
     "vlt5_enc_attn_bwd": (c_i, [C.POINTER(EncAttnDesc), C.POINTER(EncAttnGrads), vp, vp]),
