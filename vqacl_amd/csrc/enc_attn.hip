@@ -54,6 +54,10 @@ struct FusedGeo {
     static constexpr int A_BYTES = FBM * BK * 2, B_BYTES = FBN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;   // 16 + 48 (24) KB
     static constexpr int PA = FBM * 8 / FNT, PB = FBN * 8 / FNT, LPT = PA + PB;                             // DMA pieces per wave per k-tile
     static constexpr int FUSED_LDS = 2 * STAGE_BYTES;
+    // NH = 2 only (the CU's LDS is the workgroup's own): the score addends -- the relative-position bias blocks of the two heads and the
+    // key-mask rows of the two samples -- are staged behind the two stages by LDS-DMA in the prologue (64 gathers of one word per lane
+    // after the main loop cost 2.9 k cycles of load issue: profiles/r03_n_enc_attn_timeline.txt)
+    static constexpr int XTRA_BIAS = NH == 2 ? 16384 : 0, XTRA = NH == 2 ? XTRA_BIAS + 512 : 0;
     static_assert(6 * NH * TILE_BYTES <= FUSED_LDS, "the Q/K/V tiles of 2 samples x NH heads overlay the retired stages");
 };
 
@@ -167,6 +171,20 @@ __device__ __forceinline__ void qkv_attn_fwd_body(QkvAttnArgs p, unsigned long l
     for (int pc = 0; pc < LPT; ++pc) piece(0, 0, pc);
 #pragma unroll
     for (int pc = 0; pc < LPT; ++pc) piece(min(1, nk - 1), 1, pc);
+    // score addends into LDS (behind the stages): 64 words per piece, source clamped to the operand's last word; the first main-loop
+    // wait (vmcnt(0) + barrier) covers them for every wave
+    const int nbias = p.at.bias ? NH * p.at.bias_q * p.at.bias_k : 0;
+    const bool add_lds = G::XTRA > 0 && nbias * 4 <= G::XTRA_BIAS && p.at.Tk <= 64;
+    float* const bias_l = reinterpret_cast<float*>(smem + G::FUSED_LDS);
+    float* const mask_l = reinterpret_cast<float*>(smem + G::FUSED_LDS + G::XTRA_BIAS);                 // [2 samples][64]
+    if (add_lds) {
+        const float* bsrc = p.at.bias ? p.at.bias + (size_t)h0 * p.at.bias_q * p.at.bias_k : nullptr;
+        for (int c = wave; c * 64 < nbias; c += FNT / 64)
+            __builtin_amdgcn_global_load_lds(bsrc + min(c * 64 + lane, nbias - 1), (lds_ptr_t)(reinterpret_cast<char*>(bias_l) + c * 256), 4, 0, 0);
+        if (p.at.key_mask && wave < 2)
+            __builtin_amdgcn_global_load_lds(p.at.key_mask + (size_t)min(b0 + wave, p.B - 1) * p.at.Tk + min(lane, p.at.Tk - 1),
+                                             (lds_ptr_t)(reinterpret_cast<char*>(mask_l) + wave * 256), 4, 0, 0);
+    }
     stamp(1);
     float rs_own = 1.f;
     if (p.rs_part) {
@@ -200,8 +218,29 @@ __device__ __forceinline__ void qkv_attn_fwd_body(QkvAttnArgs p, unsigned long l
     // flight together) and combined after the hand-over, which hides their global round trip; kept out of the main loop, whose
     // register budget is full
     vlt5attn::AddendRaw raw[2];
+    if (!add_lds) {
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) vlt5attn::score_addend_load(p.at, cb, ch, (wave & 1) * 32 + blk * 16, lane, raw[blk]);
+        for (int blk = 0; blk < 2; ++blk) vlt5attn::score_addend_load(p.at, cb, ch, (wave & 1) * 32 + blk * 16, lane, raw[blk]);
+    } else {
+        // out of the LDS copies (same words, same arithmetic afterwards): the bias block of head ch and the mask row of sample cs.  Read
+        // BEFORE the hand-over barrier: the accumulator tiles overlay the stages only, the copies live behind them
+        const float* brow = bias_l + (size_t)chh * p.at.bias_q * p.at.bias_k;
+        const float* mrow = mask_l + cs * 64;
+        const bool hb = p.at.bias != nullptr, hm = p.at.key_mask != nullptr;
+        const int bk1 = hb ? p.at.bias_k - 1 : 0, mk1 = hm ? p.at.Tk - 1 : 0;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int i = (wave & 1) * 32 + blk * 16 + lrow;
+            const float* row = brow + (hb ? min(i, p.at.bias_q - 1) * p.at.bias_k : 0);
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    raw[blk].bv[jb][r] = row[min(jb * 16 + lg * 4 + r, bk1)];
+                    raw[blk].mv[jb][r] = mrow[min(jb * 16 + lg * 4 + r, mk1)];
+                }
+        }
+    }
     stamp(8);
     __syncthreads();
     stamp(9);
@@ -285,24 +324,24 @@ static int qkv_attn_dispatch(const QkvAttnArgs& a, KF kernel, KT kernel_tl, void
     using G = FusedGeo<NH>;
     static std::atomic<unsigned long long> optin_a{0}, optin_b{0};      // devices on which the kernels may use FUSED_LDS bytes of LDS
     {
-        int rc = vlt5_lds_optin(reinterpret_cast<const void*>(kernel), G::FUSED_LDS, optin_a);
+        int rc = vlt5_lds_optin(reinterpret_cast<const void*>(kernel), G::FUSED_LDS + G::XTRA, optin_a);
         if (rc) return rc;
-        rc = vlt5_lds_optin(reinterpret_cast<const void*>(kernel_tl), G::FUSED_LDS, optin_b);
+        rc = vlt5_lds_optin(reinterpret_cast<const void*>(kernel_tl), G::FUSED_LDS + G::XTRA, optin_b);
         if (rc) return rc;
     }
     const int inner = a.H * 64;
     const int grid = ((a.B + 1) / 2) * (a.H / NH);
     vlt5gemm::TimingState& tm = vlt5_gemm_timing_state;           // bench.py's in-situ roofline covers this MFMA kernel too
-    if (g_tl_buf) hipLaunchKernelGGL(kernel_tl, dim3(grid), dim3(G::FNT), G::FUSED_LDS, (hipStream_t)stream, a, g_tl_buf);
+    if (g_tl_buf) hipLaunchKernelGGL(kernel_tl, dim3(grid), dim3(G::FNT), G::FUSED_LDS + G::XTRA, (hipStream_t)stream, a, g_tl_buf);
     else if (tm.on && tm.rec.size() < tm.cap) {
         const size_t i = tm.rec.size();
         vlt5_gemm_timing_rec r;
         r.M = a.B * a.S; r.N = 3 * inner; r.K = a.d; r.batch = 1; r.tile_m = G::FBM; r.tile_n = 384; r.a_kmajor = 0; r.b_kmajor = 0;
         r.splits = 1; r.workgroups = grid; r.out_f32 = 0; r.ms = 0.f; r.M2 = 0; r.N2 = 0; r.K2 = 0; r.batch2 = 0;
         tm.rec.push_back(r);
-        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(G::FNT), G::FUSED_LDS, (hipStream_t)stream, tm.ev[2 * i], tm.ev[2 * i + 1], 0, a,
+        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(G::FNT), G::FUSED_LDS + G::XTRA, (hipStream_t)stream, tm.ev[2 * i], tm.ev[2 * i + 1], 0, a,
                               (unsigned long long*)nullptr);
-    } else hipLaunchKernelGGL(kernel, dim3(grid), dim3(G::FNT), G::FUSED_LDS, (hipStream_t)stream, a, (unsigned long long*)nullptr);
+    } else hipLaunchKernelGGL(kernel, dim3(grid), dim3(G::FNT), G::FUSED_LDS + G::XTRA, (hipStream_t)stream, a, (unsigned long long*)nullptr);
     LAUNCH_CHECK();
     return VLT5_OK;
 }
