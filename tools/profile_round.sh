@@ -17,6 +17,20 @@ python3 $ROOT/tools/rocpd_pmc.py $(find $OUT/${TAG}_pf -name "*.db" | head -1) $
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace -d $OUT/${TAG}_pm -o r -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-side-values > $OUT/${TAG}_pm.log 2>&1
 python3 $ROOT/tools/rocpd_counters.py $(find $OUT/${TAG}_pm -name "*.db" | head -1) --match _kernel > $OUT/${TAG}_pmc_mfma_util.txt
 cd $ROOT && python3 tools/gemm_sweep.py --graph --torch-ref > $OUT/${TAG}_gemm_tile_sweep.txt 2>&1
+# the greedy-decoding loop: throughput of the three paths, kernel stats and one token-step launch by launch
+python3 $ROOT/tools/decode_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_decode_bench.txt
+cd /tmp
+rocprofv3 --kernel-trace -d $OUT/${TAG}_dk -o r -- python3 $ROOT/tools/decode_bench.py --fast-only > $OUT/${TAG}_dk.log 2>&1
+DDB=$(find $OUT/${TAG}_dk -name "*.db" | head -1)
+python3 $ROOT/tools/rocpd_stats.py $DDB --steps 1 | grep -v "at::native" | head -24 > $OUT/${TAG}_decode_kernel_stats.txt
+python3 $ROOT/tools/rocpd_window.py $DDB dec_io_kernel -4 > $OUT/${TAG}_decode_step_timeline.txt
+# the data-parallel machinery on one GPU: the same bench through the rank launcher (RCCL, world size 1) and its kernel trace as a rank
+cd $ROOT
+python3 bench.py --gpus 1 --force-dist --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-side-values > $OUT/${TAG}_bench_line_force_dist.json 2> $OUT/${TAG}_force_dist.err
+cd /tmp
+WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 rocprofv3 --kernel-trace -d $OUT/${TAG}_dd -o r -- python3 $ROOT/bench.py --gpus 1 --force-dist --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-parity --no-side-values > $OUT/${TAG}_dd.log 2>&1
+python3 $ROOT/tools/rocpd_stats.py $(find $OUT/${TAG}_dd -name "*.db" | head -1) > $OUT/${TAG}_kernel_stats_force_dist.txt
+rm -rf $OUT/${TAG}_dk $OUT/${TAG}_dd
 # the raw rocpd databases are tens of MB each and gpurun only copies 64 MiB back: keep the summaries, drop the databases
 rm -rf $OUT/${TAG}_kt $OUT/${TAG}_pf $OUT/${TAG}_pw $OUT/${TAG}_pm
 ls -la $OUT | grep ${TAG}_ | head -30
