@@ -657,6 +657,27 @@ def main():
                        "achieved": round(gbytes / (us * 1e-6), 1), "peak": 8000.0, "unit": "GB/s",
                        "frac": round(gbytes / (us * 1e-6) / 8000.0, 4), "store_images": n_img,
                        "store_gb": round(n_img * V * (cfg.feat_dim * 2 + 16) / 1e9, 3)}
+        # greedy decoding of the same batch shape through test_step's path (key/value cache, decode kernels): the
+        # encoder + prototype retrieval + cross-K/V once, then one token per step; eos = -1 so that every row decodes the full length
+        def decode_ms(max_length, reps=3):
+            model.eval()
+            try:
+                for _ in range(2):
+                    model.greedy_generate(resident["input_ids"], (resident["vis_feats"], resident["boxes"]), max_length=max_length, eos_token_id=-1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    model.greedy_generate(resident["input_ids"], (resident["vis_feats"], resident["boxes"]), max_length=max_length, eos_token_id=-1)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / reps * 1e3
+            finally:
+                model.train()
+        t2, t20 = decode_ms(2), decode_ms(20)
+        out["decode"] = {"what": "VLT5VQA.greedy_generate (test_step), B = %d, 19 tokens per row, random weights" % B,
+                         "ms_per_batch": round(t20, 3), "ms_encoder_and_first_token": round(t2, 3),
+                         "ms_per_token_step": round((t20 - t2) / 18, 4), "tokens_per_sec": round(B * 19 / (t20 * 1e-3), 1),
+                         "weight_bytes_per_token_step": int(2 * (12 * 7077888 + 32200 * 768)),
+                         "weight_gb_per_s": round(2 * (12 * 7077888 + 32200 * 768) / ((t20 - t2) / 18 * 1e-3) / 1e9, 1)}
         if "roofline" in out:
             warm, warm_ms = time_gemms_warm(cfg, B, L, V, T, dev)
             out["roofline"]["frac_warm"] = round(warm / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)
