@@ -28,6 +28,23 @@
 #define DECLIN_WT 0                // 1: outputs written through the L2 (sc0 sc1) as the GEMM does; measured 1 % slower on these 245 KB
 #endif                             // outputs than plain stores (profiles/r04_d_ab_decode.txt), so plain is the default
 
+// Cache policy of the LDS-DMA / loads (aux 2 = nt).  Same-box A/B at B = 80 (profiles/r04_h_ab_decode_nt.txt): weight stream nt 0.575 against
+// 0.601 ms per token-step (a slice is used by the 5 row blocks of one XCD within microseconds and by nobody afterwards: it should not
+// displace the activations and the cache in L2); nt on the bf16 activation rows (re-read by all 48 column tiles) 0.611, on the keys /
+// values of the attention core 0.597 -- both left at the default policy.
+#ifndef DECLIN_W_AUX
+#define DECLIN_W_AUX 2
+#endif
+#ifndef DECLIN_X_AUX
+#define DECLIN_X_AUX 0
+#endif
+#ifndef DEC_CORE_NT
+#define DEC_CORE_NT 0
+#endif
+#ifndef DECLIN_ROWS_W_AUX
+#define DECLIN_ROWS_W_AUX DECLIN_W_AUX     // ... of the vocabulary projection (its weight is read once chip-wide)
+#endif
+
 #ifdef DECLIN_TIMELINE
 #define TLS(i) do { if (a.tl && threadIdx.x == 0) a.tl[(size_t)blockIdx.x * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
@@ -127,7 +144,7 @@ __global__ __launch_bounds__(512) void declin_kernel(const DecLinArgs a) {
                     int mr = rb * 16 + i * 8 + prow;
                     mr = mr < a.rows ? mr : a.rows - 1;
                     __builtin_amdgcn_global_load_lds(a.xb + (size_t)mr * a.ldx + k0 + kt * 64 + pchunk * 8,
-                                                     (dl_lds_ptr_t)(stage + KT * WT_BYTES + kt * XT_BYTES + i * 1024), 16, 0, 0);
+                                                     (dl_lds_ptr_t)(stage + KT * WT_BYTES + kt * XT_BYTES + i * 1024), 16, 0, DECLIN_X_AUX);
                 }
             }
 #pragma unroll
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(512) void declin_kernel(const DecLinArgs a) {
                 int n = n_tile + i * 8 + prow;
                 n = n < a.N ? n : a.N - 1;
                 __builtin_amdgcn_global_load_lds(a.W + (size_t)n * a.K + k0 + kt * 64 + pchunk * 8,
-                                                 (dl_lds_ptr_t)(stage + kt * WT_BYTES + i * 1024), 16, 0, 0);
+                                                 (dl_lds_ptr_t)(stage + kt * WT_BYTES + i * 1024), 16, 0, DECLIN_W_AUX);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(512) void declin_rows_kernel(const DecLinArgs a) {
         for (int i = 0; i < NFRAG * 2; ++i) {
             int n = n_tile + i * 8 + prow;
             n = n < a.N ? n : a.N - 1;
-            __builtin_amdgcn_global_load_lds(a.W + (size_t)n * a.K + k0 + kt * 64 + pchunk * 8, (dl_lds_ptr_t)(stage + kt * WT_BYTES + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(a.W + (size_t)n * a.K + k0 + kt * 64 + pchunk * 8, (dl_lds_ptr_t)(stage + kt * WT_BYTES + i * 1024), 16, 0, DECLIN_ROWS_W_AUX);
         }
     }
     float* strip = wst + w * 256;
@@ -424,6 +441,15 @@ static size_t declin_lds_bytes(bool af32, int kt, int nfrag, int nw) {
 // ------------------------------------------------------------------------------------------------------------------------------
 // attention core of one new token: one wave per (sample, head)
 // ------------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned dl_u32x4_t;
+__device__ __forceinline__ uint4 core_load16(const bf16_t* p) {
+#if DEC_CORE_NT
+    const dl_u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const dl_u32x4_t*>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
 template <int CH>        // CH = d_kv / 16 lanes share a key (16 dims each); 64 / CH keys per pass, CH passes cover 64 keys
 __global__ __launch_bounds__(256) void dec_core_kernel(const DecCoreArgs a) {
     constexpr int KSL = 64 / CH, LOGC = CH == 4 ? 2 : (CH == 2 ? 1 : 0);
@@ -444,10 +470,10 @@ __global__ __launch_bounds__(256) void dec_core_kernel(const DecCoreArgs a) {
     for (int p = 0; p < CH; ++p) {
         const int key = p * KSL + slot;
         const int kc = key < Tk ? key : 0;
-        kk[p][0] = *reinterpret_cast<const uint4*>(kb + (size_t)kc * a.kv_st);
-        kk[p][1] = *reinterpret_cast<const uint4*>(kb + (size_t)kc * a.kv_st + 8);
-        vv[p][0] = *reinterpret_cast<const uint4*>(vb + (size_t)kc * a.kv_st);
-        vv[p][1] = *reinterpret_cast<const uint4*>(vb + (size_t)kc * a.kv_st + 8);
+        kk[p][0] = core_load16(kb + (size_t)kc * a.kv_st);
+        kk[p][1] = core_load16(kb + (size_t)kc * a.kv_st + 8);
+        vv[p][0] = core_load16(vb + (size_t)kc * a.kv_st);
+        vv[p][1] = core_load16(vb + (size_t)kc * a.kv_st + 8);
         float ad = 0.f;
         if (a.bias) ad += a.bias[(size_t)h * a.bias_ld + kc];                                  // relative-position bias row of the step
         if (a.key_mask) ad += (1.0f - a.key_mask[(size_t)b * a.mask_ld + kc]) * a.mask_value;    // padded encoder-side keys
