@@ -21,4 +21,5 @@ for p in "${PASSES[@]}"; do
   i=$((i+1))
 done
 python3 tools/rocpd_counters.py $(find $OUT -name "*.db") --match gemm_kernel > gpurun_out/pmc_gemm.txt 2>&1
+rm -rf $OUT      # (the counter databases are large: gpurun copies at most 64 MiB back)
 cat gpurun_out/pmc_gemm.txt

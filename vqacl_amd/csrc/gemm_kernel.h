@@ -211,13 +211,41 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #ifndef GEMM_ASM_DMA
 #define GEMM_ASM_DMA 2                  // 0: builtin everywhere, 1: assembly everywhere, 2: assembly in kernels with a k-major operand
 #endif
+#ifndef GEMM_DMA_NT
+#define GEMM_DMA_NT 0                   // 1: nt cache policy on the operand stream (experiment)
+#endif
 template <bool ASM>
 __device__ __forceinline__ void lds_dma16(const bf16_t* src, char* dst_wave) {
     if constexpr (ASM) {
         const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)dst_wave);
+#if GEMM_DMA_NT
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(m0v), "v"(src));
+#else
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src));
+#endif
     } else {
-        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst_wave, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst_wave, 16, 0, GEMM_DMA_NT ? 2 : 0);
+    }
+}
+// Experiment switch (off): L2 prefetch of a k-tile that the ring has no stage for yet (GEMM_L2PF = its distance in k-tiles behind the
+// tile being requested).  Question: is the k-step (8-wave tiles 1.2-1.3 us whether 9 or 240 workgroups run, against ~1.0 us of MFMAs;
+// 3-stage tiles 0.52 us; profiles/r04_gemm_workgroup_timeline.txt) the latency of the stage's L2 MISSES (an L2 hit returns in ~300
+// cycles, TCP_TCC_READ_REQ_LATENCY / _REQ, 60-85 % of the requests hit)?  Each tile request is followed by ONE more LDS-DMA
+// instruction per wave that reads one word of every 128-byte line of a LATER tile (BM + BN lines: one per lane) into a scratch strip
+// behind the stages; it counts in vmcnt like a piece, issued last, and "tile landed" waits leave it outstanding.  Answer: no --
+// same-box A/B (profiles/r04_i_gemm_l2_prefetch.txt) 8.76 ms per step without, 9.45 / 9.65 / 9.90 ms at distance 1 / 2 / 3; the
+// warm 256 x 256 k-step stays 1.23 us, the 3-stage tiles go 0.55 -> 0.70 us.  The k-step is issue-side work (the LDS + MFMA step
+// alone measures 2357 cycles, tools/mfma_shape_probe.hip), and 64 more cache lines per wave and step are that much more of it.
+#ifndef GEMM_L2PF
+#define GEMM_L2PF 0
+#endif
+template <bool ASM>
+__device__ __forceinline__ void lds_dma4(const void* src, char* dst_wave) {
+    if constexpr (ASM) {
+        const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)dst_wave);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(src));
+    } else {
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst_wave, 4, 0, 0);
     }
 }
 template <int R, int NT, bool ASM = false>
@@ -398,11 +426,38 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
         if (BKM) lstore_km<BN, NT>(bt, rb, tid); else lstore_rm<BN, NT>(bt, rb, tid);
     };
 
+    // L2 prefetch (GEMM_L2PF, see lds_dma4): lane -> one line of the A tile (lanes < BM) or of the B tile; the line of k-tile kt0,
+    // advanced by pf_step bytes per k-tile.  k-tiles past the last full one re-request the last (the waits count on one per request).
+    static_assert(BM + BN <= NT, "one line per lane");
+    constexpr int PF = GEMM_L2PF ? 1 : 0, VPT = LPT + PF;          // vmcnt units of the prefetch / of a whole tile request
+    const char* pf_base = nullptr;
+    long long pf_step = 0;
+    const int pf_last = kt1 - 1 - (((kt1 == nk_total) && (p.K % BK != 0)) ? 1 : 0) - kt0;      // index of the last full k-tile of this workgroup
+    if constexpr (PF) {
+        const bool isa = tid < BM;
+        const int r = isa ? tid : min(tid - BM, BN - 1);
+        const bf16_t* q;
+        if (isa) {
+            if (AKM) { constexpr int LPR = BM / 64 > 0 ? BM / 64 : 1; q = p.A + (size_t)(kt0 * BK + r / LPR) * p.lda + max(min(m0 + (r % LPR) * 64, p.M - 8), 0); pf_step = (long long)BK * p.lda * 2; }
+            else     { q = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + kt0 * BK; pf_step = BK * 2; }
+        } else {
+            if (BKM) { constexpr int LPR = BN / 64 > 0 ? BN / 64 : 1; q = p.B + (size_t)(kt0 * BK + r / LPR) * p.ldb + max(min(n0 + (r % LPR) * 64, p.N - 8), 0); pf_step = (long long)BK * p.ldb * 2; }
+            else     { q = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + kt0 * BK; pf_step = BK * 2; }
+        }
+        pf_base = reinterpret_cast<const char*>(q);
+    }
+    auto l2pf = [&](int kt) __attribute__((always_inline)) {          // kt: the tile being requested; the prefetch goes GEMM_L2PF tiles behind it
+        if constexpr (PF) {
+            const int rel = max(min(kt - kt0 + GEMM_L2PF, pf_last), 0);
+            lds_dma4<ASM_DMA>(pf_base + (long long)rel * pf_step, smem + NSTAGE * STAGE_BYTES + (tid & ~63) * 4);
+        }
+    };
     auto glds = [&](int kt, int s) __attribute__((always_inline)) {                        // asynchronous: completion is awaited with vmcnt(0)
         char* at = smem + s * STAGE_BYTES;
         char* bt = at + A_BYTES;
         if (AKM) glds_km<BM, NT, ASM_DMA>(p.A, p.lda, m0, kt * BK, p.M, at, tid); else glds_rm<BM, NT, ASM_DMA>(p.A, p.lda, m0, kt * BK, p.M, at, tid);
         if (BKM) glds_km<BN, NT, ASM_DMA>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid); else glds_rm<BN, NT, ASM_DMA>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid);
+        l2pf(kt);
     };
     const int lrow = lane & 15, lg = lane >> 4;
     auto glds_piece = [&](int kt, int s, int pc) __attribute__((always_inline)) {
@@ -415,6 +470,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
             if (BKM) glds_km_piece<BN, NT, ASM_DMA>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid, pc - PA);
             else     glds_rm_piece<BN, NT, ASM_DMA>(p.B, p.ldb, n0, kt * BK, p.N, bt, tid, pc - PA);
         }
+        if (pc == LPT - 1) l2pf(kt);                       // (the last piece of a tile request)
     };
     auto ldA = [&](const char* at, int i, int ks) __attribute__((always_inline)) -> bf16x8_t {
         const int r0 = wm * TM + i * 16;
@@ -596,7 +652,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
         // branch-free steps (see the 8-wave loop below): the last NSTAGE-1 steps re-request the final k-tile, so the counted
         // vmcnt is a constant and the whole step is one scheduling region
         for (int i = 0; i < nmain; ++i) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * (NSTAGE - 2)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF + VPT * (NSTAGE - 2)) : "memory");     // tile i has landed (its prefetch and the later requests may be out)
             __builtin_amdgcn_s_barrier();
 #ifdef GEMM_TIMELINE
             if (i == 0) TL(2);
@@ -710,7 +766,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                     }
                 }
             };
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");          // tile 0 (the older group) has landed
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF + VPT) : "memory");          // tile 0 (the older group) has landed
             __builtin_amdgcn_s_barrier();
             TL(2);
 #pragma unroll
@@ -722,7 +778,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                 const char* at = smem + stg * STAGE_BYTES;
                 const char* at2 = smem + (stg ^ 1) * STAGE_BYTES;
                 half(fa0, fb0, fa1, fb1, at, at + A_BYTES, 1, 0, 0, false);
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PF) : "memory");
                 __builtin_amdgcn_s_barrier();
                 half(fa1, fb1, fa0, fb0, at2, at2 + A_BYTES, 0, min(kt0 + i + 2, kt0 + nmain - 1), stg, true);   // (past the end: the last tile again)
                 stg ^= 1;
@@ -737,7 +793,7 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
         // whole step one scheduling region.
         static_assert(NSTAGE == 2, "two stages: the step waits for the single k-tile in flight");
         for (int i = 0; i < nmain; ++i) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF) : "memory");
             __builtin_amdgcn_s_barrier();
 #ifdef GEMM_TIMELINE
             if (i == 0) TL(2);
@@ -749,8 +805,8 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
         if (has_tail) __syncthreads();
     } else
     for (int i = 0; i < nmain; ++i) {
-        if (NSTAGE == 3 && i + 1 < nmain) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-        else                               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NSTAGE == 3 && i + 1 < nmain) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF + VPT) : "memory");
+        else                               asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF) : "memory");
         __builtin_amdgcn_s_barrier();
 #ifdef GEMM_TIMELINE
         if (i == 0) TL(2);
@@ -1079,7 +1135,7 @@ namespace vlt5gemm {
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
 int launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
     constexpr int NT_ = WM * WN * 64;
-    constexpr size_t lds = (size_t)NS * ((BM * 8 + NT_ - 1) / NT_ + (BN * 8 + NT_ - 1) / NT_) * NT_ * 16;
+    constexpr size_t lds = (size_t)NS * ((BM * 8 + NT_ - 1) / NT_ + (BN * 8 + NT_ - 1) / NT_) * NT_ * 16 + (GEMM_L2PF ? NT_ * 4 : 0);
     static std::atomic<unsigned long long> optin{0};        // > 64 KB of dynamic LDS needs an explicit opt-in, per kernel and device
     if (int rc = vlt5_lds_optin(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WM, WN, AKM, BKM, NS>), (int)lds, optin)) return rc;
 #ifdef GEMM_TIMELINE
