@@ -27,7 +27,7 @@ extern "C" {
 #define VLT5_OK 0
 #define VLT5_ERR_ARG 1001
 #define VLT5_ERR_ALIGN 1002
-#define VLT5_ABI_VERSION 5
+#define VLT5_ABI_VERSION 6
 
 int vlt5_abi_version(void);
 
@@ -50,7 +50,10 @@ typedef struct {
     int gemm_split_kmin;    /* > 0: shortest reduction the automatic split-K cuts (default 768) */
     int decode_fast;        /* 1: greedy decoding steps through the tiled GEMM / attention launches of the training path;
                                2: through the decode kernels (csrc/decode.hip; default where the shapes allow) */
-    int reserved[6];
+    int decode_split_norm;  /* decode kernels, the T5 norm in front of a projection: 1: folded into the projection (f32 rows in, norm weight and sum
+                               of squares inside); 2: split -- the launch that writes a residual-stream row also writes bf16(row * w) and the row's
+                               partial sums of squares, the projection reads half the bytes (default) */
+    int reserved[5];
 } vlt5_tuning;
 
 /* ---- GEMM: C[M,N] = epi(alpha * sum_k A[m,k] B[n,k]) -------------------------------------------
@@ -590,7 +593,11 @@ int vlt5_decode_fast_supported(const vlt5_config* c, const vlt5_step* s);
  * bf16(x * norm_w), rows scaled by rsqrt(mean(x^2) + norm_eps).  Outputs: f32 (out_f32) and / or bf16 (out_bf16; columns >=
  * split_col are routed to out_bf16_2 -- the k | v columns of a fused q|k|v projection straight into a cache slot).  K % 32 == 0 and
  * K / 32 = KS * NW with KS in {1, 2, 6, 8 (, 12, 16 for bf16 A)}, NW in {1, 2, 4, 8} (vlt5_decode_linear_supported); N % 4 == 0.
- * argmax_val / argmax_idx (optional, [rows][vlt5_decode_linear_tiles(...)]): first maximum of every row inside every column tile. */
+ * argmax_val / argmax_idx (optional, [rows][vlt5_decode_linear_tiles(...)]): first maximum of every row inside every column tile.
+ * A norm split between two launches (what the decode step chains): the launch that writes residual-stream rows (out_f32, N % 16 == 0)
+ * also emits next_xn_bf16 = bf16(out * next_norm_w[n]) and next_ssq[m][N / 16] = the sum of out^2 of every 16-column fragment; the
+ * projection behind that norm then takes x_bf16 = next_xn_bf16 with row_ssq = next_ssq, n_row_ssq = N / 16 (a multiple of 4, <= 64)
+ * and scales its rows by rsqrt(sum_j row_ssq[m][j] / K + norm_eps) -- the same arithmetic as the folded form on half the bytes. */
 typedef struct {
     const float* x_f32; const void* x_bf16; long long ldx;
     const float* norm_w; float norm_eps;
@@ -601,6 +608,8 @@ typedef struct {
     const float* resid; long long ld_resid;
     int relu;
     float* argmax_val; int* argmax_idx;
+    const float* next_norm_w; void* next_xn_bf16; long long ld_next_xn; float* next_ssq;      /* producer side of a split norm */
+    const float* row_ssq; int n_row_ssq;                                                       /* consumer side (with x_bf16) */
 } vlt5_decode_linear_desc;
 int vlt5_decode_linear(const vlt5_decode_linear_desc* d, void* stream);
 int vlt5_decode_linear_supported(int K, int norm_folded);

@@ -127,6 +127,93 @@ def test_decode_linear_vs_f32_reference(dev, rows, N, K, mode):
         assert bool(((pi >= 0) & (pi < N)).all()) and bool((pi.long() // width == torch.arange(tiles, device=dev)[None, :]).all())
 
 
+@pytest.mark.parametrize("rows,d_model,K_in,N_out,mode", [
+    (80, 768, 768, 2304, "plain"),       # attention output projection + residual -> [norm] -> q | k | v (t5-base)
+    (80, 768, 3072, 3072, "relu"),       # wo + residual -> [norm] -> wi + ReLU of the next sublayer
+    (80, 768, 3072, 32200, "argmax"),    # last wo + residual -> [final norm] -> rescale -> lm_head with the per-tile argmax (row-walking kernel)
+    (4, 768, 768, 32200, "argmax"),      # BASELINE configs[0] batch
+    (33, 1024, 1024, 1024, "plain"),     # t5-large width: 64 partial sums per row
+    (100, 768, 768, 32200, "argmax"),    # more than one chunk of row blocks in the row-walking kernel
+    (5, 64, 64, 192, "plain"),           # tiny configuration
+])
+def test_decode_linear_norm_split_between_two_launches(dev, rows, d_model, K_in, N_out, mode):
+    """The decode step's chain: the launch that writes a residual-stream row (x_bf16 W^T + resid) also emits bf16(row * w_norm) and the
+    row's partial sums of squares; the projection behind the norm consumes them (x_bf16 + row_ssq).  Checked against an f32 reference
+    and against the folded form (x_f32 + norm_w) of the same projection on the row the producer wrote."""
+    from vqacl_amd import _lib as L
+    from vqacl_amd._lib import lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(rows * 31 + d_model + K_in * 3 + N_out)
+    xb = torch.randn(rows, K_in, generator=g).to(BF)
+    W1 = (torch.randn(d_model, K_in, generator=g) * K_in ** -0.5).to(BF)
+    r = torch.randn(rows, d_model, generator=g) * 2.0
+    wn = 1.0 + 0.2 * torch.randn(d_model, generator=g)
+    W2 = (torch.randn(N_out, d_model, generator=g) * d_model ** -0.5 + torch.arange(N_out)[:, None] * 1e-6).to(BF)
+    xbd, W1d, rd, wnd, W2d = xb.to(dev), W1.to(dev), r.to(dev), wn.to(dev), W2.to(dev)
+    parts = d_model // 16
+    y = torch.full((rows, d_model), float("nan"), device=dev)
+    xn = torch.zeros(rows, d_model, device=dev, dtype=BF)
+    ssq = torch.full((rows, parts), float("nan"), device=dev)
+    p = L.DecodeLinearDesc()
+    p.x_bf16, p.ldx, p.w_bf16, p.rows, p.N, p.K = ptr(xbd), K_in, ptr(W1d), rows, d_model, K_in
+    p.out_f32, p.ld_out_f32, p.resid, p.ld_resid = ptr(y), d_model, ptr(rd), d_model
+    p.next_norm_w, p.next_xn_bf16, p.ld_next_xn, p.next_ssq = ptr(wnd), ptr(xn), d_model, ptr(ssq)
+    assert lib().vlt5_decode_linear(C.byref(p), stream_ptr()) == 0
+    torch.cuda.synchronize()
+    y_ref = xb.float() @ W1.float().t() + r
+    assert float((y.cpu() - y_ref).abs().max()) <= 2e-3 * float(y_ref.abs().max()) + 1e-4
+    # what the producer emits is a function of the row it wrote: bit-exact operand, sums of squares to f32 rounding
+    assert torch.equal(xn.cpu(), (y.cpu() * wn).to(BF))
+    assert torch.allclose(ssq.sum(dim=1).cpu(), (y.cpu() ** 2).sum(dim=1), rtol=1e-5)
+    assert torch.allclose(ssq.cpu(), (y.cpu() ** 2).view(rows, parts, 16).sum(dim=2), rtol=1e-5, atol=1e-6)
+
+    def consumer(split):
+        c = L.DecodeLinearDesc()
+        c.w_bf16, c.rows, c.N, c.K, c.ldx, c.norm_eps = ptr(W2d), rows, N_out, d_model, d_model, 1e-6
+        if split:
+            c.x_bf16, c.row_ssq, c.n_row_ssq = ptr(xn), ptr(ssq), parts
+        else:
+            c.x_f32, c.norm_w = ptr(y), ptr(wnd)
+        out = torch.full((rows, N_out), float("nan"), device=dev)
+        c.out_f32, c.ld_out_f32 = ptr(out), N_out
+        extra = {}
+        if mode == "relu":
+            c.relu = 1
+            ob = torch.zeros(rows, N_out, device=dev, dtype=BF)
+            c.out_bf16, c.ld_out_bf16 = ptr(ob), N_out
+            extra["ob"] = ob
+        if mode == "argmax":
+            c.alpha = d_model ** -0.5
+            tiles = lib().vlt5_decode_linear_tiles(rows, N_out, d_model, 0 if split else 1)
+            assert tiles > 0
+            pv = torch.full((rows, tiles), float("nan"), device=dev)
+            pi = torch.full((rows, tiles), -1, device=dev, dtype=torch.int32)
+            c.argmax_val, c.argmax_idx = ptr(pv), ptr(pi)
+            extra.update(pv=pv, pi=pi)
+        assert lib().vlt5_decode_linear(C.byref(c), stream_ptr()) == 0
+        torch.cuda.synchronize()
+        return out, extra
+
+    out_s, ex_s = consumer(True)
+    out_f, ex_f = consumer(False)
+    yc = y.cpu()
+    ref = ((yc * wn).to(BF).float() @ W2.float().t()) * torch.rsqrt((yc * yc).mean(dim=1, keepdim=True) + 1e-6)
+    if mode == "argmax":
+        ref = ref * d_model ** -0.5
+    if mode == "relu":
+        ref = ref.clamp(min=0)
+    scale = float(ref.abs().max())
+    assert float((out_s.cpu() - ref).abs().max()) <= 2e-3 * scale + 1e-4
+    # same operand bits, same MFMA order; only the order of the sum of squares differs (rstd to an ulp or two)
+    assert float((out_s - out_f).abs().max()) <= 1e-5 * scale + 1e-6
+    if mode == "relu":
+        assert torch.equal(ex_s["ob"].cpu(), out_s.to(BF).cpu())
+    if mode == "argmax":
+        pv, pi = ex_s["pv"], ex_s["pi"]
+        best = pv.max(dim=1, keepdim=True).values
+        cand = torch.where(pv == best, pi, torch.full_like(pi, 2 ** 30))
+        assert torch.equal(cand.min(dim=1).values.long(), out_s.argmax(dim=1))
+
+
 def test_decode_linear_rejects_bad_arguments(dev):
     from vqacl_amd import _lib as L
     from vqacl_amd._lib import lib, ptr, stream_ptr
@@ -142,6 +229,19 @@ def test_decode_linear_rejects_bad_arguments(dev):
     d.out_f32 = None
     assert lib().vlt5_decode_linear(C.byref(d), stream_ptr()) == 1001                                                  # no output
     assert lib().vlt5_decode_linear(None, stream_ptr()) == 1001
+    # split norm: the producer needs the f32 output, the norm weights and the partials buffer; the consumer a bf16 operand and 4 | n <= 64
+    d.out_f32 = ptr(o)
+    xn = torch.zeros(8, 64, device=dev, dtype=BF)
+    d.next_xn_bf16, d.ld_next_xn = ptr(xn), 64
+    assert lib().vlt5_decode_linear(C.byref(d), stream_ptr()) == 1001                                                  # no norm weights / partials
+    d.next_xn_bf16 = None
+    ss = torch.zeros(8, 6, device=dev)
+    d.row_ssq, d.n_row_ssq = ptr(ss), 6
+    assert lib().vlt5_decode_linear(C.byref(d), stream_ptr()) == 1001                                                  # 6 parts: not a multiple of 4
+    xf = torch.zeros(8, 64, device=dev)
+    wf = torch.ones(64, device=dev)
+    d.x_bf16, d.x_f32, d.norm_w, d.n_row_ssq = None, ptr(xf), ptr(wf), 4
+    assert lib().vlt5_decode_linear(C.byref(d), stream_ptr()) == 1001                                                  # partials with an f32 operand
 
 
 @pytest.mark.parametrize("B,H,dk,Tk,kind", [(80, 12, 64, 1, "self"), (80, 12, 64, 7, "self"), (80, 12, 64, 20, "self"), (80, 12, 64, 64, "self"),
@@ -280,6 +380,15 @@ def test_decode_kernels_against_the_tiled_path_at_base_size(dev, B):
         assert torch.equal(ids_f[t][ok], ids_t[t][ok])
         checked += int(ok.sum())
     assert rel_max_err(cache_f, cache_t) < 2e-2
+    # the norms folded into the projections (vlt5_tuning.decode_split_norm off) against the default, the norm split between two launches:
+    # the same operand bits, only the order of the sums of squares differs
+    model.tuning.decode_split_norm = 1
+    with torch.no_grad():
+        folded, ids_n, cache_n = _step_logits(model, batch, dec_in, dev, fast=True)
+    model.tuning.decode_split_norm = 0
+    for t in range(T):
+        assert rel_max_err(folded[t], fast[t]) < 1e-3, t
+    assert rel_max_err(cache_n, cache_f) < 1e-2
     from test_gpu_model import parity_log
     parity_log(f"decode kernels vs tiled path (base, B={B}, {T} steps): logits rel max err {worst:.4g}, {checked} of {B * T} margin-gated "
                f"next-token ids equal")

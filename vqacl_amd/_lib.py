@@ -22,7 +22,7 @@ class Tuning(C.Structure):
     """vlt5_tuning: experiment switches, every field 0 = the library's default (include/vlt5_hip.h)."""
     _fields_ = [("fold_norm", c_i), ("fold_norm_dec", c_i), ("fused_attn", c_i), ("fused_heads", c_i), ("dec_fused", c_i),
                 ("enc_cut", c_i), ("wgrad_shadow", c_i), ("wgrad_grouped", c_i), ("gemm_t128_kmkm", c_i), ("gemm_t256_km", c_i),
-                ("gemm_t256_min", c_i), ("gemm_dec_tall", c_i), ("gemm_split_kmin", c_i), ("decode_fast", c_i), ("reserved", c_i * 6)]
+                ("gemm_t256_min", c_i), ("gemm_dec_tall", c_i), ("gemm_split_kmin", c_i), ("decode_fast", c_i), ("decode_split_norm", c_i), ("reserved", c_i * 5)]
 
 
 # environment variable -> (field, how its value maps): the library itself reads no environment; the host reads these ONCE per model
@@ -32,7 +32,8 @@ _TUNING_ENV = {"VLT5_FOLD_NORM": ("fold_norm", "onoff"), "VLT5_FOLD_NORM_DEC": (
                "VLT5_ENC_CUT": ("enc_cut", "int"), "VLT5_WGRAD_SHADOW": ("wgrad_shadow", "onoff"), "VLT5_WGRAD_GROUPED": ("wgrad_grouped", "onoff"),
                "VLT5_GEMM_T128_KMKM": ("gemm_t128_kmkm", "int"), "VLT5_GEMM_T256_KM": ("gemm_t256_km", "int"),
                "VLT5_GEMM_T256_MIN": ("gemm_t256_min", "int"), "VLT5_GEMM_DEC_TALL": ("gemm_dec_tall", "onoff"),
-               "VLT5_GEMM_SPLIT_KMIN": ("gemm_split_kmin", "int"), "VLT5_DECODE_FAST": ("decode_fast", "onoff")}
+               "VLT5_GEMM_SPLIT_KMIN": ("gemm_split_kmin", "int"), "VLT5_DECODE_FAST": ("decode_fast", "onoff"),
+               "VLT5_DECODE_SPLIT_NORM": ("decode_split_norm", "onoff")}
 
 
 def make_tuning(**fields):
@@ -166,7 +167,8 @@ class DecodeLinearDesc(C.Structure):
     _fields_ = [("x_f32", vp), ("x_bf16", vp), ("ldx", c_ll), ("norm_w", vp), ("norm_eps", c_f), ("w_bf16", vp), ("rows", c_i), ("N", c_i),
                 ("K", c_i), ("alpha", c_f), ("out_bf16", vp), ("ld_out_bf16", c_ll), ("split_col", c_i), ("out_bf16_2", vp),
                 ("ld_out_bf16_2", c_ll), ("out_f32", vp), ("ld_out_f32", c_ll), ("resid", vp), ("ld_resid", c_ll), ("relu", c_i),
-                ("argmax_val", vp), ("argmax_idx", vp)]
+                ("argmax_val", vp), ("argmax_idx", vp), ("next_norm_w", vp), ("next_xn_bf16", vp), ("ld_next_xn", c_ll), ("next_ssq", vp),
+                ("row_ssq", vp), ("n_row_ssq", c_i)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/vlt5_hip.h
@@ -286,7 +288,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.vlt5_abi_version() != 5:
+        if L.vlt5_abi_version() != 6:
             raise Vlt5Error("libvlt5_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -20,6 +20,11 @@ struct DecLinArgs {
     int relu;
     float* pmax; int* pidx; int ptiles;       // per (row, column tile) first maximum and its column: [rows][CT]
     const int* t_ptr; long long t_stride2;    // optional device-side step index (for out_b2)
+    // T5 RMS norm split between two launches (the decode step's chain): the PRODUCER of a residual-stream row also emits the operand of the
+    // projection behind the next norm, bf16(v * nx_w[n]) (half the bytes of the f32 row, staged by LDS-DMA), and the sum of v^2 of every
+    // (row, 16-column fragment) -- nx_parts = N / 16 per row; the CONSUMER (bf16 A) scales its rows by rsqrt(sum_j rs_part[m][j] / K + eps)
+    const float* nx_w; bf16_t* nx_b; long long ld_nx; float* nx_ssq; int nx_parts;
+    const float* rs_part; int rs_n;           // rs_n a multiple of 4, <= 64
     int RB, CT, ct_per_xcd;                   // filled by vlt5_declin_launch
     long long* tl;                            // -DDECLIN_TIMELINE builds: [workgroup][8] shader-clock stamps of wave 0 (tools/declin_timeline.py)
 };
@@ -49,6 +54,7 @@ struct DecIoArgs {
     long long* out_tokens; long long out_ld; int out_col;       // emitted token -> out_tokens[b*out_ld + out_col]
     const long long* tokens;                  // [B] decoder input ids when there is no argmax to finish
     const float* table; int d, vocab; float* emb_out;           // emb_out[b] = table[token_b] (null: skip)
+    const float* nx_w; bf16_t* nx_b; float* nx_ssq; int nx_parts;    // with emb_out: bf16(row * nx_w) and the row's sum of squares (in part 0, zeros behind it)
     const float* rel_table; const int* lut; int lut_ld, tq, H; float* bias_out; int bias_ld;   // bias_out[h][j] = rel_table[lut[tq][j]][h], j <= tq
 };
 int vlt5_dec_io_launch(const DecIoArgs& a, int B, hipStream_t st);

@@ -111,6 +111,20 @@ __global__ __launch_bounds__(512) void declin_kernel(const DecLinArgs a) {
         const int n0 = n_tile + w * 16 + kq * 4;
         if (a.resid && w < NFRAG && m < a.rows && n0 < a.N) rpre = *reinterpret_cast<const float4*>(a.resid + (size_t)m * a.ldr + n0);
     }
+    // producer of a split norm: the next norm's weights of the same quad; consumer: this lane's share of the row's partial sums of squares
+    float4 wpre = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 rsp[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    {
+        const int n0 = n_tile + w * 16 + kq * 4;
+        if (a.nx_b && w < NFRAG && n0 < a.N) wpre = *reinterpret_cast<const float4*>(a.nx_w + n0);
+        if constexpr (!AF32) {
+            if (a.rs_part && w < NFRAG) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i * 16 + kq * 4 < a.rs_n) rsp[i] = *reinterpret_cast<const float4*>(a.rs_part + (size_t)mc * a.rs_n + i * 16 + kq * 4);
+            }
+        }
+    }
     const int t_step = a.t_ptr ? *a.t_ptr : 0;
     f32x4_t acc[NFRAG];
 #pragma unroll
@@ -212,6 +226,13 @@ __global__ __launch_bounds__(512) void declin_kernel(const DecLinArgs a) {
         float s = 0.f;
         for (int ww = 0; ww < NW; ++ww) s += ssq_s[ww * 16 + r16];
         rs *= rsqrtf(s / (float)a.K + a.eps);
+    } else if (a.rs_part) {                                       // (waves >= NFRAG hold zeros and finish no fragment)
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += (rsp[i].x + rsp[i].y) + (rsp[i].z + rsp[i].w);
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        rs *= rsqrtf(s / (float)a.K + a.eps);
     }
     for (int f = w; f < NFRAG; f += NW) {
         float4 v = red[f * 64 + lane];
@@ -228,6 +249,17 @@ __global__ __launch_bounds__(512) void declin_kernel(const DecLinArgs a) {
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (a.nx_b) {                                              // (workgroup-uniform) split norm: operand of the next projection + this fragment's sum of squares
+            float q = ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (lane < 16 && m < a.rows && n_tile + f * 16 < a.N) a.nx_ssq[(size_t)m * a.nx_parts + (n_tile >> 4) + f] = q;
+            if (ok) {
+                float4 wq = wpre;
+                if (f != w) wq = *reinterpret_cast<const float4*>(a.nx_w + n0);
+                dl_store8(a.nx_b + (size_t)m * a.ld_nx + n0, make_uint2(pack_bf16x2(v.x * wq.x, v.y * wq.y), pack_bf16x2(v.z * wq.z, v.w * wq.w)));
+            }
+        }
         if (ok) {
             if (a.out_f) dl_store16f(a.out_f + (size_t)m * a.ldf + n0, v);
             if (a.out_b) {
@@ -281,133 +313,198 @@ __global__ __launch_bounds__(512) void declin_kernel(const DecLinArgs a) {
 // The vocabulary projection: N = 32200 columns make 504 column tiles -- enough workgroups without cutting the rows, and its 49.5 MB weight
 // is the one operand of the step that is worth reading ONCE: a workgroup stages its 64-column slice a single time and walks the row blocks
 // (the f32 rows of block rb + 1 are requested while block rb is computed).  Norm folded in as in declin_kernel<true, ...>; one phase only.
-template <int KT, int NFRAG>
-__global__ __launch_bounds__(512) void declin_rows_kernel(const DecLinArgs a) {
+// The reduction is split over the waves as above, but the waves' partial tiles meet ONCE per chunk of RBC row blocks instead of once per
+// row block: a wave keeps the accumulators of the whole chunk (RBC x NFRAG tiles), after the last MFMA the partials overwrite the weight
+// stage (nobody reads it any more) and wave w finishes row blocks w, w + NW, ...: sums, rstd, the logits store if asked for, and the
+// (row, column tile) argmax partial, all four fragments in its own registers.  Three barriers per chunk (B = 80: one chunk) against two
+// per row block before -- the walk was a chain of five reduce / barrier / epilogue rounds per workgroup, 39 us per step.
+template <bool AF32, int KT, int NFRAG>
+__global__ __launch_bounds__(256) void declin_rows_kernel(const DecLinArgs a) {      // (<= 4 waves: the chunk's accumulators + two sets of f32 rows need > 256 registers)
+    constexpr int RBC = KT * 2 < 5 ? KT * 2 : 5;                   // row blocks per chunk: their partial tiles fit the weight stage
     extern __shared__ __attribute__((aligned(16))) char dl_smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
     const int ct = blockIdx.x;
     const int r16 = lane & 15, kq = lane >> 4;
     const int n_tile = ct * (16 * NFRAG);
     constexpr int WT_BYTES = NFRAG * 16 * 128, WAVE_BYTES = KT * WT_BYTES;
+    static_assert(RBC * NFRAG * 1024 <= WAVE_BYTES, "a wave's partial tiles of a chunk fit its share of the stage");
     char* stage = dl_smem + (size_t)w * WAVE_BYTES;
-    float4* red = reinterpret_cast<float4*>(dl_smem + (size_t)NW * WAVE_BYTES);
-    float* wst = reinterpret_cast<float*>(red + (size_t)NW * NFRAG * 64);
-    float* ssq_s = wst + NW * 256;
-    float* amax_s = ssq_s + NW * 16;
-    int* aidx_s = reinterpret_cast<int*>(amax_s + NFRAG * 16);
+    float4* red = reinterpret_cast<float4*>(dl_smem);                                     // [NW][RBC][NFRAG][64], over the stage
+    float* wst = reinterpret_cast<float*>(dl_smem + (size_t)NW * WAVE_BYTES);             // [NW][256]
+    float* ssq_s = wst + NW * 256;                                                        // [RBC][NW][16]
     const int prow = lane >> 3, pchunk = (lane & 7) ^ (lane >> 3);
     const int k0 = w * (KT * 64);
+    constexpr int XV = AF32 ? 2 : 1;                               // 16-byte loads per lane and 32-deep k-slab: 8 f32 or 8 bf16
     float4 wl = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane * 4 < KT * 64) wl = *reinterpret_cast<const float4*>(a.ln_w + k0 + lane * 4);
-    auto load_rows = [&](int rb, float4 (&x)[KT * 2][2]) {
-        int mr = rb * 16 + r16;
-        mr = mr < a.rows ? mr : a.rows - 1;
-        const float* xp = a.xf + (size_t)mr * a.ldx + k0 + kq * 8;
+    if constexpr (AF32) { if (lane * 4 < KT * 64) wl = *reinterpret_cast<const float4*>(a.ln_w + k0 + lane * 4); }
+    // split norm (bf16 rows emitted by the producer of the residual stream): wave w finishes row blocks w and w + NW of a chunk -- their
+    // partial sums of squares are requested first
+    float4 rsp[2][4];
 #pragma unroll
-        for (int ks = 0; ks < KT * 2; ++ks) {
-            x[ks][0] = *reinterpret_cast<const float4*>(xp + ks * 32);
-            x[ks][1] = *reinterpret_cast<const float4*>(xp + ks * 32 + 4);
-        }
-    };
-    float4 xa[KT * 2][2], xn[KT * 2][2];
-    load_rows(0, xa);
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
+        for (int i = 0; i < 4; ++i) rsp[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_parts = [&](int rb0) {
+        if constexpr (!AF32) {
 #pragma unroll
-        for (int i = 0; i < NFRAG * 2; ++i) {
-            int n = n_tile + i * 8 + prow;
-            n = n < a.N ? n : a.N - 1;
-            __builtin_amdgcn_global_load_lds(a.W + (size_t)n * a.K + k0 + kt * 64 + pchunk * 8, (dl_lds_ptr_t)(stage + kt * WT_BYTES + i * 1024), 16, 0, DECLIN_ROWS_W_AUX);
-        }
-    }
-    float* strip = wst + w * 256;
-    if (lane * 4 < KT * 64) *reinterpret_cast<float4*>(strip + lane * 4) = wl;
-    for (int rb = 0; rb < a.RB; ++rb) {
-        if (rb + 1 < a.RB) load_rows(rb + 1, xn);
-        __builtin_amdgcn_sched_barrier(0);
-        bf16x8_t fx[KT * 2];
-        float ssq = 0.f;
+            for (int u = 0; u < 2; ++u) {
+                const int c = w + u * NW;
+                int mr = (rb0 + c) * 16 + r16;
+                mr = mr < a.rows ? mr : a.rows - 1;
+                if (c < RBC && rb0 + c < a.RB) {
 #pragma unroll
-        for (int ks = 0; ks < KT * 2; ++ks) {
-            const float4 w0 = *reinterpret_cast<const float4*>(strip + ks * 32 + kq * 8);
-            const float4 w1 = *reinterpret_cast<const float4*>(strip + ks * 32 + kq * 8 + 4);
-            const float4 x0 = xa[ks][0], x1 = xa[ks][1];
-            ssq += x0.x * x0.x + x0.y * x0.y + x0.z * x0.z + x0.w * x0.w + x1.x * x1.x + x1.y * x1.y + x1.z * x1.z + x1.w * x1.w;
-            const uint4 pk = make_uint4(pack_bf16x2(x0.x * w0.x, x0.y * w0.y), pack_bf16x2(x0.z * w0.z, x0.w * w0.w),
-                                        pack_bf16x2(x1.x * w1.x, x1.y * w1.y), pack_bf16x2(x1.z * w1.z, x1.w * w1.w));
-            fx[ks] = __builtin_bit_cast(bf16x8_t, pk);
-        }
-        if (rb == 0) {                                             // the wave's weight pieces (requested once) have landed
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-        }
-        f32x4_t acc[NFRAG];
-#pragma unroll
-        for (int f = 0; f < NFRAG; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-            for (int p2 = 0; p2 < 2; ++p2) {
-                const int slot = (p2 * 4 + kq) ^ (r16 & 7);
-#pragma unroll
-                for (int f = 0; f < NFRAG; ++f) {
-                    const bf16x8_t fw = *reinterpret_cast<const bf16x8_t*>(stage + kt * WT_BYTES + (f * 16 + r16) * 128 + slot * 16);
-                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fx[kt * 2 + p2], acc[f], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i)
+                        if (i * 16 + kq * 4 < a.rs_n) rsp[u][i] = *reinterpret_cast<const float4*>(a.rs_part + (size_t)mr * a.rs_n + i * 16 + kq * 4);
                 }
             }
         }
+    };
+    auto load_rows = [&](int rb, float4 (&x)[KT * 2][XV]) {
+        int mr = rb * 16 + r16;
+        mr = mr < a.rows ? mr : a.rows - 1;
+        if constexpr (AF32) {
+            const float* xp = a.xf + (size_t)mr * a.ldx + k0 + kq * 8;
 #pragma unroll
-        for (int f = 0; f < NFRAG; ++f) red[(w * NFRAG + f) * 64 + lane] = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
-        ssq += __shfl_xor(ssq, 16, 64);
-        ssq += __shfl_xor(ssq, 32, 64);
-        if (lane < 16) ssq_s[w * 16 + lane] = ssq;
-        __syncthreads();
-        float s = 0.f;
-        for (int ww = 0; ww < NW; ++ww) s += ssq_s[ww * 16 + r16];
-        const float rs = a.alpha * rsqrtf(s / (float)a.K + a.eps);
-        const int m = rb * 16 + r16;
-        for (int f = w; f < NFRAG; f += NW) {
-            float4 v = red[f * 64 + lane];
-            for (int ww = 1; ww < NW; ++ww) {
-                const float4 o = red[(ww * NFRAG + f) * 64 + lane];
-                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            for (int ks = 0; ks < KT * 2; ++ks) {
+                x[ks][0] = *reinterpret_cast<const float4*>(xp + ks * 32);
+                x[ks][XV - 1] = *reinterpret_cast<const float4*>(xp + ks * 32 + 4);
             }
-            v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
-            const int n0 = n_tile + f * 16 + kq * 4;
-            const bool ok = m < a.rows && n0 < a.N;
-            if (ok && a.out_f) dl_store16f(a.out_f + (size_t)m * a.ldf + n0, v);
+        } else {
+            const bf16_t* xp = a.xb + (size_t)mr * a.ldx + k0 + kq * 8;
+#pragma unroll
+            for (int ks = 0; ks < KT * 2; ++ks) x[ks][0] = *reinterpret_cast<const float4*>(xp + ks * 32);
+        }
+    };
+    auto stage_w = [&]() {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+            for (int i = 0; i < NFRAG * 2; ++i) {
+                int n = n_tile + i * 8 + prow;
+                n = n < a.N ? n : a.N - 1;
+                __builtin_amdgcn_global_load_lds(a.W + (size_t)n * a.K + k0 + kt * 64 + pchunk * 8, (dl_lds_ptr_t)(stage + kt * WT_BYTES + i * 1024), 16, 0, DECLIN_ROWS_W_AUX);
+            }
+        }
+    };
+    float4 xa[KT * 2][XV], xn[KT * 2][XV];
+    load_parts(0);
+    load_rows(0, xa);
+    stage_w();
+    float* strip = wst + w * 256;
+    if constexpr (AF32) { if (lane * 4 < KT * 64) *reinterpret_cast<float4*>(strip + lane * 4) = wl; }
+    for (int rb0 = 0; rb0 < a.RB; rb0 += RBC) {
+        if (rb0 > 0) {                                             // (more than RBC row blocks: the stage held partial tiles -- fetch the slice again)
+            __syncthreads();
+            load_parts(rb0);
+            load_rows(rb0, xa);
+            stage_w();
+        }
+        f32x4_t acc[RBC][NFRAG];
+#pragma unroll
+        for (int c = 0; c < RBC; ++c)
+#pragma unroll
+            for (int f = 0; f < NFRAG; ++f) acc[c][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < RBC; ++c) {
+            const int rb = rb0 + c;
+            if (rb < a.RB) {                                       // (workgroup-uniform)
+                if (c + 1 < RBC && rb + 1 < a.RB) load_rows(rb + 1, xn);
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8_t fx[KT * 2];
+                if constexpr (AF32) {
+                    float ssq = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KT * 2; ++ks) {
+                        const float4 w0 = *reinterpret_cast<const float4*>(strip + ks * 32 + kq * 8);
+                        const float4 w1 = *reinterpret_cast<const float4*>(strip + ks * 32 + kq * 8 + 4);
+                        const float4 x0 = xa[ks][0], x1 = xa[ks][XV - 1];
+                        ssq += x0.x * x0.x + x0.y * x0.y + x0.z * x0.z + x0.w * x0.w + x1.x * x1.x + x1.y * x1.y + x1.z * x1.z + x1.w * x1.w;
+                        const uint4 pk = make_uint4(pack_bf16x2(x0.x * w0.x, x0.y * w0.y), pack_bf16x2(x0.z * w0.z, x0.w * w0.w),
+                                                    pack_bf16x2(x1.x * w1.x, x1.y * w1.y), pack_bf16x2(x1.z * w1.z, x1.w * w1.w));
+                        fx[ks] = __builtin_bit_cast(bf16x8_t, pk);
+                    }
+                    ssq += __shfl_xor(ssq, 16, 64);
+                    ssq += __shfl_xor(ssq, 32, 64);
+                    if (lane < 16) ssq_s[(c * NW + w) * 16 + lane] = ssq;
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < KT * 2; ++ks) fx[ks] = __builtin_bit_cast(bf16x8_t, xa[ks][0]);
+                }
+                if (c == 0) {                                      // the wave's weight pieces have landed (the rows of block rb + 1 stay in flight)
+                    if (RBC > 1 && rb + 1 < a.RB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KT * 2 * XV) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                    for (int p2 = 0; p2 < 2; ++p2) {
+                        const int slot = (p2 * 4 + kq) ^ (r16 & 7);
+#pragma unroll
+                        for (int f = 0; f < NFRAG; ++f) {
+                            const bf16x8_t fw = *reinterpret_cast<const bf16x8_t*>(stage + kt * WT_BYTES + (f * 16 + r16) * 128 + slot * 16);
+                            acc[c][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fx[kt * 2 + p2], acc[c][f], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < KT * 2; ++ks) { xa[ks][0] = xn[ks][0]; xa[ks][XV - 1] = xn[ks][XV - 1]; }
+            }
+        }
+        __syncthreads();                                           // every wave is done with the weight stage
+#pragma unroll
+        for (int c = 0; c < RBC; ++c)
+#pragma unroll
+            for (int f = 0; f < NFRAG; ++f)
+                red[((w * RBC + c) * NFRAG + f) * 64 + lane] = make_float4(acc[c][f][0], acc[c][f][1], acc[c][f][2], acc[c][f][3]);
+        __syncthreads();
+        for (int c = w; c < RBC; c += NW) {
+            const int rb = rb0 + c;
+            if (rb >= a.RB) break;
+            float s = 0.f;
+            if constexpr (AF32) {
+                for (int ww = 0; ww < NW; ++ww) s += ssq_s[(c * NW + ww) * 16 + r16];
+            } else {
+                const int u = c >= NW ? 1 : 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s += (u ? (rsp[1][i].x + rsp[1][i].y) + (rsp[1][i].z + rsp[1][i].w) : (rsp[0][i].x + rsp[0][i].y) + (rsp[0][i].z + rsp[0][i].w));
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+            }
+            const float rs = a.alpha * rsqrtf(s / (float)a.K + a.eps);
+            const int m = rb * 16 + r16;
             float best = -INFINITY;
             int bi = 0x7fffffff;
-            if (ok) {
-                best = v.x; bi = n0;
-                if (v.y > best) { best = v.y; bi = n0 + 1; }
-                if (v.z > best) { best = v.z; bi = n0 + 2; }
-                if (v.w > best) { best = v.w; bi = n0 + 3; }
+#pragma unroll
+            for (int f = 0; f < NFRAG; ++f) {
+                float4 v = red[(c * NFRAG + f) * 64 + lane];
+                for (int ww = 1; ww < NW; ++ww) {
+                    const float4 o = red[((ww * RBC + c) * NFRAG + f) * 64 + lane];
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
+                const int n0 = n_tile + f * 16 + kq * 4;
+                const bool ok = m < a.rows && n0 < a.N;
+                if (ok && a.out_f) dl_store16f(a.out_f + (size_t)m * a.ldf + n0, v);
+                if (ok) {                                          // first maximum wins: columns ascend with f, then within the quad
+                    if (v.x > best) { best = v.x; bi = n0; }
+                    if (v.y > best) { best = v.y; bi = n0 + 1; }
+                    if (v.z > best) { best = v.z; bi = n0 + 2; }
+                    if (v.w > best) { best = v.w; bi = n0 + 3; }
+                }
             }
 #pragma unroll
-            for (int o = 16; o <= 32; o <<= 1) {
+            for (int o = 16; o <= 32; o <<= 1) {                   // the four lanes of a row (their quads interleave: ties go to the lower column)
                 const float ov = __shfl_xor(best, o, 64);
                 const int oi = __shfl_xor(bi, o, 64);
                 if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
             }
-            if (lane < 16) { amax_s[f * 16 + lane] = best; aidx_s[f * 16 + lane] = bi; }
-        }
-        __syncthreads();
-        if (a.pmax && threadIdx.x < 16 && rb * 16 + (int)threadIdx.x < a.rows) {
-            float best = amax_s[threadIdx.x];
-            int bi = aidx_s[threadIdx.x];
-#pragma unroll
-            for (int f = 1; f < NFRAG; ++f) {
-                const float ov = amax_s[f * 16 + threadIdx.x];
-                const int oi = aidx_s[f * 16 + threadIdx.x];
-                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            if (a.pmax && lane < 16 && m < a.rows) {
+                const size_t slot = (size_t)m * a.CT + ct;
+                a.pmax[slot] = best;
+                a.pidx[slot] = bi;
             }
-            const size_t slot = (size_t)(rb * 16 + threadIdx.x) * a.CT + ct;
-            a.pmax[slot] = best;
-            a.pidx[slot] = bi;
         }
-#pragma unroll
-        for (int ks = 0; ks < KT * 2; ++ks) { xa[ks][0] = xn[ks][0]; xa[ks][1] = xn[ks][1]; }
     }
 }
 
@@ -582,7 +679,24 @@ __global__ __launch_bounds__(256) void dec_io_kernel(const DecIoArgs a) {
         long long id = tok < 0 ? 0 : (tok >= a.vocab ? a.vocab - 1 : tok);
         const float4* src = reinterpret_cast<const float4*>(a.table + (size_t)id * a.d);
         float4* dst = reinterpret_cast<float4*>(a.emb_out + (size_t)b * a.d);
-        for (int i = tid; i < a.d / 4; i += 256) dst[i] = src[i];
+        float q = 0.f;
+        for (int i = tid; i < a.d / 4; i += 256) {
+            const float4 v = src[i];
+            dst[i] = v;
+            if (a.nx_b) {                                          // split norm (DecLinArgs.nx_*): the operand of the first projection of layer 0
+                const float4 wq = reinterpret_cast<const float4*>(a.nx_w)[i];
+                q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                *reinterpret_cast<uint2*>(a.nx_b + (size_t)b * a.d + i * 4) = make_uint2(pack_bf16x2(v.x * wq.x, v.y * wq.y), pack_bf16x2(v.z * wq.z, v.w * wq.w));
+            }
+        }
+        if (a.nx_b) {
+            __shared__ float qs[4];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            if ((tid & 63) == 0) qs[tid >> 6] = q;
+            __syncthreads();
+            for (int j = tid; j < a.nx_parts; j += 256) a.nx_ssq[(size_t)b * a.nx_parts + j] = j == 0 ? (qs[0] + qs[1]) + (qs[2] + qs[3]) : 0.f;
+        }
     }
     if (a.bias_out && b == 0) {                                    // bias row of query position tq against keys 0..tq: [H][bias_ld]
         const int n = a.H * (a.tq + 1);
@@ -638,6 +752,8 @@ int vlt5_declin_launch(DecLinArgs a, hipStream_t st) {
     const bool af32 = a.xf != nullptr;
     if ((!a.xf && !a.xb) || !a.W || a.rows <= 0 || a.N <= 0 || (a.N & 3)) return VLT5_ERR_ARG;
     if (af32 && !a.ln_w) return VLT5_ERR_ARG;
+    if (a.rs_part && (af32 || a.rs_n <= 0 || a.rs_n > 64 || (a.rs_n & 3) || (((uintptr_t)a.rs_part) & 15))) return VLT5_ERR_ARG;
+    if (a.nx_b && (!a.nx_w || !a.nx_ssq || a.relu || a.nx_parts != a.N / 16 || (a.N & 15) || (a.ld_nx & 3))) return VLT5_ERR_ARG;
     if ((a.ldx & 7) || (a.K & 63)) return VLT5_ERR_ALIGN;
     int kt, nw, nfrag;
     if (!declin_geometry(a.rows, a.N, a.K, af32, &kt, &nw, &nfrag)) return VLT5_ERR_ARG;
@@ -649,12 +765,14 @@ int vlt5_declin_launch(DecLinArgs a, hipStream_t st) {
     if (a.pmax && a.ptiles != a.CT) return VLT5_ERR_ARG;
     // the row-walking form for a wide norm-folded projection without a bf16 output (the vocabulary projection): the weight slice is
     // staged once per column tile
-    if (af32 && nfrag == 4 && a.RB > 1 && a.CT >= 256 && a.K == 64 * kt * nw && !a.out_b && !a.resid && !a.relu && (kt == 3 || kt == 4)) {
-        const size_t lds_r = declin_lds_bytes(true, kt, 4, nw);
-        static std::atomic<unsigned long long> optin_r[2];
-        declin_fn fr = kt == 3 ? &declin_rows_kernel<3, 4> : &declin_rows_kernel<4, 4>;
+    if ((af32 || a.rs_part) && nfrag == 4 && nw <= 4 && a.RB > 1 && a.CT >= 256 && a.K == 64 * kt * nw && !a.out_b && !a.resid && !a.relu && !a.nx_b &&
+        (kt == 3 || kt == 4)) {
+        const size_t lds_r = (size_t)nw * kt * 4 * 16 * 128 + (size_t)nw * 256 * 4 + (size_t)5 * nw * 16 * 4;     // weight stage (the partial tiles overlay it) + norm-weight strips + sums of squares
+        static std::atomic<unsigned long long> optin_r[4];
+        declin_fn fr = af32 ? (kt == 3 ? &declin_rows_kernel<true, 3, 4> : &declin_rows_kernel<true, 4, 4>)
+                            : (kt == 3 ? &declin_rows_kernel<false, 3, 4> : &declin_rows_kernel<false, 4, 4>);
         if (lds_r > 64 * 1024) {
-            const int rc = vlt5_lds_optin((const void*)fr, 160 * 1024, optin_r[kt - 3]);
+            const int rc = vlt5_lds_optin((const void*)fr, 160 * 1024, optin_r[(af32 ? 0 : 2) + kt - 3]);
             if (rc) return rc;
         }
         hipLaunchKernelGGL(fr, dim3(a.CT), dim3(nw * 64), lds_r, st, a);
@@ -716,6 +834,15 @@ extern "C" int vlt5_decode_linear(const vlt5_decode_linear_desc* d, void* stream
     a.out_b2 = (bf16_t*)d->out_bf16_2; a.ldo2 = d->ld_out_bf16_2;
     a.out_f = d->out_f32; a.ldf = d->ld_out_f32; a.resid = d->resid; a.ldr = d->ld_resid; a.relu = d->relu;
     if ((a.xf && a.xb) || (!a.out_b && !a.out_f)) return VLT5_ERR_ARG;
+    if (d->next_xn_bf16) {
+        if (!a.out_f || !d->next_norm_w || !d->next_ssq || (a.N & 15)) return VLT5_ERR_ARG;
+        if ((d->ld_next_xn & 3) || (((uintptr_t)d->next_norm_w) & 15)) return VLT5_ERR_ALIGN;
+        a.nx_w = d->next_norm_w; a.nx_b = (bf16_t*)d->next_xn_bf16; a.ld_nx = d->ld_next_xn; a.nx_ssq = d->next_ssq; a.nx_parts = a.N / 16;
+    }
+    if (d->row_ssq) {
+        if (!a.xb) return VLT5_ERR_ARG;
+        a.rs_part = d->row_ssq; a.rs_n = d->n_row_ssq; a.eps = d->norm_eps;
+    }
     if (a.out_b && ((a.ldo & 3) || (a.out_b2 && ((a.ldo2 & 3) || (a.split_col & 3))))) return VLT5_ERR_ALIGN;
     if ((a.out_f && (a.ldf & 3)) || (a.resid && (a.ldr & 3))) return VLT5_ERR_ALIGN;
     if (d->argmax_val || d->argmax_idx) {

@@ -799,9 +799,17 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
         for (int l = 0; l < Ld; ++l) RC(k.wait_bucket(Ld - 1 - l));
     }
     float* bias_t = k.w<float>(p.dec_bias);                        // [H][Tcap]: relative-position bias row of query position t
+    // split norms (decode.h DecLinArgs.nx_*): whoever writes a row of the residual stream also writes bf16(row * w) for the norm that reads
+    // it next and the row's partial sums of squares; the projection behind the norm stages half the bytes and scales its rows by rstd.
+    // One operand buffer and one partials buffer serve the whole chain (a launch reads what the launch before it wrote).
+    const int nparts = d / 16;
+    const bool split_norm = k.tun.decode_split_norm != 1 && (d % 64) == 0 && nparts <= 64 && vlt5_decode_linear_supported(d, 0);
+    bf16_t* xn = reinterpret_cast<bf16_t*>(k.w<float>(p.tmp));
+    float* xn_ssq = reinterpret_cast<float*>(reinterpret_cast<char*>(xn) + (((size_t)B * d * 2 + 255) & ~(size_t)255));
     if (t == 0 || !chained) {
         DecIoArgs io;
         memset(&io, 0, sizeof io);
+        if (split_norm) { io.nx_w = k.P + L.dec[0].ln_s; io.nx_b = xn; io.nx_ssq = xn_ssq; io.nx_parts = nparts; }
         io.tokens = g.tokens; io.table = k.P + L.shared; io.d = d; io.vocab = c.vocab; io.emb_out = k.w<float>(p.y[0]);
         io.rel_table = k.P + L.dec_rel; io.lut = s.dec_lut; io.lut_ld = Tcap; io.tq = t; io.H = k.H; io.bias_out = bias_t; io.bias_ld = Tcap;
         RC(vlt5_dec_io_launch(io, B, k.st));
@@ -812,6 +820,18 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
         memset(&a, 0, sizeof a);
         a.xf = xf; a.xb = xb; a.ldx = K; a.ln_w = xf ? k.P + ln_w : nullptr; a.eps = c.eps; a.W = W; a.rows = B; a.N = N; a.K = K;
         a.alpha = 1.f; a.out_b = ob; a.ldo = ldo; a.split_col = 0x7fffffff; a.out_f = of; a.ldf = N; a.resid = resid; a.ldr = N; a.relu = relu;
+        return a;
+    };
+    // the projection behind a norm: the bf16 operand + partials its producer left (split_norm), or the f32 row with the norm folded in
+    auto normed = [&](const float* yf, long long ln_w, const bf16_t* W, int N, bf16_t* ob, long long ldo, int relu) {
+        DecLinArgs a = split_norm ? lin(nullptr, 0, xn, d, W, N, ob, ldo, nullptr, nullptr, relu) : lin(yf, ln_w, nullptr, d, W, N, ob, ldo, nullptr, nullptr, relu);
+        if (split_norm) { a.rs_part = xn_ssq; a.rs_n = nparts; a.eps = c.eps; }
+        return a;
+    };
+    // the producer of residual-stream row `of` = resid + xb W^T, feeding the norm with weights next_ln
+    auto resid_out = [&](const bf16_t* xb, int K, const bf16_t* W, float* of, const float* resid, long long next_ln) {
+        DecLinArgs a = lin(nullptr, 0, xb, K, W, d, nullptr, 0, of, resid, 0);
+        if (split_norm) { a.nx_w = k.P + next_ln; a.nx_b = xn; a.ld_nx = d; a.nx_ssq = xn_ssq; a.nx_parts = nparts; }
         return a;
     };
     const size_t cache_layer = (size_t)B * Tcap * 2 * inner;
@@ -826,7 +846,7 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
         bf16_t* kv = k.w<bf16_t>(p.kv_all) + (size_t)l * Mx * 2 * inner;  // [B][Sx][2*inner]: k | v of this layer
         const int ffw = c.gated_act ? 2 * ff : ff;
         {   // norm -> q | k | v: q to its buffer, k | v into cache slot t
-            DecLinArgs a = lin(y0, D.ln_s, nullptr, d, k.Pb + D.sqkv, 3 * inner, q, inner, nullptr, nullptr, 0);
+            DecLinArgs a = normed(y0, D.ln_s, k.Pb + D.sqkv, 3 * inner, q, inner, 0);
             a.split_col = inner; a.out_b2 = kc + (size_t)t * 2 * inner; a.ldo2 = (long long)Tcap * 2 * inner;
             RC(vlt5_declin_launch(a, k.st));
         }
@@ -838,11 +858,11 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
             RC(vlt5_dec_core_launch(a, c.d_kv, k.st));
         }
         {
-            DecLinArgs a = lin(nullptr, 0, k.w<bf16_t>(p.ctx_s[l]), inner, k.Pb + D.so, d, nullptr, 0, y1, y0, 0);
+            DecLinArgs a = resid_out(k.w<bf16_t>(p.ctx_s[l]), inner, k.Pb + D.so, y1, y0, D.ln_c);
             RC(vlt5_declin_launch(a, k.st));
         }
         {
-            DecLinArgs a = lin(y1, D.ln_c, nullptr, d, k.Pb + D.cq, inner, k.w<bf16_t>(p.qc[l]), inner, nullptr, nullptr, 0);
+            DecLinArgs a = normed(y1, D.ln_c, k.Pb + D.cq, inner, k.w<bf16_t>(p.qc[l]), inner, 0);
             RC(vlt5_declin_launch(a, k.st));
         }
         {
@@ -854,30 +874,31 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
             RC(vlt5_dec_core_launch(a, c.d_kv, k.st));
         }
         {
-            DecLinArgs a = lin(nullptr, 0, k.w<bf16_t>(p.ctx_c[l]), inner, k.Pb + D.co, d, nullptr, 0, y2, y1, 0);
+            DecLinArgs a = resid_out(k.w<bf16_t>(p.ctx_c[l]), inner, k.Pb + D.co, y2, y1, D.ln_f);
             RC(vlt5_declin_launch(a, k.st));
         }
         if (c.gated_act) {
-            DecLinArgs a = lin(y2, D.ln_f, nullptr, d, k.Pb + D.wi, 2 * ff, k.w<bf16_t>(p.ud[l]), 2 * ff, nullptr, nullptr, 0);
+            DecLinArgs a = normed(y2, D.ln_f, k.Pb + D.wi, 2 * ff, k.w<bf16_t>(p.ud[l]), 2 * ff, 0);
             RC(vlt5_declin_launch(a, k.st));
             RC(vlt5_glu_fwd(k.w<bf16_t>(p.ud[l]), k.w<bf16_t>(p.hd[l]), B, ff, 0.f, 0, k.st));
         } else {
-            DecLinArgs a = lin(y2, D.ln_f, nullptr, d, k.Pb + D.wi, ff, k.w<bf16_t>(p.hd[l]), ff, nullptr, nullptr, 1);
+            DecLinArgs a = normed(y2, D.ln_f, k.Pb + D.wi, ff, k.w<bf16_t>(p.hd[l]), ff, 1);
             RC(vlt5_declin_launch(a, k.st));
         }
         {
-            DecLinArgs a = lin(nullptr, 0, k.w<bf16_t>(p.hd[l]), ff, k.Pb + D.wo, d, nullptr, 0, y3, y2, 0);
+            DecLinArgs a = resid_out(k.w<bf16_t>(p.hd[l]), ff, k.Pb + D.wo, y3, y2, l + 1 < Ld ? L.dec[l + 1].ln_s : L.dec_final_ln);
             RC(vlt5_declin_launch(a, k.st));
         }
     }
     // final norm + rescale + tied lm_head (+ the first maximum of every column tile)
     const bool want_ids = g.next_ids || g.done;
-    const int tiles = vlt5_declin_tiles(B, c.vocab, d, 1);
+    const int tiles = vlt5_declin_tiles(B, c.vocab, d, split_norm ? 0 : 1);
     float* pmax = k.w<float>(p.slab);
     int* pidx = reinterpret_cast<int*>(pmax + (size_t)B * tiles);
     if ((size_t)B * tiles * 8 > p.slab_bytes) return VLT5_ERR_ARG;
     {
-        DecLinArgs a = lin(k.w<float>(p.y[3 * Ld]), L.dec_final_ln, nullptr, d, k.Pb + L.shared, c.vocab, nullptr, 0, g.logits, nullptr, 0);
+        DecLinArgs a = normed(k.w<float>(p.y[3 * Ld]), L.dec_final_ln, k.Pb + L.shared, c.vocab, nullptr, 0, 0);
+        a.out_f = g.logits; a.ldf = c.vocab;
         a.alpha = 1.0f / sqrtf((float)d);                           // tied embeddings: rescale before the vocabulary projection
         if (want_ids) { a.pmax = pmax; a.pidx = pidx; a.ptiles = tiles; }
         if (!g.logits && !want_ids) return VLT5_ERR_ARG;
@@ -890,6 +911,7 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
         io.done = g.done; io.eos_id = g.eos_id; io.pad_id = g.pad_id; io.out_tokens = g.out_tokens; io.out_ld = g.out_ld; io.out_col = t + 1;
         if (chained && t + 1 < Tcap) {                              // input row and bias row of the next step
             io.table = k.P + L.shared; io.d = d; io.vocab = c.vocab; io.emb_out = k.w<float>(p.y[0]);
+            if (split_norm) { io.nx_w = k.P + L.dec[0].ln_s; io.nx_b = xn; io.nx_ssq = xn_ssq; io.nx_parts = nparts; }
             io.rel_table = k.P + L.dec_rel; io.lut = s.dec_lut; io.lut_ld = Tcap; io.tq = t + 1; io.H = k.H; io.bias_out = bias_t; io.bias_ld = Tcap;
         }
         RC(vlt5_dec_io_launch(io, B, k.st));
