@@ -381,13 +381,14 @@ def test_decode_kernels_against_the_tiled_path_at_base_size(dev, B):
         checked += int(ok.sum())
     assert rel_max_err(cache_f, cache_t) < 2e-2
     # the norms folded into the projections (vlt5_tuning.decode_split_norm off) against the default, the norm split between two launches:
-    # the same operand bits, only the order of the sums of squares differs
+    # per projection the same operand bits and a sum of squares in another order (1e-5, kernel test above); through 12 layers the odd
+    # flipped bf16 rounding of an activation grows to ~2e-3 of the logit range
     model.tuning.decode_split_norm = 1
     with torch.no_grad():
         folded, ids_n, cache_n = _step_logits(model, batch, dec_in, dev, fast=True)
     model.tuning.decode_split_norm = 0
     for t in range(T):
-        assert rel_max_err(folded[t], fast[t]) < 1e-3, t
+        assert rel_max_err(folded[t], fast[t]) < 5e-3, t
     assert rel_max_err(cache_n, cache_f) < 1e-2
     from test_gpu_model import parity_log
     parity_log(f"decode kernels vs tiled path (base, B={B}, {T} steps): logits rel max err {worst:.4g}, {checked} of {B * T} margin-gated "

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int i0 = wave * 16;
     float add[4][4];
-    if (i0 < p.Tq) score_addend(p, b, h, i0, lane, add);
+    AddendRaw araw;                                  // requested with the tiles, combined once they are in LDS: one round trip
+    if (i0 < p.Tq) score_addend_load(p, b, h, i0, lane, araw);
     {
         TileRegs rq, rk, rv;
         tile_load(p.q + b * p.q_sb + (long long)h * p.dk, p.q_st, p.Tq, p.dk, tid, rq);
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     }
     __syncthreads();
     if (i0 >= p.Tq) return;
+    score_addend_finish(p, i0, lane, araw, add);
     attn_fwd_rows<DK64>(p, Qs, Ks, Vs, b, h, i0, lane, add);
 }
 
@@ -94,15 +96,23 @@ __device__ __forceinline__ void attn_bwd_rows(const AttnArgs& p, const bf16_t* Q
         }
     }
     dsum = quad_lane_sum(dsum);
+    const bool vdb = p.dbias && (p.bias_k & 3) == 0 && (p.Tk & 3) == 0 && (reinterpret_cast<uintptr_t>(p.dbias) & 15) == 0;     // one 16-byte store per key block
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
+    for (int jb = 0; jb < 4; ++jb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            ds[jb][r] = pr[jb][r] * (dp[jb][r] - dsum);
-            const int j = jb * 16 + g * 4 + r;
-            if (p.dbias && i < p.bias_q && j < p.bias_k && i < p.Tq && j < p.Tk)
-                p.dbias[(((size_t)b * p.H + h) * p.bias_q + i) * p.bias_k + j] = ds[jb][r];
+        for (int r = 0; r < 4; ++r) ds[jb][r] = pr[jb][r] * (dp[jb][r] - dsum);
+        const int j0 = jb * 16 + g * 4;
+        float* drow = p.dbias ? p.dbias + (((size_t)b * p.H + h) * p.bias_q + i) * p.bias_k : nullptr;
+        if (vdb) {
+            if (i < p.bias_q && i < p.Tq && j0 < p.bias_k && j0 < p.Tk) *reinterpret_cast<float4*>(drow + j0) = make_float4(ds[jb][0], ds[jb][1], ds[jb][2], ds[jb][3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + r;
+                if (p.dbias && i < p.bias_q && j < p.bias_k && i < p.Tq && j < p.Tk) drow[j] = ds[jb][r];
+            }
         }
+    }
     // dQ[i][d] = sum_j dS[i][j] K[j][d]   (K^T gathered from the natural K tile with transpose reads)
     bf16x8_t dsf[2] = {pack_slots(ds[0], ds[1]), pack_slots(ds[2], ds[3])};
 #pragma unroll
@@ -173,9 +183,18 @@ __device__ __forceinline__ void attn_bwd_keys(const AttnArgs& p, const bf16_t* P
     }
 }
 
+// -DATTN_TIMELINE (debug builds, tools/attn_bwd_timeline.py): wave 0 of every workgroup stamps the shader clock at the phase boundaries
+#ifdef ATTN_TIMELINE
+static __device__ long long* g_attn_tl = nullptr;
+extern "C" int vlt5dbg_set_attn_timeline(long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_tl), &buf, sizeof buf); }
+#define ATL(i) do { if (g_attn_tl && threadIdx.x == 0) g_attn_tl[(size_t)blockIdx.x * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define ATL(i) do { } while (0)
+#endif
 template <bool DK64>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    ATL(0);
     bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + TILE_BYTES);
     bf16_t* Vs = reinterpret_cast<bf16_t*>(smem + 2 * TILE_BYTES);
@@ -187,10 +206,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
     const long long hoff = (long long)h * p.dk;
     float add[4][4];
     float lse_row = 0.f;
+    // every load of the workgroup is requested before anything waits: the addend words and the saved log-sum-exp first (combined after
+    // the tiles are in LDS), then the four tiles -- one round trip instead of two
+    vlt5attn::AddendRaw araw;
     if (wave * 16 < p.Tq) {
-        score_addend(p, b, h, wave * 16, lane, add);
+        score_addend_load(p, b, h, wave * 16, lane, araw);
         const int ir = wave * 16 + (lane & 15);
-        if (ir < p.Tq) lse_row = p.lse[((size_t)b * p.H + h) * p.Tq + ir];
+        lse_row = p.lse[((size_t)b * p.H + h) * p.Tq + min(ir, p.Tq - 1)];
     }
     {
         TileRegs rq, rk, rv, ro;
@@ -198,23 +220,33 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
         tile_load(p.k + b * p.k_sb + hoff, p.k_st, p.Tk, p.dk, tid, rk);
         tile_load(p.v + b * p.v_sb + hoff, p.v_st, p.Tk, p.dk, tid, rv);
         tile_load(p.d_ctx + b * p.do_sb + hoff, p.do_st, p.Tq, p.dk, tid, ro);
+        ATL(1);
         tile_store(Qs, tid, rq);
         tile_store(Ks, tid, rk);
         tile_store(Vs, tid, rv);
         tile_store(dOs, tid, ro);
     }
     __syncthreads();
+    ATL(2);
     const int i0 = wave * 16;
+    if (i0 < p.Tq) score_addend_finish(p, i0, lane, araw, add);
     float pd[4][4], ds[4][4];
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pd[jb][r] = 0.f; ds[jb][r] = 0.f; }
     if (i0 < p.Tq) attn_bwd_rows<DK64>(p, Qs, Ks, Vs, dOs, b, h, i0, lane, add, lse_row, pd, ds);      // wave-uniform
+    ATL(3);
     __syncthreads();                     // every wave is done with the K / V tiles -> reuse them for Pd / dS
     attn_bwd_put(Ps, dSs, i0, lane, pd, ds);
     __syncthreads();
+    ATL(4);
     if (wave * 16 < p.Tk) attn_bwd_keys<DK64>(p, Ps, dSs, dOs, Qs, b, h, wave * 16, lane);              // wave w owns key rows 16w..
+    ATL(5);
+#ifdef ATTN_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATL(6);
+#endif
 }
 
 // (Tried and removed, round 2: few-query variants for the decoder (Tq <= 16) in which a WAVE owns a (batch, head), stages its own
