@@ -32,8 +32,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int i0 = wave * 16;
     float add[4][4];
-    AddendRaw araw;                                  // requested with the tiles, combined once they are in LDS: one round trip
-    if (i0 < p.Tq) score_addend_load(p, b, h, i0, lane, araw);
+    if (i0 < p.Tq) score_addend(p, b, h, i0, lane, add);
     {
         TileRegs rq, rk, rv;
         tile_load(p.q + b * p.q_sb + (long long)h * p.dk, p.q_st, p.Tq, p.dk, tid, rq);
@@ -45,7 +44,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     }
     __syncthreads();
     if (i0 >= p.Tq) return;
-    score_addend_finish(p, i0, lane, araw, add);
     attn_fwd_rows<DK64>(p, Qs, Ks, Vs, b, h, i0, lane, add);
 }
 
@@ -96,23 +94,15 @@ __device__ __forceinline__ void attn_bwd_rows(const AttnArgs& p, const bf16_t* Q
         }
     }
     dsum = quad_lane_sum(dsum);
-    const bool vdb = p.dbias && (p.bias_k & 3) == 0 && (p.Tk & 3) == 0 && (reinterpret_cast<uintptr_t>(p.dbias) & 15) == 0;     // one 16-byte store per key block
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
+    for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ds[jb][r] = pr[jb][r] * (dp[jb][r] - dsum);
-        const int j0 = jb * 16 + g * 4;
-        float* drow = p.dbias ? p.dbias + (((size_t)b * p.H + h) * p.bias_q + i) * p.bias_k : nullptr;
-        if (vdb) {
-            if (i < p.bias_q && i < p.Tq && j0 < p.bias_k && j0 < p.Tk) *reinterpret_cast<float4*>(drow + j0) = make_float4(ds[jb][0], ds[jb][1], ds[jb][2], ds[jb][3]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = j0 + r;
-                if (p.dbias && i < p.bias_q && j < p.bias_k && i < p.Tq && j < p.Tk) drow[j] = ds[jb][r];
-            }
+        for (int r = 0; r < 4; ++r) {
+            ds[jb][r] = pr[jb][r] * (dp[jb][r] - dsum);
+            const int j = jb * 16 + g * 4 + r;
+            if (p.dbias && i < p.bias_q && j < p.bias_k && i < p.Tq && j < p.Tk)
+                p.dbias[(((size_t)b * p.H + h) * p.bias_q + i) * p.bias_k + j] = ds[jb][r];
         }
-    }
     // dQ[i][d] = sum_j dS[i][j] K[j][d]   (K^T gathered from the natural K tile with transpose reads)
     bf16x8_t dsf[2] = {pack_slots(ds[0], ds[1]), pack_slots(ds[2], ds[3])};
 #pragma unroll
@@ -183,7 +173,11 @@ __device__ __forceinline__ void attn_bwd_keys(const AttnArgs& p, const bf16_t* P
     }
 }
 
-// -DATTN_TIMELINE (debug builds, tools/attn_bwd_timeline.py): wave 0 of every workgroup stamps the shader clock at the phase boundaries
+// -DATTN_TIMELINE (debug builds, tools/attn_bwd_timeline.py): wave 0 of every workgroup stamps the shader clock at the phase boundaries.
+// (Round 4, measured and NOT kept: the addend words as 16-byte loads, dbias as 16-byte stores and every load of the workgroup requested
+// before the first wait take this kernel from 43.9 k to 32.6 k cycles per workgroup at the encoder shape when it is launched alone on
+// warm buffers -- and from 14.3 to 14.9-15.1 us per launch inside the step, where its operands come cold from HBM and 960 small
+// workgroups already hide the round trips; the extra live registers cost more.  profiles/r04_j_attn_bwd_timeline.txt)
 #ifdef ATTN_TIMELINE
 static __device__ long long* g_attn_tl = nullptr;
 extern "C" int vlt5dbg_set_attn_timeline(long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_tl), &buf, sizeof buf); }
@@ -206,13 +200,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
     const long long hoff = (long long)h * p.dk;
     float add[4][4];
     float lse_row = 0.f;
-    // every load of the workgroup is requested before anything waits: the addend words and the saved log-sum-exp first (combined after
-    // the tiles are in LDS), then the four tiles -- one round trip instead of two
-    vlt5attn::AddendRaw araw;
     if (wave * 16 < p.Tq) {
-        score_addend_load(p, b, h, wave * 16, lane, araw);
+        score_addend(p, b, h, wave * 16, lane, add);
         const int ir = wave * 16 + (lane & 15);
-        lse_row = p.lse[((size_t)b * p.H + h) * p.Tq + min(ir, p.Tq - 1)];
+        if (ir < p.Tq) lse_row = p.lse[((size_t)b * p.H + h) * p.Tq + ir];
     }
     {
         TileRegs rq, rk, rv, ro;
@@ -229,7 +220,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
     __syncthreads();
     ATL(2);
     const int i0 = wave * 16;
-    if (i0 < p.Tq) score_addend_finish(p, i0, lane, araw, add);
     float pd[4][4], ds[4][4];
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)

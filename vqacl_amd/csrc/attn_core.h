@@ -104,29 +104,13 @@ __device__ __forceinline__ void score_addend_load(const AttnArgs& p, int b, int 
     const float* row = hb ? p.bias + ((size_t)h * p.bias_q + min(i, p.bias_q - 1)) * p.bias_k : reinterpret_cast<const float*>(p.q);
     const float* mrow = hm ? p.key_mask + (size_t)b * p.Tk : reinterpret_cast<const float*>(p.q);
     const int bk1 = hb ? p.bias_k - 1 : 0, mk1 = hm ? p.Tk - 1 : 0;
-    // a lane's four words of a key block are consecutive: one 16-byte load each where the rows allow it (row length a multiple of 4 words,
-    // 16-byte aligned base) -- a wave-level gather costs the texture-address unit ~50 cycles whatever its width, and with 16 waves per
-    // CU issuing 32 of them each the addend requests alone were 40 % of the encoder's attention backward (profiles/r04_attn_bwd_timeline.txt)
-    const bool vb = hb && (p.bias_k & 3) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;                 // wave-uniform
-    const bool vm = hm && (p.Tk & 3) == 0 && (reinterpret_cast<uintptr_t>(p.key_mask) & 15) == 0;
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-        const int j0 = jb * 16 + g * 4;
-        if (vb) {
-            const float4 t = *reinterpret_cast<const float4*>(row + (j0 + 3 <= bk1 ? j0 : 0));      // (a quad is inside or outside as a whole)
-            raw.bv[jb][0] = t.x; raw.bv[jb][1] = t.y; raw.bv[jb][2] = t.z; raw.bv[jb][3] = t.w;
-        } else {
+    for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) raw.bv[jb][r] = row[min(j0 + r, bk1)];
+        for (int r = 0; r < 4; ++r) {
+            raw.bv[jb][r] = row[min(jb * 16 + g * 4 + r, bk1)];
+            raw.mv[jb][r] = mrow[min(jb * 16 + g * 4 + r, mk1)];
         }
-        if (vm) {
-            const float4 t = *reinterpret_cast<const float4*>(mrow + (j0 + 3 <= mk1 ? j0 : 0));
-            raw.mv[jb][0] = t.x; raw.mv[jb][1] = t.y; raw.mv[jb][2] = t.z; raw.mv[jb][3] = t.w;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) raw.mv[jb][r] = mrow[min(j0 + r, mk1)];
-        }
-    }
 }
 __device__ __forceinline__ void score_addend_finish(const AttnArgs& p, int i0, int lane, const AddendRaw& raw, float (&add)[4][4]) {
     const int lr = lane & 15, g = lane >> 4, i = i0 + lr;
