@@ -597,26 +597,8 @@ def main():
         out["launcher"] = "bench.py" if os.environ.get("LOCAL_WORLD_SIZE") and "TORCHELASTIC_RUN_ID" not in os.environ else "external"
     solo = rank == 0 and world == 1 and not distributed
 
-    if not args.no_roofline:
-        # in-situ roofline of the dominant kernel family: real steps, every GEMM dispatch timed.  Under data parallelism EVERY rank
-        # runs the same extra steps (their collectives have to pair up); rank 0's records are the ones reported
-        roof = insitu_gemm_roofline(lambda i: step_store(n_total + i), 8)
-        if rank == 0:
-            out["roofline"] = roof
-    if solo and "roofline" in out:
-        tr = trace_roofline(out["roofline"]["gflop_per_launch"] * out["roofline"]["launches_per_step"])
-        if tr:
-            out["roofline"].update(tr)
-        pmc = committed_profile("pmc_hbm_traffic.json")
-        if pmc:           # HBM bytes per GEMM launch from the committed PMC passes (tagged with the build they were taken with; not measured in this run)
-            g = [r for r in json.load(open(pmc)) if any(k in r.get("kernel", "") for k in ("gemm_kernel", "skinny_kernel", "qkv_attn_fwd", "dec_attn_fwd_kernel"))]
-            meta = [r for r in json.load(open(pmc)) if "source_sha16" in r]
-            from vqacl_amd.build import source_hash
-            if g:
-                out["roofline"]["traffic"] = round(sum(r["calls"] * r["hbm_mb"] for r in g) / sum(r["calls"] for r in g) * 1e6)
-                out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"
-                out["roofline"]["traffic_build_matches"] = bool(meta and meta[0]["source_sha16"] == source_hash())
-
+    # (the side values run BEFORE the event-timed roofline pass: once a dispatch has carried timing events the runtime keeps the queue in its
+    # profiling mode, launches get slower on the host side and the launch-bound decode loop measured 0.62 instead of 0.57 ms per token-step)
     if solo and not args.no_side_values:
         resident = {k: v.to(dev) for k, v in synthetic_batch(B, L, V, T, seed=66666).items()}
 
@@ -678,10 +660,30 @@ def main():
                          "ms_per_token_step": round((t20 - t2) / 18, 4), "tokens_per_sec": round(B * 19 / (t20 * 1e-3), 1),
                          "weight_bytes_per_token_step": int(2 * (12 * 7077888 + 32200 * 768)),
                          "weight_gb_per_s": round(2 * (12 * 7077888 + 32200 * 768) / ((t20 - t2) / 18 * 1e-3) / 1e9, 1)}
-        if "roofline" in out:
-            warm, warm_ms = time_gemms_warm(cfg, B, L, V, T, dev)
-            out["roofline"]["frac_warm"] = round(warm / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)
-            out["roofline"]["gemm_ms_per_step_warm_replay"] = round(warm_ms, 3)
+    if not args.no_roofline:
+        # in-situ roofline of the dominant kernel family: real steps, every GEMM dispatch timed.  Under data parallelism EVERY rank
+        # runs the same extra steps (their collectives have to pair up); rank 0's records are the ones reported
+        roof = insitu_gemm_roofline(lambda i: step_store(n_total + i), 8)
+        if rank == 0:
+            out["roofline"] = roof
+    if solo and "roofline" in out:
+        tr = trace_roofline(out["roofline"]["gflop_per_launch"] * out["roofline"]["launches_per_step"])
+        if tr:
+            out["roofline"].update(tr)
+        pmc = committed_profile("pmc_hbm_traffic.json")
+        if pmc:           # HBM bytes per GEMM launch from the committed PMC passes (tagged with the build they were taken with; not measured in this run)
+            g = [r for r in json.load(open(pmc)) if any(k in r.get("kernel", "") for k in ("gemm_kernel", "skinny_kernel", "qkv_attn_fwd", "dec_attn_fwd_kernel"))]
+            meta = [r for r in json.load(open(pmc)) if "source_sha16" in r]
+            from vqacl_amd.build import source_hash
+            if g:
+                out["roofline"]["traffic"] = round(sum(r["calls"] * r["hbm_mb"] for r in g) / sum(r["calls"] for r in g) * 1e6)
+                out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"
+                out["roofline"]["traffic_build_matches"] = bool(meta and meta[0]["source_sha16"] == source_hash())
+
+    if solo and not args.no_side_values and "roofline" in out:
+        warm, warm_ms = time_gemms_warm(cfg, B, L, V, T, dev)
+        out["roofline"]["frac_warm"] = round(warm / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)
+        out["roofline"]["gemm_ms_per_step_warm_replay"] = round(warm_ms, 3)
     if solo and not args.no_parity:
         out["parity"] = parity_vs_oracle(model, dev, B)
     if solo and not args.no_cpu_baseline:
