@@ -130,6 +130,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             }
         }
     };
+    // dy handed over as split-K slabs of the producing GEMM (the decoder's 400-row launches): slabs 1..3 are requested together with the
+    // row -- into the registers of the row read-ahead, which such launches do not use -- instead of one dependent round trip per slab and
+    // column chunk behind the first wait (nslabs = 4: nine in a row, half of the kernel's 9 us)
+    auto load_slabs = [&](int row, float4 (&s1)[LN_MAXCH], float4 (&s2)[LN_MAXCH], float4 (&s3)[LN_MAXCH]) {
+        const float* gr = dy + (size_t)remap_row(row, group, gstride) * d;
+#pragma unroll
+        for (int k = 0; k < LN_MAXCH; ++k) {
+            const int c = lane * 4 + k * 256;
+            if (c < d) {
+                s1[k] = *reinterpret_cast<const float4*>(gr + (size_t)slab_stride + c);
+                if (nslabs > 2) s2[k] = *reinterpret_cast<const float4*>(gr + 2 * (size_t)slab_stride + c);
+                if (nslabs > 3) s3[k] = *reinterpret_cast<const float4*>(gr + 3 * (size_t)slab_stride + c);
+            }
+        }
+    };
     const int stride = gridDim.x * 4;
     int row = blockIdx.x * 4 + wave;
     float4 xv[LN_MAXCH], gv[LN_MAXCH], qv[LN_MAXCH], xn[LN_MAXCH], gn[LN_MAXCH], qn[LN_MAXCH];
@@ -138,6 +153,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         const int nxt = row + stride;
         const bool ahead = nslabs == 1 && nxt < rows;           // (with slabs a wave has one row: few-row launches)
         if (ahead) load_row(nxt, xn, gn, qn);
+        if (nslabs > 1) load_slabs(row, xn, gn, qn);
         const float rs = rstd[row];
         float s = 0.f;
 #pragma unroll
@@ -145,9 +161,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             int c = lane * 4 + k * 256;
             if (c < d) {
                 float4 t = gv[k];
-                if (nslabs > 1) {          // dy handed over as split-K slabs of the producing GEMM: fixed-order sum, 4 loads in flight
+                if (nslabs > 1) {          // fixed-order sum over the slabs: 1..3 are in registers, the rest 4 loads at a time
                     const float* gr = dy + (size_t)remap_row(row, group, gstride) * d + c;
-                    int sl = 1;
+                    t.x += xn[k].x; t.y += xn[k].y; t.z += xn[k].z; t.w += xn[k].w;
+                    if (nslabs > 2) { t.x += gn[k].x; t.y += gn[k].y; t.z += gn[k].z; t.w += gn[k].w; }
+                    if (nslabs > 3) { t.x += qn[k].x; t.y += qn[k].y; t.z += qn[k].z; t.w += qn[k].w; }
+                    int sl = 4;
                     for (; sl + 3 < nslabs; sl += 4) {
                         const float* q = gr + (size_t)sl * slab_stride;
                         const float4 u0 = *reinterpret_cast<const float4*>(q);
