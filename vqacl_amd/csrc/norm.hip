@@ -25,14 +25,34 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const float* xr = x + (size_t)row * d;
     float ss = 0.f;
     float4 xv[8];                                   // this lane's slice of the row (d <= 2048), read from HBM once
+    // SLABS (the decoder's 400-row launches, one row per wave): every load of the row -- slab 0, slabs 1..3, the residual, the norm weight --
+    // is requested before the first wait; a slab loop with a wait per iteration and column chunk, the residual behind it and the weight
+    // behind the row reduction were up to a dozen dependent round trips in a kernel that moves 12 KB per wave
+    float4 s1[SLABS ? 8 : 1], s2[SLABS ? 8 : 1], s3[SLABS ? 8 : 1], rv[SLABS ? 8 : 1], wv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = lane * 4 + k * 256;
+        if (c < d) {
+            xv[k] = *reinterpret_cast<const float4*>(xr + c);
+            if (SLABS) {
+                if (nslabs > 1) s1[k] = *reinterpret_cast<const float4*>(xr + (size_t)slab_stride + c);
+                if (nslabs > 2) s2[k] = *reinterpret_cast<const float4*>(xr + 2 * (size_t)slab_stride + c);
+                if (nslabs > 3) s3[k] = *reinterpret_cast<const float4*>(xr + 3 * (size_t)slab_stride + c);
+                rv[k] = *reinterpret_cast<const float4*>(resid + (size_t)row * d + c);
+            }
+            wv[k] = *reinterpret_cast<const float4*>(w + c);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         int c = lane * 4 + k * 256;
         if (c < d) {
-            xv[k] = *reinterpret_cast<const float4*>(xr + c);
             if (SLABS) {
-                int sl = 1;
-                for (; sl + 3 < nslabs; sl += 4) {            // four slab loads in flight, summed in slab order
+                if (nslabs > 1) { xv[k].x += s1[k].x; xv[k].y += s1[k].y; xv[k].z += s1[k].z; xv[k].w += s1[k].w; }
+                if (nslabs > 2) { xv[k].x += s2[k].x; xv[k].y += s2[k].y; xv[k].z += s2[k].z; xv[k].w += s2[k].w; }
+                if (nslabs > 3) { xv[k].x += s3[k].x; xv[k].y += s3[k].y; xv[k].z += s3[k].z; xv[k].w += s3[k].w; }
+                int sl = 4;
+                for (; sl + 3 < nslabs; sl += 4) {            // (more than four slabs) four slab loads in flight, summed in slab order
                     const float* q = xr + (size_t)sl * slab_stride + c;
                     const float4 u0 = *reinterpret_cast<const float4*>(q);
                     const float4 u1 = *reinterpret_cast<const float4*>(q + slab_stride);
@@ -54,7 +74,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                     xv[k].z = kp[2] ? xv[k].z * rsc : 0.f;
                     xv[k].w = kp[3] ? xv[k].w * rsc : 0.f;
                 }
-                const float4 r = *reinterpret_cast<const float4*>(resid + (size_t)row * d + c);
+                const float4 r = rv[k];
                 xv[k].x += r.x; xv[k].y += r.y; xv[k].z += r.z; xv[k].w += r.w;
                 *reinterpret_cast<float4*>(xsum + (size_t)row * d + c) = xv[k];
             }
@@ -71,7 +91,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const int c = lane * 4 + k * 256;
         if (c >= d) continue;
         float4 v = xv[k];
-        float4 g = *reinterpret_cast<const float4*>(w + c);
+        float4 g = wv[k];
         float o[4] = {g.x * (v.x * rs), g.y * (v.y * rs), g.z * (v.z * rs), g.w * (v.w * rs)};
         if (thr) {
             bool kp[4];
