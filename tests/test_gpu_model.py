@@ -610,8 +610,9 @@ def test_loading_weights_after_an_optimizer_step_refreshes_the_bf16_shadow(dev, 
     assert fwd_err(pa) < 1e-2
 
 
+@pytest.mark.parametrize("variant", ["relu", "gated-gelu", "one-row", "folded-norm", "wide-heads"])
 @pytest.mark.parametrize("fast", [True, False], ids=["decode-kernels", "tiled-path"])
-def test_incremental_decoder_step_matches_full_decoder_logits(dev, fast):
+def test_incremental_decoder_step_matches_full_decoder_logits(dev, fast, variant):
     """vlt5_decoder_step (one token, key/value cache) reproduces the logits the full decoder computes for the same prefix:
     position t of a teacher-forced forward == step t of the incremental decoder fed the same inputs -- through the decode kernels
     (csrc/decode.hip, the default) and through the tiled launches of the training path (vlt5_tuning.decode_fast off)."""
@@ -620,10 +621,17 @@ def test_incremental_decoder_step_matches_full_decoder_logits(dev, fast):
     from vqacl_amd import _lib as L
     from vqacl_amd._lib import check, lib, ptr, stream_ptr
     from vqacl_amd import ops
-    ocfg = R.tiny_cfg()
+    # variants: the t5-v1.1 gated FFN (the decode path's u -> glu launch), a single row (one ragged row block), the norms folded into
+    # the projections instead of split between two launches (vlt5_tuning.decode_split_norm off), d_kv = 32 (two lanes per key in the core)
+    if variant != "relu" and not fast and variant in ("folded-norm",):
+        pytest.skip("a switch of the decode kernels only")
+    ocfg = R.tiny_cfg(gated_act=True) if variant == "gated-gelu" else (R.tiny_cfg(d_kv=32, num_heads=2) if variant == "wide-heads" else R.tiny_cfg())
     params = R.init_params(ocfg, seed=43)
-    model = set_tuning(make_model(ocfg, params, dev), dict(decode_fast=fast))
-    batch = R.synthetic_batch(ocfg, B=5, L=9, V=36, T=6, seed=14)
+    tune = dict(decode_fast=fast)
+    if variant == "folded-norm":
+        tune["decode_split_norm"] = False
+    model = set_tuning(make_model(ocfg, params, dev), tune)
+    batch = R.synthetic_batch(ocfg, B=1 if variant == "one-row" else 5, L=9, V=36, T=6, seed=14)
     model.train()
     model.train_step(batch, 0, 0.5, 0.3)          # populate the prototypes
     model.eval()
@@ -661,7 +669,7 @@ def test_incremental_decoder_step_matches_full_decoder_logits(dev, fast):
             check(lib().vlt5_decoder_step(C.byref(c), C.byref(cs), ptr(tok), t, ptr(cache), ptr(logits), ptr(nxt), stream_ptr()))
             err = rel_max_err(logits, ref_logits[:, t])
             assert err < 1e-2, (t, err)
-            check_pin(f"incremental step ({'decode kernels' if fast else 'tiled path'})/logits", err, "logits")
+            check_pin(f"incremental step ({'decode kernels' if fast else 'tiled path'}){'' if variant == 'relu' else ' [' + variant + ']'}/logits", err, "logits")
             assert torch.equal(nxt, logits.argmax(dim=-1)), "argmax kernel == torch.argmax (first maximum)"
     # argument checks: training state, position beyond the cache
     st["training"] = True
