@@ -613,7 +613,7 @@ typedef struct {
 } vlt5_decode_linear_desc;
 int vlt5_decode_linear(const vlt5_decode_linear_desc* d, void* stream);
 int vlt5_decode_linear_supported(int K, int norm_folded);
-int vlt5_decode_linear_tiles(int rows, int N, int K, int norm_folded);
+int vlt5_decode_linear_tiles(int rows, int N, int K, int norm_folded);     /* norm_folded: 1 = x_f32 + norm_w, 0 = x_bf16, 2 = x_bf16 + row_ssq */
 /* attention core for ONE query per (sample, head) (Tq == 1, no dropout, no causal mask: every cached key is visible): softmax in
  * f32 over <= 64 keys, d_kv in {16, 32, 64}; vlt5_attn_desc as for vlt5_attn_fwd with q_sb the sample stride of q, k_sb == v_sb,
  * k_st == v_st, bias [H][1][bias_k] (bias_q == 1), key_mask [B][Tk]; lse is not written. */

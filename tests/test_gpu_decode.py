@@ -183,7 +183,7 @@ def test_decode_linear_norm_split_between_two_launches(dev, rows, d_model, K_in,
             extra["ob"] = ob
         if mode == "argmax":
             c.alpha = d_model ** -0.5
-            tiles = lib().vlt5_decode_linear_tiles(rows, N_out, d_model, 0 if split else 1)
+            tiles = lib().vlt5_decode_linear_tiles(rows, N_out, d_model, 2 if split else 1)
             assert tiles > 0
             pv = torch.full((rows, tiles), float("nan"), device=dev)
             pi = torch.full((rows, tiles), -1, device=dev, dtype=torch.int32)

@@ -41,6 +41,9 @@
 #ifndef DEC_CORE_NT
 #define DEC_CORE_NT 0
 #endif
+#ifndef DECLIN_VOCAB
+#define DECLIN_VOCAB 1             // 0: the vocabulary projection through declin_rows_kernel (A/B builds)
+#endif
 #ifndef DECLIN_ROWS_W_AUX
 #define DECLIN_ROWS_W_AUX DECLIN_W_AUX     // ... of the vocabulary projection (its weight is read once chip-wide)
 #endif
@@ -508,6 +511,111 @@ __global__ __launch_bounds__(256) void declin_rows_kernel(const DecLinArgs a) { 
     }
 }
 
+// The vocabulary projection of the decode step, second form (split norm: bf16 rows + partial sums of squares from the producer; <= 8 row
+// blocks).  What bounded declin_rows_kernel: 504 workgroups = two rounds per CU, each re-reading all rows (123 KB bf16 beside its 98 KB
+// weight slice) and with nothing in flight while it reduces.  Here a workgroup is RESIDENT (<= one per CU) and walks 32-column tiles:
+//   * wave w owns row block w for the whole launch: its 16 rows x K as MFMA fragments stay in registers (K / 32 x 4 VGPRs), requested once;
+//   * a tile's weight slice (32 x K bf16 = 48 KB at K = 768) is staged by all waves together, double-buffered: the pieces of tile i + 1 are
+//     requested before tile i is computed, so the 49.5 MB weight streams behind the MFMAs instead of in front of them;
+//   * no reduction split over waves: a wave reads every weight fragment of the tile (each feeds its one row block), finishes its rows
+//     itself -- rstd from the partial sums, the logits store if asked for, the first maximum of the row inside the tile -- and ONE
+//     workgroup barrier per tile orders the stage hand-over (everybody's pieces of tile i landed / everybody done with tile i - 1).
+// Tiles per row: ceil(N / 32) (vlt5_declin_vocab_tiles); tile t of workgroup b: b + t * gridDim.
+template <int KTT>                                              // K / 64
+__global__ __launch_bounds__(512) void declin_vocab_kernel(const DecLinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dl_smem[];
+    constexpr int TILE_ROWS = 32, PIECES = TILE_ROWS * KTT / 8;   // 1 KB pieces (8 weight rows x 128 B) of a tile: [kt][row / 8]
+    constexpr int STAGE_BYTES = PIECES * 1024;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int prow = lane >> 3, pchunk = (lane & 7) ^ (lane >> 3);
+    const int ppw = (PIECES + NW - 1) / NW;                       // pieces per wave (the last ones repeat piece PIECES - 1: a uniform vmcnt)
+    const int ntiles = (a.N + TILE_ROWS - 1) / TILE_ROWS;
+    int mr = w * 16 + r16;
+    const int m = mr;
+    mr = mr < a.rows ? mr : a.rows - 1;
+    // this lane's share of the row's partial sums of squares, then the row itself as fragments
+    float4 rsp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rsp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i * 16 + kq * 4 < a.rs_n) rsp[i] = *reinterpret_cast<const float4*>(a.rs_part + (size_t)mr * a.rs_n + i * 16 + kq * 4);
+    }
+    bf16x8_t fx[KTT * 2];
+    {
+        const bf16_t* xp = a.xb + (size_t)mr * a.ldx + kq * 8;
+#pragma unroll
+        for (int ks = 0; ks < KTT * 2; ++ks) fx[ks] = *reinterpret_cast<const bf16x8_t*>(xp + ks * 32);
+    }
+    auto stage_tile = [&](int tile, int buf) {                   // this wave's pieces of the tile -> stage `buf`
+        const int n_tile = tile * TILE_ROWS;
+        char* st = dl_smem + (size_t)buf * STAGE_BYTES;
+        for (int i = 0; i < ppw; ++i) {
+            int pc = w + i * NW;
+            pc = pc < PIECES ? pc : PIECES - 1;
+            const int kt = pc / (TILE_ROWS / 8), rg = pc % (TILE_ROWS / 8);
+            int n = n_tile + rg * 8 + prow;
+            n = n < a.N ? n : a.N - 1;
+            __builtin_amdgcn_global_load_lds(a.W + (size_t)n * a.K + kt * 64 + pchunk * 8, (dl_lds_ptr_t)(st + (size_t)pc * 1024), 16, 0, DECLIN_ROWS_W_AUX);
+        }
+    };
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += (rsp[i].x + rsp[i].y) + (rsp[i].z + rsp[i].w);
+    int tile = blockIdx.x, it = 0;
+    if (tile < ntiles) stage_tile(tile, 0);
+    s += __shfl_xor(s, 16, 64);                                    // (the first use of the partials: behind the first tile's requests)
+    s += __shfl_xor(s, 32, 64);
+    const float rs = a.alpha * rsqrtf(s / (float)a.K + a.eps);
+    for (; tile < ntiles; tile += gridDim.x, ++it) {
+        const int buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my pieces of this tile (and, first time, my rows) have landed
+        __syncthreads();                                         // everybody's have; everybody is done with the other stage
+        if (tile + (int)gridDim.x < ntiles) stage_tile(tile + gridDim.x, buf ^ 1);
+        const char* st = dl_smem + (size_t)buf * STAGE_BYTES;
+        f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kt = 0; kt < KTT; ++kt) {
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const int slot = (p2 * 4 + kq) ^ (r16 & 7);
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {                     // piece (kt, rg) holds weight rows rg*8 .. +7 of the tile: row f*16 + r16
+                    const bf16x8_t fw = *reinterpret_cast<const bf16x8_t*>(st + (size_t)(kt * (TILE_ROWS / 8)) * 1024 + (f * 16 + r16) * 128 + slot * 16);
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fx[kt * 2 + p2], acc[f], 0, 0, 0);
+                }
+            }
+        }
+        const int n_tile = tile * TILE_ROWS;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const float4 v = make_float4(acc[f][0] * rs, acc[f][1] * rs, acc[f][2] * rs, acc[f][3] * rs);
+            const int n0 = n_tile + f * 16 + kq * 4;
+            const bool ok = m < a.rows && n0 < a.N;
+            if (ok && a.out_f) dl_store16f(a.out_f + (size_t)m * a.ldf + n0, v);
+            if (ok) {                                              // first maximum wins: columns ascend with f, then within the quad
+                if (v.x > best) { best = v.x; bi = n0; }
+                if (v.y > best) { best = v.y; bi = n0 + 1; }
+                if (v.z > best) { best = v.z; bi = n0 + 2; }
+                if (v.w > best) { best = v.w; bi = n0 + 3; }
+            }
+        }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (a.pmax && lane < 16 && m < a.rows) {
+            const size_t slot = (size_t)m * ntiles + tile;
+            a.pmax[slot] = best;
+            a.pidx[slot] = bi;
+        }
+    }
+}
+
 typedef void (*declin_fn)(const DecLinArgs);
 template <bool AF32, int KT>
 declin_fn declin_pick_nfrag(int nfrag) {
@@ -748,6 +856,11 @@ static long long* g_declin_tl = nullptr;       // instrumented builds only (neve
 static long long g_declin_tl_stride = 0;
 extern "C" void vlt5_declin_timeline(long long* buf, long long stride_per_launch) { g_declin_tl = buf; g_declin_tl_stride = stride_per_launch; }
 #endif
+// the resident vocabulary form: bf16 rows + partial sums (split norm), a wide projection with nothing but the f32 / argmax outputs
+static bool vlt5_declin_vocab_ok(const DecLinArgs& a) {
+    const int RB = (a.rows + 15) / 16;
+    return DECLIN_VOCAB && a.xb && a.rs_part && !a.out_b && !a.resid && !a.relu && !a.nx_b && a.N >= 8192 && RB <= 8 && (a.K == 768 || a.K == 1024);
+}
 int vlt5_declin_launch(DecLinArgs a, hipStream_t st) {
     const bool af32 = a.xf != nullptr;
     if ((!a.xf && !a.xb) || !a.W || a.rows <= 0 || a.N <= 0 || (a.N & 3)) return VLT5_ERR_ARG;
@@ -762,6 +875,22 @@ int vlt5_declin_launch(DecLinArgs a, hipStream_t st) {
     a.ct_per_xcd = (a.CT + 7) / 8;
     declin_fn fn = af32 ? declin_pick<true>(kt, nfrag) : declin_pick<false>(kt, nfrag);
     if (!fn) return VLT5_ERR_ARG;
+    // the resident form of the vocabulary projection (split norm, <= 8 row blocks): see declin_vocab_kernel
+    if (vlt5_declin_vocab_ok(a)) {
+        const int ktt = a.K / 64, ntl = (a.N + 31) / 32, nwv = a.RB;
+        if (a.pmax && a.ptiles != ntl) return VLT5_ERR_ARG;
+        declin_fn fv = ktt == 12 ? &declin_vocab_kernel<12> : &declin_vocab_kernel<16>;
+        static std::atomic<unsigned long long> optin_v[2];
+        const size_t lds_v = (size_t)2 * (32 * ktt / 8) * 1024;
+        if (lds_v > 64 * 1024) {
+            const int rc = vlt5_lds_optin((const void*)fv, 160 * 1024, optin_v[ktt == 12 ? 0 : 1]);
+            if (rc) return rc;
+        }
+        int grid = ntl < 256 ? ntl : 256;
+        hipLaunchKernelGGL(fv, dim3(grid), dim3(nwv * 64), lds_v, st, a);
+        LAUNCH_CHECK();
+        return VLT5_OK;
+    }
     if (a.pmax && a.ptiles != a.CT) return VLT5_ERR_ARG;
     // the row-walking form for a wide norm-folded projection without a bf16 output (the vocabulary projection): the weight slice is
     // staged once per column tile
@@ -796,6 +925,13 @@ int vlt5_declin_launch(DecLinArgs a, hipStream_t st) {
 
 // column tiles of the vocabulary projection (= argmax partials per row) for `rows` rows of a [N, K] weight
 int vlt5_declin_tiles(int rows, int N, int K, int af32) {
+    if (af32 == 2) {                                              // bf16 rows with the norm split off (row_ssq): the resident vocabulary form where it applies
+        af32 = 0;
+        DecLinArgs t;
+        memset(&t, 0, sizeof t);
+        t.rows = rows; t.N = N; t.K = K; t.xb = reinterpret_cast<const bf16_t*>(&t); t.rs_part = reinterpret_cast<const float*>(&t);
+        if (vlt5_declin_vocab_ok(t)) return (N + 31) / 32;
+    }
     int ks, nw, nfrag;
     if (!declin_geometry(rows, N, K, af32 != 0, &ks, &nw, &nfrag)) return -1;
     return (N + 16 * nfrag - 1) / (16 * nfrag);
@@ -848,7 +984,7 @@ extern "C" int vlt5_decode_linear(const vlt5_decode_linear_desc* d, void* stream
     if (d->argmax_val || d->argmax_idx) {
         if (!d->argmax_val || !d->argmax_idx) return VLT5_ERR_ARG;
         a.pmax = d->argmax_val; a.pidx = d->argmax_idx;
-        a.ptiles = vlt5_declin_tiles(a.rows, a.N, a.K, a.xf != nullptr);
+        a.ptiles = vlt5_declin_tiles(a.rows, a.N, a.K, a.xf ? 1 : (d->row_ssq ? 2 : 0));
     }
     return vlt5_declin_launch(a, (hipStream_t)stream);
 }

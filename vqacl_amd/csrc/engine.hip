@@ -892,7 +892,7 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
     }
     // final norm + rescale + tied lm_head (+ the first maximum of every column tile)
     const bool want_ids = g.next_ids || g.done;
-    const int tiles = vlt5_declin_tiles(B, c.vocab, d, split_norm ? 0 : 1);
+    const int tiles = vlt5_declin_tiles(B, c.vocab, d, split_norm ? 2 : 1);
     float* pmax = k.w<float>(p.slab);
     int* pidx = reinterpret_cast<int*>(pmax + (size_t)B * tiles);
     if ((size_t)B * tiles * 8 > p.slab_bytes) return VLT5_ERR_ARG;
