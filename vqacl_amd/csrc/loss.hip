@@ -25,11 +25,24 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     const int r = blockIdx.x;
     const float* row = logits + (size_t)r * V;
     float m = -INFINITY, s = 0.f;
-    for (int c = threadIdx.x * 4; c < V; c += 1024) {
-        const float4 v = *reinterpret_cast<const float4*>(row + c);
-        const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-        if (mx > m) { s *= fast_exp(m - mx); m = mx; }
-        s += (fast_exp(v.x - m) + fast_exp(v.y - m)) + (fast_exp(v.z - m) + fast_exp(v.w - m));
+    // (eight quads requested before the first is consumed, same order of arithmetic: 400 workgroups are 6 waves per CU, and one dependent
+    // load per iteration made the 32 iterations of a thread 32 round trips)
+    for (int c0 = threadIdx.x * 4; c0 < V; c0 += 8 * 1024) {
+        float4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u * 1024;
+            q[u] = c < V ? *reinterpret_cast<const float4*>(row + c) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (c0 + u * 1024 < V) {
+                const float4 v = q[u];
+                const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+                if (mx > m) { s *= fast_exp(m - mx); m = mx; }
+                s += (fast_exp(v.x - m) + fast_exp(v.y - m)) + (fast_exp(v.z - m) + fast_exp(v.w - m));
+            }
+        }
     }
     const float M = block_reduce(m, true, sh);
     s = block_reduce(s * fast_exp(m - M), false, sh);          // (a thread without elements: m = -inf, s = 0 -> 0 * exp(-inf) = 0)
@@ -51,19 +64,30 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     const bool valid = (y >= 0 && y < V);
     const float w = valid ? row_w[r] * (gout ? gout[0] : 1.f) : 0.f;
     const float l = lse[r];
-    for (int c = threadIdx.x * 4; c < V; c += 1024) {
-        float4 v = *reinterpret_cast<const float4*>(row + c);
-        float o[4] = {v.x, v.y, v.z, v.w};
+    for (int c0 = threadIdx.x * 4; c0 < V; c0 += 8 * 1024) {
+        float4 q[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float p = valid ? fast_exp(o[k] - l) : 0.f;
-            if (c + k == y) p -= 1.f;
-            o[k] = p * w;
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u * 1024;
+            q[u] = c < V ? *reinterpret_cast<const float4*>(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        uint2 pk;
-        pk.x = pack_bf16x2(o[0], o[1]);
-        pk.y = pack_bf16x2(o[2], o[3]);
-        *reinterpret_cast<uint2*>(drow + c) = pk;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u * 1024;
+            if (c < V) {
+                float o[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float p = valid ? fast_exp(o[k] - l) : 0.f;
+                    if (c + k == y) p -= 1.f;
+                    o[k] = p * w;
+                }
+                uint2 pk;
+                pk.x = pack_bf16x2(o[0], o[1]);
+                pk.y = pack_bf16x2(o[2], o[3]);
+                *reinterpret_cast<uint2*>(drow + c) = pk;
+            }
+        }
     }
 }
 
