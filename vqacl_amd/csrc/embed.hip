@@ -503,7 +503,15 @@ __global__ void relbias_sum_mats_kernel(const float* __restrict__ dS, float* __r
     if (i >= n) return;
     const int m0 = blockIdx.y * per_group, m1 = min(nmat, m0 + per_group);
     float s = 0.f;
-    for (int m = m0; m < m1; ++m) s += dS[(size_t)m * n + i];
+    int m = m0;
+    for (; m + 7 < m1; m += 8) {                     // eight loads in flight, summed in matrix order
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = dS[(size_t)(m + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; m < m1; ++m) s += dS[(size_t)m * n + i];
     R[(size_t)blockIdx.y * n + i] = s;
 }
 // one workgroup per (bucket, head): lanes stride over the positions, the four waves over the partial matrices; fixed order

@@ -270,6 +270,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 __device__ __forceinline__ float strided_rows_sum(const float* __restrict__ col, size_t row_stride, int grp, int nblk) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int b = grp;
+    for (; b + 60 < nblk; b += 64) {            // sixteen loads in flight; the four sums receive their terms in the order of the loop below
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = col[(size_t)(b + 4 * u) * row_stride];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { s0 += t[u]; s1 += t[u + 1]; s2 += t[u + 2]; s3 += t[u + 3]; }
+    }
     for (; b + 12 < nblk; b += 16) {
         s0 += col[(size_t)b * row_stride];
         s1 += col[(size_t)(b + 4) * row_stride];
