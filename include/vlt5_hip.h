@@ -580,6 +580,10 @@ typedef struct {
     long long* out_tokens; long long out_ld;    /* [B, out_ld >= T]: column t + 1 receives the emitted token */
     int* done;                     /* [B] in/out: 1 once the row has emitted eos_id */
     int eos_id, pad_id;
+    int* t_dev;                    /* optional device-side step index (one int, 0 before the first step): every launch of a step reads the cache
+                                      slot / key count / output column from it and the step increments it -- `t` then only tells the first step
+                                      (t == 0: encoder-side keys | values, first input row) from the others (any t != 0), whose launches do not
+                                      depend on t: capture ONE such call in a HIP graph and replay it per token (vqa_model.greedy_generate) */
 } vlt5_greedy_desc;
 int vlt5_decoder_step_greedy(const vlt5_config* c, const vlt5_step* s, const vlt5_greedy_desc* g, void* stream);
 /* 1 if this configuration / shape / tuning record decodes through the decode kernels (vlt5_decoder_step_greedy is then available;

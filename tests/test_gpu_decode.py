@@ -441,3 +441,41 @@ def test_greedy_generate_base_model_vs_oracle_and_bookkeeping(dev):
         row, free = fa[r].tolist(), a[r].tolist()
         cut = row.index(eos) if eos in row[1:] else len(row) - 1
         assert row[:cut + 1] == free[:cut + 1] and all(x == model.cfg.pad_token_id for x in row[cut + 1:])
+
+
+def test_greedy_loop_replayed_from_a_graph_equals_the_enqueued_loop(dev):
+    """greedy_generate replays the token-step from a HIP graph (device-side step index): the same tokens as enqueueing the launches every
+    step, on repeated calls (the graph and its buffers are reused), with another batch in between, with an EOS that stops rows early, and
+    after the parameters moved (the graph is keyed by what its raw pointers come from)."""
+    R, ocfg, params, batch, model = _base_model(dev, 4242, 6, L=11, boost=8.0)
+    model.eval()
+    fb = (batch["vis_feats"], batch["boxes"])
+
+    def run(graph, eos=-1, b=batch, f=fb, n=9):
+        model.decode_graph = graph
+        return model.greedy_generate(b["input_ids"], f, max_length=n, eos_token_id=eos).clone()
+
+    ref = run(False)
+    a1, a2 = run(True), run(True)
+    assert torch.equal(ref, a1) and torch.equal(ref, a2)
+    states = model._decode_states
+    assert len(states) == 1 and next(iter(states.values()))["graph"] is not None
+    # another batch of the same shape through the same graph
+    batch2 = R.synthetic_batch(ocfg, B=6, L=11, V=36, T=5, seed=99)
+    fb2 = (batch2["vis_feats"], batch2["boxes"])
+    assert torch.equal(run(False, b=batch2, f=fb2), run(True, b=batch2, f=fb2))
+    assert torch.equal(run(True), ref), "the first batch again"
+    # an EOS some row emits early: pad afterwards, the loop may stop before max_length
+    cands = [int(v) for v in ref[:, 2].tolist() if v != model.cfg.pad_token_id]
+    if cands:
+        assert torch.equal(run(False, eos=cands[0]), run(True, eos=cands[0]))
+    # a different length is a different graph; the old one is still valid
+    assert torch.equal(run(False, n=5), run(True, n=5)) and len(model._decode_states) >= 2
+    # the parameters move: same shape key, the graph is re-captured
+    with torch.no_grad():
+        model._flat.mul_(1.0)
+        p = dict(model.named_parameters())["decoder.block.0.layer.2.DenseReluDense.wo.weight"]
+        p.add_(0.01 * torch.randn_like(p))
+    model.sync_bf16()
+    assert torch.equal(run(False), run(True))
+    model.decode_graph = True

@@ -160,7 +160,7 @@ class LmheadCeGrads(C.Structure):
 
 class GreedyDesc(C.Structure):
     _fields_ = [("tokens", vp), ("t", c_i), ("kv_cache", vp), ("logits", vp), ("next_ids", vp), ("out_tokens", vp), ("out_ld", c_ll),
-                ("done", vp), ("eos_id", c_i), ("pad_id", c_i)]
+                ("done", vp), ("eos_id", c_i), ("pad_id", c_i), ("t_dev", vp)]
 
 
 class DecodeLinearDesc(C.Structure):

@@ -25,6 +25,7 @@ struct DecLinArgs {
     // (row, 16-column fragment) -- nx_parts = N / 16 per row; the CONSUMER (bf16 A) scales its rows by rsqrt(sum_j rs_part[m][j] / K + eps)
     const float* nx_w; bf16_t* nx_b; long long ld_nx; float* nx_ssq; int nx_parts;
     const float* rs_part; int rs_n;           // rs_n a multiple of 4, <= 64
+    int* t_inc;                               // optional device-side step index incremented by this launch when it ends (t_ptr must be null)
     int RB, CT, ct_per_xcd;                   // filled by vlt5_declin_launch
     long long* tl;                            // -DDECLIN_TIMELINE builds: [workgroup][8] shader-clock stamps of wave 0 (tools/declin_timeline.py)
 };
@@ -56,5 +57,6 @@ struct DecIoArgs {
     const float* table; int d, vocab; float* emb_out;           // emb_out[b] = table[token_b] (null: skip)
     const float* nx_w; bf16_t* nx_b; float* nx_ssq; int nx_parts;    // with emb_out: bf16(row * nx_w) and the row's sum of squares (in part 0, zeros behind it)
     const float* rel_table; const int* lut; int lut_ld, tq, H; float* bias_out; int bias_ld;   // bias_out[h][j] = rel_table[lut[tq][j]][h], j <= tq
+    const int* t_ptr; int Tcap;               // optional device-side step index: out_col = tq = *t_ptr; the next input / bias row only while tq < Tcap
 };
 int vlt5_dec_io_launch(const DecIoArgs& a, int B, hipStream_t st);

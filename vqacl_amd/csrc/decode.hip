@@ -311,6 +311,7 @@ __global__ __launch_bounds__(512) void declin_kernel(const DecLinArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TLS(6);
 #endif
+    if (a.t_inc && blockIdx.x == 0 && threadIdx.x == 0) *a.t_inc += 1;          // (no workgroup of this launch reads the index: t_ptr is null)
 }
 
 // The vocabulary projection: N = 32200 columns make 504 column tiles -- enough workgroups without cutting the rows, and its 49.5 MB weight
@@ -509,6 +510,7 @@ __global__ __launch_bounds__(256) void declin_rows_kernel(const DecLinArgs a) { 
             }
         }
     }
+    if (a.t_inc && blockIdx.x == 0 && threadIdx.x == 0) *a.t_inc += 1;
 }
 
 // The vocabulary projection of the decode step, second form (split norm: bf16 rows + partial sums of squares from the producer; <= 8 row
@@ -614,6 +616,7 @@ __global__ __launch_bounds__(512) void declin_vocab_kernel(const DecLinArgs a) {
             a.pidx[slot] = bi;
         }
     }
+    if (a.t_inc && blockIdx.x == 0 && threadIdx.x == 0) *a.t_inc += 1;
 }
 
 typedef void (*declin_fn)(const DecLinArgs);
@@ -747,6 +750,8 @@ __global__ __launch_bounds__(256) void dec_io_kernel(const DecIoArgs a) {
     __shared__ int bi[4];
     __shared__ long long tok_s;
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int tq = a.t_ptr ? *a.t_ptr : a.tq, out_col = a.t_ptr ? tq : a.out_col;        // (device-side step index: see vlt5_greedy_desc.t_dev)
+    const bool emit_next = !a.t_ptr || tq < a.Tcap;
     long long tok;
     if (a.pmax) {
         float best = -INFINITY;
@@ -774,7 +779,7 @@ __global__ __launch_bounds__(256) void dec_io_kernel(const DecIoArgs a) {
                 const int was = a.done[b];
                 if (was) nxt = a.pad_id;
                 a.done[b] = was | (nxt == a.eos_id);
-                if (a.out_tokens) a.out_tokens[(size_t)b * a.out_ld + a.out_col] = nxt;
+                if (a.out_tokens) a.out_tokens[(size_t)b * a.out_ld + out_col] = nxt;
             }
             tok_s = nxt;
         }
@@ -783,7 +788,7 @@ __global__ __launch_bounds__(256) void dec_io_kernel(const DecIoArgs a) {
     } else {
         tok = a.tokens[b];
     }
-    if (a.emb_out) {                                               // next step's decoder input row (embedding lookup, eval: no dropout)
+    if (a.emb_out && emit_next) {                                  // next step's decoder input row (embedding lookup, eval: no dropout)
         long long id = tok < 0 ? 0 : (tok >= a.vocab ? a.vocab - 1 : tok);
         const float4* src = reinterpret_cast<const float4*>(a.table + (size_t)id * a.d);
         float4* dst = reinterpret_cast<float4*>(a.emb_out + (size_t)b * a.d);
@@ -806,11 +811,11 @@ __global__ __launch_bounds__(256) void dec_io_kernel(const DecIoArgs a) {
             for (int j = tid; j < a.nx_parts; j += 256) a.nx_ssq[(size_t)b * a.nx_parts + j] = j == 0 ? (qs[0] + qs[1]) + (qs[2] + qs[3]) : 0.f;
         }
     }
-    if (a.bias_out && b == 0) {                                    // bias row of query position tq against keys 0..tq: [H][bias_ld]
-        const int n = a.H * (a.tq + 1);
+    if (a.bias_out && b == 0 && emit_next) {                       // bias row of query position tq against keys 0..tq: [H][bias_ld]
+        const int n = a.H * (tq + 1);
         for (int i = tid; i < n; i += 256) {
-            const int h = i / (a.tq + 1), jk = i % (a.tq + 1);
-            a.bias_out[(size_t)h * a.bias_ld + jk] = a.rel_table[(size_t)a.lut[(size_t)a.tq * a.lut_ld + jk] * a.H + h];
+            const int h = i / (tq + 1), jk = i % (tq + 1);
+            a.bias_out[(size_t)h * a.bias_ld + jk] = a.rel_table[(size_t)a.lut[(size_t)tq * a.lut_ld + jk] * a.H + h];
         }
     }
 }
@@ -865,6 +870,7 @@ int vlt5_declin_launch(DecLinArgs a, hipStream_t st) {
     const bool af32 = a.xf != nullptr;
     if ((!a.xf && !a.xb) || !a.W || a.rows <= 0 || a.N <= 0 || (a.N & 3)) return VLT5_ERR_ARG;
     if (af32 && !a.ln_w) return VLT5_ERR_ARG;
+    if (a.t_inc && a.t_ptr) return VLT5_ERR_ARG;
     if (a.rs_part && (af32 || a.rs_n <= 0 || a.rs_n > 64 || (a.rs_n & 3) || (((uintptr_t)a.rs_part) & 15))) return VLT5_ERR_ARG;
     if (a.nx_b && (!a.nx_w || !a.nx_ssq || a.relu || a.nx_parts != a.N / 16 || (a.N & 15) || (a.ld_nx & 3))) return VLT5_ERR_ARG;
     if ((a.ldx & 7) || (a.K & 63)) return VLT5_ERR_ALIGN;

@@ -783,6 +783,10 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
     const int d = k.d, inner = k.inner, ff = k.ff, Mx = p.Mx, Sx = p.Sx, B = s.B, Tcap = s.T, Ld = c.num_decoder_layers, t = g.t;
     const int kvw = Ld * 2 * inner, Tk = t + 1;
     bf16_t* cache = (bf16_t*)g.kv_cache;
+    // device-side step index (vlt5_greedy_desc.t_dev): every launch of a step t > 0 is then independent of t on the host side -- the cache
+    // slot, the number of cached keys, the output column and the position of the next bias row are read from *t_dev, which the vocabulary
+    // projection increments when it ends -- so the caller can capture one step in a HIP graph and replay it for every later token
+    int* t_dev = g.t_dev;
     if (t == 0) {
         RC(k.wait_bucket(Ld + c.num_layers + 1));
         RC(k.wait_bucket(Ld));
@@ -847,7 +851,9 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
         const int ffw = c.gated_act ? 2 * ff : ff;
         {   // norm -> q | k | v: q to its buffer, k | v into cache slot t
             DecLinArgs a = normed(y0, D.ln_s, k.Pb + D.sqkv, 3 * inner, q, inner, 0);
-            a.split_col = inner; a.out_b2 = kc + (size_t)t * 2 * inner; a.ldo2 = (long long)Tcap * 2 * inner;
+            a.split_col = inner; a.ldo2 = (long long)Tcap * 2 * inner;
+            if (t_dev) { a.out_b2 = kc; a.t_ptr = t_dev; a.t_stride2 = 2 * inner; }
+            else a.out_b2 = kc + (size_t)t * 2 * inner;
             RC(vlt5_declin_launch(a, k.st));
         }
         {
@@ -855,6 +861,7 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
             memset(&a, 0, sizeof a);
             a.q = q; a.q_ld = inner; a.k = kc; a.v = kc + inner; a.kv_sb = (long long)Tcap * 2 * inner; a.kv_st = 2 * inner;
             a.ctx = k.w<bf16_t>(p.ctx_s[l]); a.ctx_ld = inner; a.bias = bias_t; a.bias_ld = Tcap; a.B = B; a.H = k.H; a.Tk = Tk;
+            if (t_dev) { a.t_ptr = t_dev; a.Tk = 1; }
             RC(vlt5_dec_core_launch(a, c.d_kv, k.st));
         }
         {
@@ -902,6 +909,7 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
         a.alpha = 1.0f / sqrtf((float)d);                           // tied embeddings: rescale before the vocabulary projection
         if (want_ids) { a.pmax = pmax; a.pidx = pidx; a.ptiles = tiles; }
         if (!g.logits && !want_ids) return VLT5_ERR_ARG;
+        a.t_inc = t_dev;
         RC(vlt5_declin_launch(a, k.st));
     }
     if (want_ids) {
@@ -909,7 +917,8 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
         memset(&io, 0, sizeof io);
         io.pmax = pmax; io.pidx = pidx; io.ptiles = tiles; io.next_ids = g.next_ids;
         io.done = g.done; io.eos_id = g.eos_id; io.pad_id = g.pad_id; io.out_tokens = g.out_tokens; io.out_ld = g.out_ld; io.out_col = t + 1;
-        if (chained && t + 1 < Tcap) {                              // input row and bias row of the next step
+        if (t_dev) { io.t_ptr = t_dev; io.Tcap = Tcap; }
+        if (chained && (t_dev || t + 1 < Tcap)) {                   // input row and bias row of the next step
             io.table = k.P + L.shared; io.d = d; io.vocab = c.vocab; io.emb_out = k.w<float>(p.y[0]);
             if (split_norm) { io.nx_w = k.P + L.dec[0].ln_s; io.nx_b = xn; io.nx_ssq = xn_ssq; io.nx_parts = nparts; }
             io.rel_table = k.P + L.dec_rel; io.lut = s.dec_lut; io.lut_ld = Tcap; io.tq = t + 1; io.H = k.H; io.bias_out = bias_t; io.bias_ld = Tcap;
@@ -1270,7 +1279,8 @@ extern "C" int vlt5_decoder_step(const vlt5_config* c, const vlt5_step* s, const
 }
 extern "C" int vlt5_decoder_step_greedy(const vlt5_config* c, const vlt5_step* s, const vlt5_greedy_desc* g, void* stream) {
     if (!c || !s || !g || !g->kv_cache || !g->done || !g->out_tokens) return VLT5_ERR_ARG;
-    if (g->t < 0 || g->t >= s->T || s->training || g->out_ld < g->t + 2) return VLT5_ERR_ARG;
+    if (g->t_dev) { if (s->training || g->out_ld < s->T) return VLT5_ERR_ARG; }              // (the step index lives on the device: t only says "first step or not")
+    else if (g->t < 0 || g->t >= s->T || s->training || g->out_ld < g->t + 2) return VLT5_ERR_ARG;
     if (g->t == 0 && !g->tokens) return VLT5_ERR_ARG;
     Ctx k(*c, *s, stream);
     int rc = k.check(false);

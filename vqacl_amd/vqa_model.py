@@ -115,28 +115,43 @@ class VLT5VQA(VLT5):
         poolQ, poolV = ops.proto_pool(enc_f32, S, self.L)
         self.proto.retrieve(poolQ, poolV, enc_f32, enc_b16, S)        # rows S, S+1 <- retrieved prototypes (modeling_t5_our.py:608-612)
         inner = self.cfg.num_heads * self.cfg.d_kv
-        cache = torch.empty(self.cfg.num_decoder_layers, B, Tcap, 2 * inner, device=dev, dtype=torch.bfloat16)
-        logits = torch.empty(B, self.cfg.vocab_size, device=dev, dtype=torch.float32)
-        nxt = torch.empty(B, dtype=torch.long, device=dev)
-        cur = torch.full((B,), start, dtype=torch.long, device=dev)
         if lib().vlt5_decode_fast_supported(C.byref(c), C.byref(cs)) == 1:
             # the decode kernels: HF's loop body (argmax -> pad after EOS -> done flags -> next input row) runs on the device inside the
-            # step, the host only enqueues steps and looks at the done flags every 8 tokens
-            out = torch.full((B, Tcap), pad, dtype=torch.long, device=dev)
+            # step, the step index lives on the device too (vlt5_greedy_desc.t_dev), so every step after the first is the SAME ~100
+            # launches: they are captured once per shape in a HIP graph and replayed per token -- the host enqueues one graph launch per
+            # token instead of ~100 kernels (0.3-0.45 ms of host time per step against 0.56 ms on the device: a slower host was the
+            # bound) and looks at the done flags every 8 tokens
+            ds = self._decode_state(B, Lt, V, Tcap, int(eos_token_id), int(pad))
+            cache, out, done, cur, t_dev = ds["cache"], ds["out"], ds["done"], ds["cur"], ds["t_dev"]
+            out.fill_(pad)
             out[:, 0] = start
-            done = torch.zeros(B, dtype=torch.int32, device=dev)
-            g = L.GreedyDesc()
+            done.zero_()
+            cur.fill_(start)
+            t_dev.zero_()
+            g = ds["desc"]
             g.tokens, g.kv_cache, g.out_tokens, g.out_ld, g.done = ptr(cur), ptr(cache), ptr(out), Tcap, ptr(done)
-            g.eos_id, g.pad_id = int(eos_token_id), int(pad)
+            g.eos_id, g.pad_id, g.t_dev = int(eos_token_id), int(pad), ptr(t_dev)
             steps = 0
             for t in range(Tcap - 1):
                 g.t = t
-                check(lib().vlt5_decoder_step_greedy(C.byref(c), C.byref(cs), C.byref(g), stream), "vlt5_decoder_step_greedy")
+                if t >= 2 and self.decode_graph:
+                    if ds["graph"] is None:               # (steps 0 and 1 ran directly: every lazy per-kernel set-up has happened)
+                        gr = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gr):
+                            check(lib().vlt5_decoder_step_greedy(C.byref(c), C.byref(cs), C.byref(g), stream_ptr()), "vlt5_decoder_step_greedy")
+                        ds["graph"] = gr
+                    ds["graph"].replay()
+                else:
+                    check(lib().vlt5_decoder_step_greedy(C.byref(c), C.byref(cs), C.byref(g), stream), "vlt5_decoder_step_greedy")
                 steps = t + 1
                 if (t & 7) == 7 and bool(done.all()):
                     break
-            out = out[:, :steps + 1]
+            out = out[:, :steps + 1].clone()
         else:
+            cache = torch.empty(self.cfg.num_decoder_layers, B, Tcap, 2 * inner, device=dev, dtype=torch.bfloat16)
+            logits = torch.empty(B, self.cfg.vocab_size, device=dev, dtype=torch.float32)
+            nxt = torch.empty(B, dtype=torch.long, device=dev)
+            cur = torch.full((B,), start, dtype=torch.long, device=dev)
             done = torch.zeros(B, dtype=torch.bool, device=dev)
             padv = torch.full((B,), pad, dtype=torch.long, device=dev)
             tokens = [cur]
@@ -153,6 +168,32 @@ class VLT5VQA(VLT5):
         alive = (out != eos_token_id).long().cumprod(dim=1)               # 1 until (excluding) a row's first EOS
         length = int(alive.sum(dim=1).max()) + 1                      # longest row incl. its EOS
         return out[:, :min(out.shape[1], max(length, 1))]
+
+    decode_graph = True            # replay the token-step of the decode kernels from a HIP graph (False: enqueue its launches every step)
+
+    def _decode_state(self, B, Lt, V, Tcap, eos, pad):
+        """Per-shape buffers of the greedy loop (key/value cache, emitted tokens, done flags, current input ids, the device-side step
+        index) and the captured graph of one token-step.  The graph holds raw pointers: it is keyed by everything they come from
+        (the workspace arena, the parameter buffers, the engine switches) and dropped when any of them changed."""
+        from . import _lib as L
+        key = (B, Lt, V, Tcap, eos, pad)
+        sig = (self._ws.data_ptr(), self._ws.numel(), self._flat.data_ptr(), self._flat_bf16.data_ptr(), bytes(self.tuning))
+        cache = getattr(self, "_decode_states", None)
+        if cache is None:
+            cache = self._decode_states = {}
+        ds = cache.get(key)
+        if ds is None:
+            if len(cache) >= 4:                     # a few shapes at most (the evaluator's batch size and its last, shorter batch)
+                cache.pop(next(iter(cache)))
+            dev, inner = self._device, self.cfg.num_heads * self.cfg.d_kv
+            ds = dict(cache=torch.empty(self.cfg.num_decoder_layers, B, Tcap, 2 * inner, device=dev, dtype=torch.bfloat16),
+                      out=torch.empty(B, Tcap, dtype=torch.long, device=dev), done=torch.empty(B, dtype=torch.int32, device=dev),
+                      cur=torch.empty(B, dtype=torch.long, device=dev), t_dev=torch.zeros(1, dtype=torch.int32, device=dev),
+                      desc=L.GreedyDesc(), graph=None, sig=sig)
+            cache[key] = ds
+        if ds["sig"] != sig:
+            ds["graph"], ds["sig"] = None, sig
+        return ds
 
     @torch.no_grad()
     def _greedy_generate_recompute(self, input_ids, vis_inputs, max_length=20, eos_token_id=1):
