@@ -172,25 +172,35 @@ class VLT5VQA(VLT5):
     decode_graph = True            # replay the token-step of the decode kernels from a HIP graph (False: enqueue its launches every step)
 
     def _decode_state(self, B, Lt, V, Tcap, eos, pad):
-        """Per-shape buffers of the greedy loop (key/value cache, emitted tokens, done flags, current input ids, the device-side step
-        index) and the captured graph of one token-step.  The graph holds raw pointers: it is keyed by everything they come from
-        (the workspace arena, the parameter buffers, the engine switches) and dropped when any of them changed."""
+        """Buffers of the greedy loop (key/value cache, emitted tokens, done flags, current input ids, the device-side step index: one set
+        per (B, max_length)) and the captured graph of one token-step per shape -- the evaluator pads the questions of a batch to the
+        batch's longest, so a handful of question lengths alternate: up to 16 graphs are kept.  A graph holds raw pointers: it is keyed
+        by everything they come from (its buffers, the workspace arena, the parameter buffers, the engine switches) and dropped when any
+        of them changed."""
         from . import _lib as L
+        bufs = getattr(self, "_decode_bufs", None)
+        if bufs is None:
+            bufs, self._decode_states = {}, {}
+            self._decode_bufs = bufs
+        bk = (B, Tcap)
+        if bk not in bufs:
+            if len(bufs) >= 4:
+                old = next(iter(bufs))
+                bufs.pop(old)
+                for k in [k for k in self._decode_states if (k[0], k[3]) == old]:
+                    self._decode_states.pop(k)
+            dev, inner = self._device, self.cfg.num_heads * self.cfg.d_kv
+            bufs[bk] = dict(cache=torch.empty(self.cfg.num_decoder_layers, B, Tcap, 2 * inner, device=dev, dtype=torch.bfloat16),
+                            out=torch.empty(B, Tcap, dtype=torch.long, device=dev), done=torch.empty(B, dtype=torch.int32, device=dev),
+                            cur=torch.empty(B, dtype=torch.long, device=dev), t_dev=torch.zeros(1, dtype=torch.int32, device=dev))
         key = (B, Lt, V, Tcap, eos, pad)
         sig = (self._ws.data_ptr(), self._ws.numel(), self._flat.data_ptr(), self._flat_bf16.data_ptr(), bytes(self.tuning))
-        cache = getattr(self, "_decode_states", None)
-        if cache is None:
-            cache = self._decode_states = {}
-        ds = cache.get(key)
+        ds = self._decode_states.get(key)
         if ds is None:
-            if len(cache) >= 4:                     # a few shapes at most (the evaluator's batch size and its last, shorter batch)
-                cache.pop(next(iter(cache)))
-            dev, inner = self._device, self.cfg.num_heads * self.cfg.d_kv
-            ds = dict(cache=torch.empty(self.cfg.num_decoder_layers, B, Tcap, 2 * inner, device=dev, dtype=torch.bfloat16),
-                      out=torch.empty(B, Tcap, dtype=torch.long, device=dev), done=torch.empty(B, dtype=torch.int32, device=dev),
-                      cur=torch.empty(B, dtype=torch.long, device=dev), t_dev=torch.zeros(1, dtype=torch.int32, device=dev),
-                      desc=L.GreedyDesc(), graph=None, sig=sig)
-            cache[key] = ds
+            if len(self._decode_states) >= 16:
+                self._decode_states.pop(next(iter(self._decode_states)))
+            ds = dict(bufs[bk], desc=L.GreedyDesc(), graph=None, sig=sig)
+            self._decode_states[key] = ds
         if ds["sig"] != sig:
             ds["graph"], ds["sig"] = None, sig
         return ds
