@@ -14,7 +14,7 @@ from vqacl_amd import FusedAdamW, VLT5Config, VLT5VQA, reference_param_groups  #
 from vqacl_amd.feed import FeatureStore  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-dev = torch.device("cuda", 0)
+dev = torch.device("cuda")
 B, L, V, T = 80, 20, 36, 5
 
 

@@ -91,6 +91,8 @@ class FeatureStore:
             raise _lib.Vlt5Error("FeatureStore: feat_dim must be a multiple of 8, 0 < n_boxes <= 256, capacity > 0")
         self.capacity, self.V, self.feat_dim = int(capacity), int(n_boxes), int(feat_dim)
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:       # (tensors report "cuda:0": keep comparisons by equality meaningful)
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.feats = torch.zeros(self.capacity, self.V, self.feat_dim, dtype=torch.bfloat16, device=self.device)
         self.boxes = torch.zeros(self.capacity, self.V, 4, dtype=torch.float32, device=self.device)
         self.index = {}

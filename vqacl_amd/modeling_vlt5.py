@@ -109,6 +109,15 @@ class _Embedding(nn.Embedding):
         raise RuntimeError("sub-modules of the engine-backed VLT5 hold parameters only; call the model itself")
 
 
+def _canonical_device(device):
+    """torch.device with an explicit index for CUDA ("cuda" -> the current device): tensors report "cuda:0", and the store / model checks
+    compare devices for equality."""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return d
+
+
 def to_device(t, dev, dtype=None):
     """Host -> device hand-over of a batch tensor.  A tensor in PINNED host memory is copied stream-ordered without a host wait
     (the host keeps its lead of a whole step over the device: a blocking copy queues behind the previous step's kernels and
@@ -153,7 +162,7 @@ class VLT5(nn.Module):
         self.V_L = 36
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-        self._device = torch.device(device)
+        self._device = _canonical_device(device)
         self.tokenizer = None
         self._ws = None
         self._lut_cache = {}
