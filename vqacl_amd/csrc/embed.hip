@@ -532,8 +532,17 @@ __global__ __launch_bounds__(256) void relbias_scatter_kernel(const float* __res
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int pos = pos0 + u * 64;
-            if (pos < npos && id[u] == bucket)
-                for (int g = wave; g < ngroups; g += 4) s += R[((size_t)g * H + h) * npos + pos];
+            if (pos < npos && id[u] == bucket) {
+                int g = wave;
+                for (; g + 28 < ngroups; g += 32) {              // eight of this wave's groups per round (all sixteen of 64 groups in two)
+                    float t[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) t[q] = R[((size_t)(g + 4 * q) * H + h) * npos + pos];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) s += t[q];
+                }
+                for (; g < ngroups; g += 4) s += R[((size_t)g * H + h) * npos + pos];
+            }
         }
     }
     s = wave_sum(s);
