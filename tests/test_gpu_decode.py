@@ -133,7 +133,9 @@ def test_decode_linear_vs_f32_reference(dev, rows, N, K, mode):
     (80, 768, 3072, 32200, "argmax"),    # last wo + residual -> [final norm] -> rescale -> lm_head with the per-tile argmax (row-walking kernel)
     (4, 768, 768, 32200, "argmax"),      # BASELINE configs[0] batch
     (33, 1024, 1024, 1024, "plain"),     # t5-large width: 64 partial sums per row
-    (100, 768, 768, 32200, "argmax"),    # more than one chunk of row blocks in the row-walking kernel
+    (100, 768, 768, 32200, "argmax"),    # seven row blocks: seven waves in the resident vocabulary kernel
+    (140, 768, 768, 32200, "argmax"),    # nine row blocks: the row-walking kernel on the bf16 operand, two chunks of row blocks
+    (20, 1024, 1024, 32128, "argmax"),   # t5-large width and vocabulary: the resident kernel with 16 k-tiles per row
     (5, 64, 64, 192, "plain"),           # tiny configuration
 ])
 def test_decode_linear_norm_split_between_two_launches(dev, rows, d_model, K_in, N_out, mode):
