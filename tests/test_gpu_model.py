@@ -1003,7 +1003,23 @@ def test_full_size_large_model_properties(dev):
         assert torch.isfinite(grads[0][n]).all(), n
         assert torch.equal(grads[1][n], 2 * grads[0][n]), n
         assert torch.equal(grads[2][n], grads[1][n]), n
-    del model, grads
+    del grads
+    # greedy decoding at this size goes through the decode kernels (d = 1024: 64 partial sums per row in the split norms, 16 k-tiles in
+    # the resident vocabulary projection); replayed from a graph or enqueued step by step: the same tokens; and close to the tiled path
+    import ctypes as C
+    from vqacl_amd._lib import lib
+    model.eval()
+    sub = torch.arange(8, device=dev)
+    fb = (batch["vis_feats"][sub], batch["boxes"][sub])
+    outs = {}
+    for name, fast, graph in (("graph", 2, True), ("enqueued", 2, False), ("tiled", 1, False)):
+        model.tuning.decode_fast, model.decode_graph = fast, graph
+        outs[name] = model.greedy_generate(batch["input_ids"][sub], fb, max_length=6, eos_token_id=-1).clone()
+    model.tuning.decode_fast, model.decode_graph = 0, True
+    assert len(model._decode_states) >= 1, "the decode kernels were taken"
+    assert torch.equal(outs["graph"], outs["enqueued"])
+    assert outs["tiled"].shape == outs["graph"].shape and int((outs["tiled"] == outs["graph"]).all(dim=1).sum()) >= 5      # (random weights: near-ties turn single rows)
+    del model
     torch.cuda.empty_cache()
 
 
