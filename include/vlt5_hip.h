@@ -37,7 +37,8 @@ int vlt5_abi_version(void);
 typedef struct {
     int fold_norm;          /* 1: encoder RMS norms as stand-alone launches (unfolded); 2: folded (default) */
     int fold_norm_dec;      /* 2: also fold the decoder's cross / FFN norms (default 1: off) */
-    int fused_attn;         /* 1: encoder q|k|v GEMM + attention core as separate launches; 2: the fused kernel (default) */
+    int fused_attn;         /* 1: encoder q|k|v GEMM + attention core as separate launches; 2: the fused kernel; 0 (default): the fused
+                               kernel where its grid fills the chip (B / 2 x H / 2 >= 128 workgroups), the separate launches below that */
     int fused_heads;        /* heads per workgroup of the fused encoder kernel: 1 or 2 (default 2) */
     int dec_fused;          /* 2: fused decoder attention sublayers (csrc/dec_attn.hip) in the training forward (default 1: off) */
     int enc_cut;            /* > 0: number of encoder layers whose weight gradients run in the late group (default num_layers / 2) */

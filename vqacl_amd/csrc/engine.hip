@@ -492,7 +492,13 @@ int attn_call(const Ctx& k, bool bwd, const bf16_t* q, long long q_sb, long long
 
 // the fused q|k|v projection + attention core kernel (csrc/enc_attn.hip) covers d_kv = 64, S <= 64 and
 // d_model % 64 == 0 (every T5 size); vlt5_tuning.fused_attn = 1 selects the GEMM + attention-core launches instead (A/B runs, tests)
-bool fused_attn_ok(const Ctx& k) { return k.tun.fused_attn != 1 && k.c.d_kv == 64 && k.p.S <= 64 && (k.d & 63) == 0; }
+// By default only where its grid fills the chip: a workgroup is 2 samples x 2 heads, B / 2 x H / 2 of them -- below ~128 a launch takes the
+// 26 us of ONE workgroup whatever B is, and the separate projection + core launches win (B = 4 ... 32 at 12 heads: 4.86 / 5.19 / 5.64 /
+// 6.57 ms per step against 5.01 / 5.31 / 5.80 / 6.62; B = 48, 144 workgroups: 7.16 against 7.19).  fused_attn = 2 forces it.
+bool fused_attn_ok(const Ctx& k) {
+    if (k.tun.fused_attn == 1 || k.c.d_kv != 64 || k.p.S > 64 || (k.d & 63) != 0) return false;
+    return k.tun.fused_attn == 2 || ((k.s.B + 1) / 2) * (k.H / 2) >= 128;
+}
 
 // the fused decoder attention sublayers (csrc/dec_attn.hip: projection + core + per-head output-projection slabs in one launch instead of
 // three): built and bit-checked, measured level with the three launches they replace -- vlt5_tuning.dec_fused = 2 selects them
