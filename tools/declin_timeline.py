@@ -19,6 +19,7 @@ dev = torch.device("cuda")
 torch.manual_seed(1)
 model = VLT5VQA(VLT5Config(dropout_rate=0.1), device=dev)
 model.eval()
+model.decode_graph = False          # every launch gets its own stamp block from the host side of the launch: enqueue the steps, do not replay them
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synthetic_batch(Cfg(), B=B, L=20, V=36, T=5, seed=3, task_id=0).items()}
 fb = (batch["vis_feats"], batch["boxes"])
 raw = C.CDLL(LIB_PATH)
@@ -26,7 +27,7 @@ assert hasattr(raw, "vlt5_declin_timeline"), "needs a -DDECLIN_TIMELINE build (b
 raw.vlt5_declin_timeline.argtypes = [C.c_void_p, C.c_longlong]
 for _ in range(2):
     model.greedy_generate(batch["input_ids"], fb, max_length=8, eos_token_id=-1)
-STEPS, PER_STEP, WGS = 6, 12 * 6 + 1, 2520
+STEPS, PER_STEP, WGS = 6, 12 * 6, 2520          # (the vocabulary projection runs its own kernels: no stamp block)
 buf = torch.zeros(STEPS * PER_STEP, WGS * 8, dtype=torch.int64, device=dev)
 raw.vlt5_declin_timeline(C.c_void_p(buf.data_ptr()), WGS * 8)
 model.greedy_generate(batch["input_ids"], fb, max_length=STEPS + 1, eos_token_id=-1)
