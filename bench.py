@@ -43,6 +43,10 @@ def parse_args(argv=None):
     ap.add_argument("--dp-algo", default=os.environ.get("VQACL_DP_ALGO", "auto"), help="gradient exchange of the DP wrapper (parallel.py)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run through the rank launcher and the data-parallel wrapper (RCCL) even with --gpus 1")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="dress rehearsal of the N-rank path on ONE GPU: the launcher starts --gpus N rank processes that all use cuda:0 "
+                         "and exchange gradients through gloo (RCCL cannot place two ranks on one device); the line is flagged "
+                         "\"rehearsal\": true and carries NO value -- it proves launcher, rendezvous, wrapper, events and JSON relay, not speed")
     ap.add_argument("--dry-launch", action="store_true", help="print the environment and command of every rank the launcher would start, start nothing")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="seconds before the launcher gives up on its ranks")
     return ap.parse_args(argv)
@@ -69,7 +73,7 @@ def launch_plan(args, argv, environ=None, port=None):
             raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={inherited} in the environment: the launcher that set "
                              f"WORLD_SIZE started {inherited} ranks; pass --gpus {inherited} or unset WORLD_SIZE")
         return None                                        # a rank of somebody else's launcher (torch.distributed.run)
-    if args.gpus == 1 and not (args.force_dist or environ.get("VQACL_FORCE_DIST") == "1"):
+    if args.gpus == 1 and not (args.force_dist or args.rehearsal or environ.get("VQACL_FORCE_DIST") == "1"):
         return None                                        # the plain single-process run
     if port is None:
         import socket
@@ -88,6 +92,17 @@ def launch_plan(args, argv, environ=None, port=None):
     return plan
 
 
+def profiler_preload(environ=None):
+    """The profiler tool library preloaded into this process, if any (rocprofv3 sets LD_PRELOAD / ROCP_TOOL_LIBRARIES /
+    HSA_TOOLS_LIB to its librocprofiler-sdk-tool); None otherwise."""
+    environ = os.environ if environ is None else environ
+    for var in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD"):
+        val = environ.get(var, "")
+        if "rocprof" in val.lower() or "roctracer" in val.lower():
+            return f"{var}={val}"
+    return None
+
+
 def run_launcher(args, argv):
     """Start the ranks of launch_plan(), wait, relay.  Returns the exit code of the job."""
     import subprocess
@@ -99,6 +114,15 @@ def run_launcher(args, argv):
         for env, cmd in plan:
             print(json.dumps({"env": env, "cmd": cmd}), flush=True)
         return 0
+    tool = profiler_preload()
+    if tool:
+        # a profiler's preloaded library has initialised the GPU in THIS process already: starting rank processes from it is the
+        # forbidden "program started from a GPU-initialised process" on this pool -- the profiled process has to BE the rank
+        print(f"bench.py launcher: refusing to start ranks under a preloaded profiler ({tool}).  Run the rank itself under the "
+              f"profiler: set WORLD_SIZE={args.gpus} RANK=<r> LOCAL_RANK=<r> MASTER_ADDR=127.0.0.1 MASTER_PORT=<port>"
+              + (" VQACL_FORCE_DIST=1" if args.gpus == 1 else "") + " in the environment (tools/profile_round.sh does) and put "
+              "`python3 bench.py ...` after `--`", file=sys.stderr, flush=True)
+        return 2
     procs, lines = [], []
 
     def pump(rank, stream):            # every rank's stdout: rank 0's last JSON object is the bench line, the rest goes to stderr
@@ -191,6 +215,14 @@ def synthetic_batch(B, L=20, V=36, T=5, seed=66666, task_id=0, cate_group=0, wit
     out["cate_labels"] = torch.zeros(B, N_CATE).scatter_(1, cate_ids[:, None] % N_CATE, 1.0)
     out["scores"] = torch.tensor([0.3, 0.6, 0.9, 1.0])[torch.randint(0, 4, (B,), generator=g)]
     return out
+
+
+def decode_weight_bytes(cfg):
+    """bf16 weight bytes one greedy token-step reads: per decoder layer the self-attention q|k|v and o, the cross-attention q and o
+    (cross k|v are projected once per batch, not per token), wi and wo; plus the tied embedding as the lm_head."""
+    d, inner, ff = cfg.d_model, cfg.num_heads * cfg.d_kv, cfg.d_ff
+    ffw = (3 if cfg.is_gated_act else 2) * d * ff
+    return int(2 * (cfg.num_decoder_layers * (3 * inner * d + 3 * inner * d + ffw) + cfg.vocab_size * d))
 
 
 def gemm_schedule(cfg, B, L, V, T):
@@ -349,7 +381,7 @@ def parity_vs_oracle(model, dev, B):
         r["loss_reduced"].backward()
         lo = R.train_step_loss(o["loss"], sub["target_ids"], sub["scores"])
         lo.backward()
-        res["loss_abs_err"] = abs(float(r["loss_reduced"]) - float(lo))
+        res["loss_abs_err"] = abs(float(r["loss_reduced"].detach()) - float(lo.detach()))
         worst, worst_name = 1.0, None
         named = dict(model.named_parameters())
         for k, p in oracle.P.items():
@@ -499,18 +531,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, (world, args.gpus)            # (launch_plan() refuses a WORLD_SIZE that contradicts --gpus)
-    distributed = world > 1 or args.force_dist or os.environ.get("VQACL_FORCE_DIST") == "1"   # --force-dist: the RCCL path on 1 GPU
+    rehearsal = bool(args.rehearsal)
+    distributed = world > 1 or rehearsal or args.force_dist or os.environ.get("VQACL_FORCE_DIST") == "1"   # --force-dist: the RCCL path on 1 GPU
+    if rehearsal:
+        local = 0                                          # every rank of the rehearsal shares cuda:0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        # high-priority RCCL stream: the bucket collectives must start when their gradients are ready, not queue behind the
-        # backward GEMMs of the compute stream (measured with tools/dp_overlap_probe.py: at normal priority the casts of a
-        # bucket released mid-backward only ran after backward had finished)
-        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
+        if rehearsal:
+            # gloo moves CUDA tensors through the host: slow, and that is fine -- nothing of this run is a throughput figure
+            import datetime
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=1800))
+        else:
+            # high-priority RCCL stream: the bucket collectives must start when their gradients are ready, not queue behind the
+            # backward GEMMs of the compute stream (measured with tools/dp_overlap_probe.py: at normal priority the casts of a
+            # bucket released mid-backward only ran after backward had finished)
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
 
     from vqacl_amd import VLT5VQA, VLT5Config, FusedAdamW, reference_param_groups
     from vqacl_amd.feed import FeatureStore
@@ -592,9 +632,28 @@ def main():
            "step_tflops_per_gpu": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms, 2),
            "step_frac_of_mfma_peak": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
     if distributed:
-        out["rccl_ranks_seen"] = dist.get_world_size()
+        out["rccl_ranks_seen" if not rehearsal else "ranks_seen"] = dist.get_world_size()
         out["grad_exchange"] = dp_info
         out["launcher"] = "bench.py" if os.environ.get("LOCAL_WORLD_SIZE") and "TORCHELASTIC_RUN_ID" not in os.environ else "external"
+        # after the timed region: every rank must hold the same weights (what the exchange is for).  Two checksums of the f32
+        # master per rank, all-gathered; a rank that missed a collective or applied a different update shows up here
+        flat = model.flat_params()
+        mine = torch.stack([flat.double().sum(), flat.double().abs().sum()])
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        out["weights_in_sync"] = bool(all(torch.equal(x, seen[0]) for x in seen))
+    if rehearsal:
+        # a dress rehearsal is not a measurement: N processes time-share one GPU and the gradients travel through the host
+        out["rehearsal"] = True
+        out["rehearsal_samples_per_sec"] = out["value"]
+        out["rehearsal_ms_per_step"] = out["ms_per_step"]
+        out["value"] = None
+        out["samples_per_sec_per_gpu"] = None
+        out["step_tflops_per_gpu"] = out["step_frac_of_mfma_peak"] = None
+        out["backend"] = "gloo"
+        out["config"]["parallelism"] = f"dp{world} REHEARSAL: {world} rank processes share cuda:0, collectives through gloo"
+        out["rehearsal_note"] = ("launcher -> N rank processes -> rendezvous -> DataParallelVLT5 -> store-fed train steps -> in-situ GEMM "
+                                 "timing on every rank -> JSON relay, with the real kernels; NOT a throughput figure (value is null)")
     solo = rank == 0 and world == 1 and not distributed
 
     # (the side values run BEFORE the event-timed roofline pass: once a dispatch has carried timing events the runtime keeps the queue in its
@@ -658,12 +717,12 @@ def main():
         out["decode"] = {"what": "VLT5VQA.greedy_generate (test_step), B = %d, 19 tokens per row, random weights" % B,
                          "ms_per_batch": round(t20, 3), "ms_encoder_and_first_token": round(t2, 3),
                          "ms_per_token_step": round((t20 - t2) / 18, 4), "tokens_per_sec": round(B * 19 / (t20 * 1e-3), 1),
-                         "weight_bytes_per_token_step": int(2 * (12 * 7077888 + 32200 * 768)),
-                         "weight_gb_per_s": round(2 * (12 * 7077888 + 32200 * 768) / ((t20 - t2) / 18 * 1e-3) / 1e9, 1)}
+                         "weight_bytes_per_token_step": decode_weight_bytes(cfg),
+                         "weight_gb_per_s": round(decode_weight_bytes(cfg) / ((t20 - t2) / 18 * 1e-3) / 1e9, 1)}
     if not args.no_roofline:
         # in-situ roofline of the dominant kernel family: real steps, every GEMM dispatch timed.  Under data parallelism EVERY rank
         # runs the same extra steps (their collectives have to pair up); rank 0's records are the ones reported
-        roof = insitu_gemm_roofline(lambda i: step_store(n_total + i), 8)
+        roof = insitu_gemm_roofline(lambda i: step_store(n_total + i), 2 if rehearsal else 8)
         if rank == 0:
             out["roofline"] = roof
     if solo and "roofline" in out:

@@ -353,12 +353,13 @@ def vlt5_forward(P: Dict[str, Tensor], state: PrototypeState, cfg: Cfg, *, input
                           mask.new_ones(B, enc_ext.shape[1] - input_ids.shape[1])], dim=1)
     if decoder_input_ids is None:
         decoder_input_ids = shift_right(labels, cfg)
-    seq = decoder_forward(P, decoder_input_ids, enc_ext, enc_mask, cfg, training)
-    seq = seq * (cfg.d_model ** -0.5)
+    dec_out = decoder_forward(P, decoder_input_ids, enc_ext, enc_mask, cfg, training)
+    seq = dec_out * (cfg.d_model ** -0.5)                          # rescale before the tied lm_head (:661-666)
     logits = F.linear(seq, P["shared.weight"])                     # lm_head tied to shared
+    # `decoder_last_hidden_state=decoder_outputs.last_hidden_state` (:699): the stack's output BEFORE the rescale
     out.update(logits=logits, encoder_hidden_states=hidden, encoder_attention_mask=enc_mask,
                max_idx_Q=idx_Q, max_idx_V=idx_V, loss_memory_Q=loss_mem_Q, loss_memory_V=loss_mem_V,
-               decoder_last_hidden_state=seq)
+               decoder_last_hidden_state=dec_out)
     if labels is not None:
         out["loss"] = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1),
                                       ignore_index=-100, reduction="none")

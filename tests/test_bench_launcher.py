@@ -54,6 +54,33 @@ def test_plain_single_gpu_run_and_external_launcher_are_not_relaunched():
     assert len(one) == 1 and one[0][0]["WORLD_SIZE"] == "1" and one[0][0]["VQACL_FORCE_DIST"] == "1"
 
 
+def test_rehearsal_goes_through_the_launcher_even_with_one_rank():
+    sys.path.insert(0, ROOT)
+    import bench
+    for n in (1, 2, 8):
+        argv = ["--gpus", str(n), "--rehearsal"]
+        plan = bench.launch_plan(bench.parse_args(argv), argv, environ={}, port=29998)
+        assert len(plan) == n and all("--rehearsal" in cmd for _, cmd in plan)
+        assert [e["RANK"] for e, _ in plan] == [str(r) for r in range(n)]
+
+
+def test_launcher_refuses_to_start_ranks_under_a_preloaded_profiler(monkeypatch, capfd):
+    """rocprofv3's preloaded tool library has initialised the GPU before bench.py starts: ranks must not be started from it."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.profiler_preload({}) is None and bench.profiler_preload({"LD_PRELOAD": "/usr/lib/libfoo.so"}) is None
+    assert "rocprofiler" in bench.profiler_preload({"LD_PRELOAD": "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"})
+    monkeypatch.setattr(bench, "profiler_preload", lambda environ=None: "LD_PRELOAD=/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    argv = ["--gpus", "1", "--force-dist"]
+    for k in ("WORLD_SIZE", "RANK", "VQACL_FORCE_DIST"):
+        monkeypatch.delenv(k, raising=False)
+    rc = bench.run_launcher(bench.parse_args(argv), argv)
+    out, err = capfd.readouterr()
+    assert rc == 2 and "refusing to start ranks under a preloaded profiler" in err and "VQACL_FORCE_DIST=1" in err and '"metric"' not in out
+    # a dry launch and a plain single-process run are unaffected
+    assert bench.run_launcher(bench.parse_args(["--gpus", "1"]), ["--gpus", "1"]) is None
+
+
 def test_gpus_contradicting_world_size_fails_loudly():
     res = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-launch"], env=_clean_env(WORLD_SIZE="2"), capture_output=True, text=True,
                          timeout=120)

@@ -481,3 +481,42 @@ def test_greedy_loop_replayed_from_a_graph_equals_the_enqueued_loop(dev):
     model.sync_bf16()
     assert torch.equal(run(False), run(True))
     model.decode_graph = True
+
+
+def test_failed_graph_capture_falls_back_to_enqueued_launches(dev, monkeypatch):
+    """A capture that fails (e.g. a pin-memory thread of the evaluator's loader touching the runtime inside the capture window) must not
+    abort evaluation: that shape decodes with enqueued launches -- the same kernels, so the same tokens -- and is not re-captured on every
+    call.  The capture itself is requested in thread-local error mode."""
+    import warnings
+    R, ocfg, params, batch, model = _base_model(dev, 4243, 4, L=11, boost=8.0)
+    model.eval()
+    fb = (batch["vis_feats"], batch["boxes"])
+    model.decode_graph = False
+    ref = model.greedy_generate(batch["input_ids"], fb, max_length=8, eos_token_id=-1).clone()
+    model.decode_graph = True
+    seen = {}
+    real_graph = torch.cuda.graph
+
+    class Broken:
+        def __init__(self, gr, *a, **kw):
+            seen["mode"] = kw.get("capture_error_mode")
+            seen["calls"] = seen.get("calls", 0) + 1
+
+        def __enter__(self):
+            raise RuntimeError("HIP error: operation failed due to a previous error during capture")
+
+        def __exit__(self, *a):
+            return False
+    monkeypatch.setattr(torch.cuda, "graph", Broken)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        a = model.greedy_generate(batch["input_ids"], fb, max_length=8, eos_token_id=-1).clone()
+        b = model.greedy_generate(batch["input_ids"], fb, max_length=8, eos_token_id=-1).clone()
+    assert seen == {"mode": "thread_local", "calls": 1}, seen          # one attempt per shape state, then the state stays on enqueue
+    assert any("capture of the token-step failed" in str(x.message) for x in w)
+    assert torch.equal(a, ref) and torch.equal(b, ref)
+    assert next(iter(model._decode_states.values()))["graph"] is False
+    # the real capture still works for a new shape state
+    monkeypatch.setattr(torch.cuda, "graph", real_graph)
+    c = model.greedy_generate(batch["input_ids"], fb, max_length=6, eos_token_id=-1)
+    assert torch.equal(c, ref[:, :6])

@@ -1,4 +1,4 @@
-"""Two data-parallel RANKS on ONE GPU (both processes use cuda:0, collectives through gloo on CUDA tensors): the whole
+"""Two (and four, and eight) data-parallel RANKS on ONE GPU (both processes use cuda:0, collectives through gloo on CUDA tensors): the whole
 multi-rank path of `vqacl_amd.parallel` -- weight broadcast, gradient buckets released by the engine's HIP events, the comm
 stream, the prototype-statistics all-reduce, the fused optimizer after the reduction -- runs with the real kernels and is
 compared against ONE process on the concatenated batch ("N ranks x b == 1 process x N*b").  RCCL itself cannot
@@ -54,7 +54,7 @@ def _worker(rank, world, port, q, grad_dtype, algo="allreduce", backend="gloo"):
         from vqacl_amd.parallel import DataParallelVLT5
         ocfg = R.tiny_cfg()
         params = R.init_params(ocfg, seed=77)
-        full = R.synthetic_batch(ocfg, B=8, L=12, V=36, T=4, seed=5)
+        full = R.synthetic_batch(ocfg, B=max(8, 2 * world), L=12, V=36, T=4, seed=5)     # >= 2 samples per rank (the accumulation step halves them)
         b = full["input_ids"].shape[0] // world
         mine = {k: (v[rank * b:(rank + 1) * b] if torch.is_tensor(v) else v) for k, v in full.items()}
 
@@ -87,7 +87,7 @@ def _worker(rank, world, port, q, grad_dtype, algo="allreduce", backend="gloo"):
             assert dp.params_sharded == (lazy and world > 1)
             for p in model.parameters():
                 p.grad = None
-            losses.append(float(res["loss"]))
+            losses.append(float(res["loss"].detach()))
         # a fourth step with gradient accumulation over two half batches (the non-overlapped reduction path): under zero1 it must
         # still be the sharded update -- the Adam moments of the chunks a rank does not own are stale since its first sharded step
         for half in (slice(0, b // 2), slice(b // 2, b)):
@@ -138,7 +138,7 @@ def _worker(rank, world, port, q, grad_dtype, algo="allreduce", backend="gloo"):
                 ropt.step()
                 for p in ref.parameters():
                     p.grad = None
-                rl.append(float(r["loss"]))
+                rl.append(float(r["loss"].detach()))
             for lo in (0, b // 2):        # the accumulation step: micro-batch = the same halves of every rank's samples
                 sel = torch.cat([torch.arange(r_ * b + lo, r_ * b + lo + b // 2) for r_ in range(world)])
                 part = {k: (v[sel] if torch.is_tensor(v) else v) for k, v in full.items()}
@@ -169,11 +169,11 @@ def _worker(rank, world, port, q, grad_dtype, algo="allreduce", backend="gloo"):
         q.put((rank, traceback.format_exc()))
 
 
-def _run_two(grad_dtype, algo, backend):
+def _run_two(grad_dtype, algo, backend, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, grad_dtype, algo, backend)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, grad_dtype, algo, backend)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -193,6 +193,17 @@ def _run_two(grad_dtype, algo, backend):
 def test_two_ranks_on_one_gpu_equal_one_process_on_the_concatenated_batch(grad_dtype, algo):
     assert torch.cuda.is_available()
     _run_two(grad_dtype, algo, "gloo")
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,grad_dtype,algo", [(4, "bfloat16", "zero1"), (8, "bfloat16", "zero1"), (4, "float32", "zero1"),
+                                                   (8, "bfloat16", "allreduce"), (4, "bfloat16", "rs_ag"), (8, "bfloat16", "zero1-lazy")])
+def test_four_and_eight_ranks_on_one_gpu_equal_one_process_on_the_concatenated_batch(world, grad_dtype, algo):
+    """World sizes 4 and 8 (the sizes the scaling bench runs) with the real kernels: chunk ownership of the sharded optimizer (every
+    slice cut into 4 / 8 chunks of whole 16-byte groups), parameter all-gathers ordered against the next forward, the prototype
+    statistics summed over 4 / 8 ranks -- N ranks x b samples == one process x N*b samples, and every rank ends with the same weights."""
+    assert torch.cuda.is_available()
+    _run_two(grad_dtype, algo, "gloo", world=world)
 
 
 @pytest.mark.timeout(600)

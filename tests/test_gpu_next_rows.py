@@ -123,7 +123,7 @@ def test_train_and_test_step_from_store_equal_the_f32_batch(dev):
     a = model.train_step(batch, 0, 0.5, 0.3)
     b = m2.train_step(fed, 0, 0.5, 0.3)
     assert torch.equal(a["encoder_hidden_states"], b["encoder_hidden_states"])
-    assert float(a["loss"]) == float(b["loss"])
+    assert float(a["loss"].detach()) == float(b["loss"].detach())
     a["loss"].backward()
     b["loss"].backward()
     for (n1, p1), (n2, p2) in zip(model.named_parameters(), m2.named_parameters()):

@@ -142,7 +142,7 @@ def test_module_tree_is_drop_in_on_cpu(built):
             module.bias.data.zero_()
     m.apply(init_bert_weights)
     assert float(m.flat_params()[m._pinfo["shared.weight"][0]]) == 0.5, "parameters are views of the flat buffer"
-    assert float(named["decoder.block.1.layer.2.DenseReluDense.wi.weight"][0, 0]) == 0.5
+    assert float(named["decoder.block.1.layer.2.DenseReluDense.wi.weight"].detach()[0, 0]) == 0.5
     # load_state_dict keeps the flat aliasing
     new = {k: torch.full_like(v, 0.25) for k, v in sd.items()}
     m.load_state_dict(new)

@@ -134,12 +134,13 @@ class VLT5VQA(VLT5):
             steps = 0
             for t in range(Tcap - 1):
                 g.t = t
-                if t >= 2 and self.decode_graph:
-                    if ds["graph"] is None:               # (steps 0 and 1 ran directly: every lazy per-kernel set-up has happened)
-                        gr = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(gr):
-                            check(lib().vlt5_decoder_step_greedy(C.byref(c), C.byref(cs), C.byref(g), stream_ptr()), "vlt5_decoder_step_greedy")
-                        ds["graph"] = gr
+                if t >= 2 and self.decode_graph and ds["graph"] is None:
+                    # (steps 0 and 1 ran directly: every lazy per-kernel set-up has happened.)  Capture in thread-local mode: the
+                    # reference's eval loaders run a pin-memory thread (vqa_data_memory.py:786) whose hipHostMalloc / hipEventQuery
+                    # calls would invalidate a global-mode capture.  A capture that still fails is not an evaluation failure: this
+                    # state then enqueues the step's launches every token (the same kernels, bit-identical tokens).
+                    ds["graph"] = self._capture_token_step(c, cs, g)
+                if t >= 2 and self.decode_graph and ds["graph"] is not False:
                     ds["graph"].replay()
                 else:
                     check(lib().vlt5_decoder_step_greedy(C.byref(c), C.byref(cs), C.byref(g), stream), "vlt5_decoder_step_greedy")
@@ -168,6 +169,24 @@ class VLT5VQA(VLT5):
         alive = (out != eos_token_id).long().cumprod(dim=1)               # 1 until (excluding) a row's first EOS
         length = int(alive.sum(dim=1).max()) + 1                      # longest row incl. its EOS
         return out[:, :min(out.shape[1], max(length, 1))]
+
+    def _capture_token_step(self, c, cs, g):
+        """One token-step of the decode kernels captured in a HIP graph, or False when the capture failed (the caller then enqueues
+        the launches every step).  The step that was being captured has NOT run in either case: graph capture records, it does not
+        execute, and a failed capture leaves no work behind on the stream."""
+        import ctypes as C
+        import warnings
+        from ._lib import check, lib, stream_ptr
+        gr = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                check(lib().vlt5_decoder_step_greedy(C.byref(c), C.byref(cs), C.byref(g), stream_ptr()), "vlt5_decoder_step_greedy")
+        except Exception as e:  # noqa: BLE001  (hipErrorStreamCaptureInvalidated and friends surface as RuntimeError / Vlt5Error)
+            warnings.warn(f"greedy_generate: HIP-graph capture of the token-step failed ({type(e).__name__}: {e}); "
+                          "this shape decodes with enqueued launches instead")
+            torch.cuda.synchronize()
+            return False
+        return gr
 
     decode_graph = True            # replay the token-step of the decode kernels from a HIP graph (False: enqueue its launches every step)
 
