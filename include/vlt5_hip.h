@@ -27,7 +27,7 @@ extern "C" {
 #define VLT5_OK 0
 #define VLT5_ERR_ARG 1001
 #define VLT5_ERR_ALIGN 1002
-#define VLT5_ABI_VERSION 6
+#define VLT5_ABI_VERSION 7
 
 int vlt5_abi_version(void);
 
@@ -42,7 +42,10 @@ typedef struct {
     int fused_heads;        /* heads per workgroup of the fused encoder kernel: 1 or 2 (default 2) */
     int dec_fused;          /* 2: fused decoder attention sublayers (csrc/dec_attn.hip) in the training forward (default 1: off) */
     int enc_cut;            /* > 0: number of encoder layers whose weight gradients run in the late group (default num_layers / 2) */
-    int wgrad_shadow;       /* 1: decoder weight gradients as launches of their own; 2: in the shadow of the encoder's (default) */
+    int wgrad_shadow;       /* 1: decoder weight gradients as launches of their own; 2: in the shadow of the encoder's (default; with
+                               gradient-bucket events the decoder's buckets are then signalled from the encoder phase's mid-point launch
+                               that finishes them); 3: in the shadow only without bucket events, launches of their own with them (the
+                               decoder's buckets are released at the end of the decoder phase: the round-4 behaviour) */
     int wgrad_grouped;      /* 1: the two attention weight gradients of a layer group as two launches; 2: one grouped launch (default) */
     int gemm_t128_kmkm;     /* > 0: tile-count threshold of the 128x128 tile for k-major/k-major problems (default 100) */
     int gemm_t256_km;       /* > 0: ... of the 256x256 tile for a k-major A operand (default 160) */
@@ -313,6 +316,12 @@ long long vlt5_embed_bwd_scratch_bytes(int B, int T, int d);
 int vlt5_embed_bwd(const long long* ids, const float* dout, long long sb, long long st, float* dtable,
                    int B, int T, int d, int vocab, float drop_p, uint32_t drop_seed, int drop_rows, int drop_row0, void* scratch,
                    void* stream);
+/* bf16 staging mirror of a scatter-added gradient table (the data-parallel bf16 bucket that holds `shared.weight`: its dense part is
+ * mirrored by the lm_head weight-gradient GEMM, vlt5_gemm_desc.c_bf16_copy; the rows the embedding backward added to afterwards are
+ * re-rounded here): rows ids0[0..n0), ids1[0..n1) (out-of-range ids clamp to row 0 like the lookups) and the last `tail_rows` rows
+ * (the object-order rows of VisualEmbedding, src/modeling_t5_our.py:126-133) of src f32 [vocab, d] -> dst_bf16, same offsets */
+int vlt5_mirror_rows_bf16(const float* src, void* dst_bf16, int vocab, int d, const long long* ids0, int n0, const long long* ids1,
+                          int n1, int tail_rows, void* stream);
 /* labels -> decoder input ids (HF _shift_right, called at src/modeling_t5_our.py:620) */
 int vlt5_shift_right(const long long* labels, long long* out, int B, int T, int start_id, int pad_id, void* stream);
 /* f32 [B,S] encoder mask: 1 where input_ids != pad for the L text columns, 1 for the rest (:225-232, :631-638) */
@@ -370,6 +379,11 @@ int vlt5_ce_bwd(const float* logits, const long long* labels, const float* lse, 
 int vlt5_proto_pool(const float* hidden, long long sb, int B, int S, int d, int split, float* poolQ, float* poolV, void* stream);
 /* calculate_current_prototype: proto[c] = sum_b onehot[b,c] pool[b] / max(cnt_c,1), cnt = sum_b onehot */
 int vlt5_proto_class_mean(const float* pool, const float* onehot, float* proto, float* cnt, int B, int C, int d, void* stream);
+/* data parallel (vqacl_amd/prototype.py::_allreduce_stats): the class statistics of both heads as ONE buffer for a single all-reduce,
+ * packed = [curQ * max(numQ,1) | numQ | curV * max(numV,1) | numV] ((CQ + CV) * (d + 1) floats); unpack != 0: the way back, class
+ * means over the global batch = summed sums / max(summed counts, 1), counts = summed counts */
+int vlt5_proto_stats_pack(float* curQ, float* numQ, float* curV, float* numV, float* packed, int CQ, int CV, int d, int unpack,
+                          void* stream);
 /* update_prototype state machine, all branches; see vqacl_amd/prototype.py for the host side.
  * first: 1 on the first batch of `task`.  qmem: this task's memory tensor [CQ,d] (NULL when task==0). */
 int vlt5_proto_update(const float* curQ, const float* curV, const float* numQ, const float* numV, float* Qproto,
@@ -530,6 +544,11 @@ int vlt5_feat_gather(const void* store_bf16, const float* box_store, const long 
  * [late, num_layers) mid-phase, layers [0, late) at the end; returns `late` */
 int vlt5_encoder_late_layers(int num_layers);
 int vlt5_encoder_late_layers_tuned(int num_layers, const vlt5_tuning* tuning);   /* with vlt5_tuning.enc_cut */
+/* 1: with gradient-bucket events (vlt5_step.events) and vlt5_step.defer_decoder_wgrads = 1 the decoder-layer buckets
+ * [0, num_decoder_layers) are signalled from INSIDE vlt5_encoder_bwd, at its mid-point together with the upper half of the encoder
+ * (their weight gradients ride in that phase's launches); the caller enqueues its waits for them after that call.  0: signalled at the
+ * end of vlt5_decoder_bwd.  The stacked cross-K/V bucket (index num_decoder_layers) is always signalled by vlt5_decoder_bwd. */
+int vlt5_decoder_buckets_late(const vlt5_config* c, const vlt5_tuning* tuning, int side_stream);
 /* a lowest-priority stream for vlt5_step.side_stream (hipStreamCreateWithPriority); the caller destroys it */
 int vlt5_side_stream_create(void** stream);
 int vlt5_side_stream_destroy(void* stream);

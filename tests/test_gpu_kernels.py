@@ -1106,3 +1106,40 @@ def test_fused_adamw_matches_reference_optimizer(dev):
     ref = torch.cat([P["w.weight"].detach(), P["b.bias"].detach()])
     close(p, ref, 1e-5, 1e-6, "parameters after 3 fused steps")
     close(pb, ref, 1e-2, 1e-3, "bf16 shadow")
+
+
+def test_mirror_rows_bf16_and_proto_stats_pack(dev):
+    """The two small kernels of the data-parallel path (round 5): rows of a scatter-added table re-rounded into the bf16 staging mirror
+    (listed ids incl. duplicates and out-of-range ids, which clamp to row 0 like the lookups, + the table's last rows); class statistics of
+    both prototype heads packed into one all-reduce buffer and unpacked again."""
+    from vqacl_amd._lib import check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(3)
+    vocab, d = 500, 192
+    src = torch.randn(vocab, d, generator=g).to(dev)
+    dst = torch.full((vocab, d), 7.0, dtype=torch.bfloat16, device=dev)
+    ids0 = torch.tensor([3, 3, 499, 17, -5, 1000], dtype=torch.long, device=dev)
+    ids1 = torch.tensor([[20, 21], [21, 22]], dtype=torch.long, device=dev)
+    check(lib().vlt5_mirror_rows_bf16(ptr(src), ptr(dst), vocab, d, ptr(ids0), 6, ptr(ids1), 4, 5, stream_ptr()), "vlt5_mirror_rows_bf16")
+    torch.cuda.synchronize()
+    rows = sorted({3, 499, 17, 0, 20, 21, 22} | set(range(vocab - 5, vocab)))
+    want = torch.full((vocab, d), 7.0, dtype=torch.bfloat16, device=dev)
+    want[rows] = src[rows].to(torch.bfloat16)
+    assert torch.equal(dst.view(torch.int16), want.view(torch.int16))
+    assert lib().vlt5_mirror_rows_bf16(ptr(src), ptr(dst), vocab, d, None, 2, None, 0, 0, stream_ptr()) != 0        # ids missing
+    assert lib().vlt5_mirror_rows_bf16(ptr(src), ptr(dst), vocab, d, None, 0, None, 0, vocab + 1, stream_ptr()) != 0
+    assert lib().vlt5_mirror_rows_bf16(ptr(src), ptr(dst), vocab, d, None, 0, None, 0, 0, stream_ptr()) == 0        # nothing to do
+
+    CQ, CV, dm = 10, 80, 64
+    curQ, curV = torch.randn(CQ, dm, generator=g).to(dev), torch.randn(CV, dm, generator=g).to(dev)
+    numQ = torch.tensor([0., 3., 1., 0., 7., 0., 0., 2., 0., 5.], device=dev)
+    numV = torch.randint(0, 4, (CV,), generator=g).float().to(dev)
+    packed = torch.empty((CQ + CV) * (dm + 1), device=dev)
+    q0, v0 = curQ.clone(), curV.clone()
+    check(lib().vlt5_proto_stats_pack(ptr(curQ), ptr(numQ), ptr(curV), ptr(numV), ptr(packed), CQ, CV, dm, 0, stream_ptr()), "pack")
+    want = torch.cat([(q0 * numQ.clamp(min=1)[:, None]).flatten(), numQ, (v0 * numV.clamp(min=1)[:, None]).flatten(), numV])
+    assert torch.equal(packed, want)
+    packed.mul_(2.0)                                              # what a 2-rank all-reduce of identical statistics leaves
+    check(lib().vlt5_proto_stats_pack(ptr(curQ), ptr(numQ), ptr(curV), ptr(numV), ptr(packed), CQ, CV, dm, 1, stream_ptr()), "unpack")
+    assert torch.equal(numQ, want[CQ * dm:CQ * dm + CQ] * 2) and torch.equal(numV, want[-CV:] * 2)
+    assert torch.allclose(curQ, 2 * q0 * (numQ / 2).clamp(min=1)[:, None] / numQ.clamp(min=1)[:, None], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(curV, 2 * v0 * (numV / 2).clamp(min=1)[:, None] / numV.clamp(min=1)[:, None], rtol=1e-6, atol=1e-7)

@@ -726,6 +726,12 @@ def test_data_parallel_overlap_path_on_one_gpu_and_rank_equivalence(dev):
         # a cast pass: bit-identical to rounding the f32 gradients (one rank: the all-reduce leaves it as it is)
         a = dp2.bucket_start[-1]
         assert a > 0 and torch.equal(dp2._g16[:a].view(torch.int16), g_plain[:a].to(BF).view(torch.int16))
+        # ... and so is the LAST bucket (round 5): its two dense matrices by their GEMMs, norm weights and small visual parameters by two
+        # small casts, the rows of `shared` the embedding backwards added to by vlt5_mirror_rows_bf16 -- no pass over the bucket
+        end = dp2.bucket_end[-1]
+        local = model2._flat_grad[:end]
+        assert torch.equal(dp2._g16[:end].view(torch.int16), local.to(BF).view(torch.int16)), "staging mirror != bf16(gradients)"
+        assert float(local[a:].abs().max()) > 0 and torch.allclose(local, g_plain[:end], rtol=1e-4, atol=1e-6), "the single-process step's f32 gradients"
         # with the fused optimizer the cast back is deferred: the norm / AdamW kernels read the reduced bf16 buckets themselves.
         # Same weights, bit for bit, as casting back first; .grad keeps the local f32 gradients until flat_grads() is asked.
         from vqacl_amd import FusedAdamW, reference_param_groups

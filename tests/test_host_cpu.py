@@ -26,7 +26,7 @@ def test_library_exports_every_symbol_of_the_header(built):
     for name in sorted(declared):
         assert hasattr(raw, name), f"libvlt5_hip.so does not export {name}"
     assert set(built.PROTOTYPES) == declared, (set(built.PROTOTYPES) ^ declared)
-    assert built.lib().vlt5_abi_version() == 6
+    assert built.lib().vlt5_abi_version() == 7
 
 
 def test_struct_sizes_match_the_c_side(built, tmp_path):

@@ -43,7 +43,7 @@ def make_tuning(**fields):
     for name, v in fields.items():
         if name not in kinds:
             raise ValueError(f"unknown tuning field {name!r}")
-        setattr(t, name, (2 if v else 1) if kinds[name] == "onoff" and isinstance(v, bool) else int(v))
+        setattr(t, name, (2 if v else 1) if kinds[name] == "onoff" and isinstance(v, bool) else int(v))     # (ints pass through: a third setting)
     return t
 
 
@@ -54,7 +54,7 @@ def tuning_from_env(environ=None):
     for var, (field, kind) in _TUNING_ENV.items():
         if var in environ:
             v = int(environ[var])
-            setattr(t, field, (2 if v else 1) if kind == "onoff" else v)
+            setattr(t, field, ((2 if v else 1) if v in (0, 1) else v) if kind == "onoff" else v)     # on/off: "0" / "1"; a larger value is a third setting, as is
     return t
 
 
@@ -187,6 +187,7 @@ PROTOTYPES = {
     "vlt5_layernorm_bwd_full": (c_i, [vp, c_i, c_ll, vp, vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, c_f, c_u32, vp, vp]),
     "vlt5_encoder_late_layers": (c_i, [c_i]),
     "vlt5_encoder_late_layers_tuned": (c_i, [c_i, C.POINTER(Tuning)]),
+    "vlt5_decoder_buckets_late": (c_i, [C.POINTER(Config), C.POINTER(Tuning), c_i]),
     "vlt5_side_stream_create": (c_i, [C.POINTER(vp)]),
     "vlt5_side_stream_destroy": (c_i, [vp]),
     "vlt5_feat_store_put": (c_i, [vp, vp, vp, c_i, vp, vp, c_ll, c_i, c_i, vp]),
@@ -216,6 +217,7 @@ PROTOTYPES = {
     "vlt5_embed_fwd": (c_i, [vp, vp, vp, c_ll, c_ll, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp]),
     "vlt5_embed_bwd_scratch_bytes": (c_ll, [c_i, c_i, c_i]),
     "vlt5_embed_bwd": (c_i, [vp, vp, c_ll, c_ll, vp, c_i, c_i, c_i, c_i, c_f, c_u32, c_i, c_i, vp, vp]),
+    "vlt5_mirror_rows_bf16": (c_i, [vp, vp, c_i, c_i, vp, c_i, vp, c_i, c_i, vp]),
     "vlt5_shift_right": (c_i, [vp, vp, c_i, c_i, c_i, c_i, vp]),
     "vlt5_stack_inputs_fwd": (c_i, [C.POINTER(StackInputsDesc), vp]),
     "vlt5_build_mask": (c_i, [vp, vp, c_i, c_i, c_i, c_i, vp]),
@@ -230,6 +232,7 @@ PROTOTYPES = {
     "vlt5_ce_bwd": (c_i, [vp, vp, vp, vp, vp, vp, c_i, c_i, vp]),
     "vlt5_proto_pool": (c_i, [vp, c_ll, c_i, c_i, c_i, c_i, vp, vp, vp]),
     "vlt5_proto_class_mean": (c_i, [vp, vp, vp, vp, c_i, c_i, c_i, vp]),
+    "vlt5_proto_stats_pack": (c_i, [vp, vp, vp, vp, vp, c_i, c_i, c_i, c_i, vp]),
     "vlt5_proto_update": (c_i, [vp] * 9 + [c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, vp]),
     "vlt5_proto_retrieve": (c_i, [vp, vp, vp, vp, c_ll, vp, c_ll, vp, c_i, c_i, c_i, vp]),
     "vlt5_proto_memory_loss": (c_i, [vp, vp, vp, vp, c_i, c_i, c_i, vp]),
@@ -288,7 +291,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.vlt5_abi_version() != 6:
+        if L.vlt5_abi_version() != 7:
             raise Vlt5Error("libvlt5_hip.so ABI version mismatch")
         _lib = L
     return _lib

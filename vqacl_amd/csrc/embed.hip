@@ -649,6 +649,33 @@ extern "C" int vlt5_embed_bwd(const long long* ids, const float* dout, long long
     LAUNCH_CHECK();
     return VLT5_OK;
 }
+// bf16 staging mirror of the rows of a scatter-added gradient table (data-parallel bf16 buckets): one workgroup per listed row
+__global__ __launch_bounds__(64) void mirror_rows_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int vocab, int d,
+                                                         const long long* __restrict__ ids0, int n0, const long long* __restrict__ ids1, int n1,
+                                                         int tail_rows) {
+    const int j = blockIdx.x;
+    long long row;
+    if (j < n0) row = emb_clamp(ids0[j], vocab);
+    else if (j < n0 + n1) row = emb_clamp(ids1[j - n0], vocab);
+    else row = vocab - tail_rows + (j - n0 - n1);
+    const float* s = src + (size_t)row * d;
+    bf16_t* o = dst + (size_t)row * d;
+    for (int c = threadIdx.x * 4; c < d; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(s + c);
+        *reinterpret_cast<uint2*>(o + c) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
+}
+extern "C" int vlt5_mirror_rows_bf16(const float* src, void* dst_bf16, int vocab, int d, const long long* ids0, int n0,
+                                     const long long* ids1, int n1, int tail_rows, void* stream) {
+    if (!src || !dst_bf16 || vocab < 1 || d < 4 || n0 < 0 || n1 < 0 || tail_rows < 0 || tail_rows > vocab) return VLT5_ERR_ARG;
+    if ((n0 > 0 && !ids0) || (n1 > 0 && !ids1)) return VLT5_ERR_ARG;
+    if ((d & 3) || (((uintptr_t)src) & 15) || (((uintptr_t)dst_bf16) & 7)) return VLT5_ERR_ALIGN;
+    const int rows = n0 + n1 + tail_rows;
+    if (rows == 0) return VLT5_OK;
+    hipLaunchKernelGGL(mirror_rows_kernel, dim3(rows), dim3(64), 0, ST, src, (bf16_t*)dst_bf16, vocab, d, ids0, n0, ids1, n1, tail_rows);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
 extern "C" int vlt5_shift_right(const long long* labels, long long* out, int B, int T, int start_id, int pad_id, void* stream) {
     if (!labels || !out || B <= 0 || T <= 0) return VLT5_ERR_ARG;
     hipLaunchKernelGGL(shift_right_kernel, dim3((B * T + 255) / 256), dim3(256), 0, ST, labels, out, B, T, start_id, pad_id);

@@ -469,8 +469,10 @@ struct Ctx {
 
 #define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
-int dec_wgrad(const Ctx& k, int which, vlt5_gemm_desc* desc, int lo = 0, int n = 0);
+int dec_wgrad(const Ctx& k, int which, vlt5_gemm_desc* desc, int lo = 0, int n = 0, const vlt5_gemm_desc* group = nullptr);
 bool shadow_wgrads(const Ctx& k);
+bool bucket_events(const Ctx& k);
+bool shadow_rule(const vlt5_config& c, const vlt5_tuning* t, bool events, bool side);
 
 int attn_call(const Ctx& k, bool bwd, const bf16_t* q, long long q_sb, long long q_st, const bf16_t* kk, const bf16_t* v,
               long long kv_sb, long long kv_st, bf16_t* ctx, float* lse, const float* bias, int bq, int bk, const float* kmask,
@@ -1035,7 +1037,9 @@ int decoder_bwd(const Ctx& k) {
             // cross-attention K/V projections of all layers at once
             RC(ks.lin_wgrad(k.w<bf16_t>(p.dkv_all), kvw, k.w<bf16_t>(p.enc_ext), d, k.Gr + L.cross_kv, Mx, kvw, d, 1.f, 0, true));
         }
-        for (int b = 0; b <= Ld; ++b) RC(ks.record(b));     // decoder-side gradient buckets are complete (rel-bias: before the fork)
+        // gradient buckets complete here: the stacked cross-K/V projection always; the decoder layers only when all six of their
+        // weight gradients ran above (shadowed: five of them are finished inside vlt5_encoder_bwd, which signals the buckets then)
+        for (int b = shadow_wgrads(k) ? Ld : 0; b <= Ld; ++b) RC(ks.record(b));     // (rel-bias: before the fork)
     }
     RC(vlt5_embed_bwd(ids, dx, (long long)T * d, d, k.Gr + L.shared, B, T, d, c.vocab, k.pdrop, k.seed(SITE_DEC_EMBED), T, 0,
                        k.w<void>(p.embed_scratch), k.st));
@@ -1052,28 +1056,38 @@ inline int enc_cut(int Le, int tuned = 0) {
 }
 // The six batched weight-gradient problems of the decoder stack (which: 0 FFN wo, 1 FFN wi, 2 cross o, 3 cross q, 4 self o, 5 self q|k|v):
 // launched (desc == nullptr) or only described (for a grouped launch)
-int dec_wgrad(const Ctx& k, int which, vlt5_gemm_desc* desc, int lo, int n) {      // layers [lo, lo + n); n <= 0: all
+int dec_wgrad(const Ctx& k, int which, vlt5_gemm_desc* desc, int lo, int n, const vlt5_gemm_desc* group) {      // layers [lo, lo + n); n <= 0: all
     const Plan& p = k.p; const Layout& L = k.lay;
     const int d = k.d, inner = k.inner, ff = k.ff, Md = p.Md, Ld = k.c.num_decoder_layers;
     if (n <= 0) { lo = 0; n = Ld; }
     const int l1 = n > 1 ? lo + 1 : lo;
     switch (which) {
-    case 0: return k.wgrad_batched(p.d_dyd_f[lo], p.d_dyd_f[l1], d, p.hd[lo], p.hd[l1], ff, L.dec[lo].wo, L.dec[l1].wo, n, Md, d, ff, desc);
-    case 1: return k.wgrad_batched(p.d_dh[lo], p.d_dh[l1], k.ffw(), p.yn_f[lo], p.yn_f[l1], d, L.dec[lo].wi, L.dec[l1].wi, n, Md, k.ffw(), d, desc);
-    case 2: return k.wgrad_batched(p.d_dyd_c[lo], p.d_dyd_c[l1], d, p.ctx_c[lo], p.ctx_c[l1], inner, L.dec[lo].co, L.dec[l1].co, n, Md, d, inner, desc);
-    case 3: return k.wgrad_batched(p.d_dq_c[lo], p.d_dq_c[l1], inner, p.yn_c[lo], p.yn_c[l1], d, L.dec[lo].cq, L.dec[l1].cq, n, Md, inner, d, desc);
-    case 4: return k.wgrad_batched(p.d_dyd_s[lo], p.d_dyd_s[l1], d, p.ctx_s[lo], p.ctx_s[l1], inner, L.dec[lo].so, L.dec[l1].so, n, Md, d, inner, desc);
-    default: return k.wgrad_batched(p.d_dqkv[lo], p.d_dqkv[l1], 3 * inner, p.yn_a[lo], p.yn_a[l1], d, L.dec[lo].sqkv, L.dec[l1].sqkv, n, Md, 3 * inner, d, desc);
+    case 0: return k.wgrad_batched(p.d_dyd_f[lo], p.d_dyd_f[l1], d, p.hd[lo], p.hd[l1], ff, L.dec[lo].wo, L.dec[l1].wo, n, Md, d, ff, desc, group);
+    case 1: return k.wgrad_batched(p.d_dh[lo], p.d_dh[l1], k.ffw(), p.yn_f[lo], p.yn_f[l1], d, L.dec[lo].wi, L.dec[l1].wi, n, Md, k.ffw(), d, desc, group);
+    case 2: return k.wgrad_batched(p.d_dyd_c[lo], p.d_dyd_c[l1], d, p.ctx_c[lo], p.ctx_c[l1], inner, L.dec[lo].co, L.dec[l1].co, n, Md, d, inner, desc, group);
+    case 3: return k.wgrad_batched(p.d_dq_c[lo], p.d_dq_c[l1], inner, p.yn_c[lo], p.yn_c[l1], d, L.dec[lo].cq, L.dec[l1].cq, n, Md, inner, d, desc, group);
+    case 4: return k.wgrad_batched(p.d_dyd_s[lo], p.d_dyd_s[l1], d, p.ctx_s[lo], p.ctx_s[l1], inner, L.dec[lo].so, L.dec[l1].so, n, Md, d, inner, desc, group);
+    default: return k.wgrad_batched(p.d_dqkv[lo], p.d_dqkv[l1], 3 * inner, p.yn_a[lo], p.yn_a[l1], d, L.dec[lo].sqkv, L.dec[l1].sqkv, n, Md, 3 * inner, d, desc, group);
     }
 }
 // vlt5_step.defer_decoder_wgrads: the decoder's weight gradients (400 rows: short reductions, 45-60 us per launch on their own) ride
 // in the shadow of the long 216-tile launches -- the stacked cross-K/V gradient and the encoder's FFN gradients leave 40 of the 256
 // CUs idle for their whole duration; as the second problem of those grouped launches the decoder's tiles run there.
+// With gradient-bucket events (data parallel) the guests are placed so that every decoder bucket is complete at the MID-POINT of the
+// encoder phase (FFN wo / wi ride with the upper half's FFN launches as before, cross o + q run there as one grouped launch of their
+// own instead of riding with the lower half's), and the decoder's bucket events are recorded there: one launch more than the
+// single-process step instead of six, the decoder's exchange starts ~1.3 ms later but still has the lower half's chain and weight
+// gradients (~2 ms at B = 80) to hide under.  vlt5_tuning.wgrad_shadow = 3: the round-4 behaviour (no shadow with events).
+bool bucket_events(const Ctx& k) { return k.s.events && k.s.n_events > 0; }
+// would the decoder's weight gradients ride in the encoder phase's launches?  (a function of the configuration, the tuning record and
+// whether there are bucket events / a side stream only: the host asks the same question through vlt5_decoder_buckets_late)
+bool shadow_rule(const vlt5_config& c, const vlt5_tuning* t, bool events, bool side) {
+    const int ws = t ? t->wgrad_shadow : 0;
+    if (ws == 1 || (ws == 3 && events) || side) return false;
+    return c.num_layers > 1 && c.num_decoder_layers > 0;
+}
 bool shadow_wgrads(const Ctx& k) {
-    const bool off = k.tun.wgrad_shadow == 1;
-    // (never with gradient-bucket events: the decoder buckets would be signalled at the end of vlt5_decoder_bwd although five of
-    // their six weight gradients are only written inside vlt5_encoder_bwd)
-    return !off && k.s.defer_decoder_wgrads && !k.side && !(k.s.events && k.s.n_events > 0) && k.c.num_layers > 1 && k.c.num_decoder_layers > 0;
+    return k.s.defer_decoder_wgrads && shadow_rule(k.c, &k.tun, bucket_events(k), k.side != nullptr);
 }
 
 // weight gradients of encoder layers [lo, hi): one batched GEMM per weight kind (grid.z = layer); guest_wo / guest_wi >= 0: that
@@ -1138,6 +1152,14 @@ int encoder_bwd(const Ctx& k) {
             RC(k.fork(1));
             const Ctx ks = k.on_side();                   // beside the lower half's chain when there is a side stream
             RC(enc_wgrads(ks, enc_cut(Le, k.tun.enc_cut), Le, shadow_wgrads(k) ? 0 : -1, shadow_wgrads(k) ? 1 : -1));   // + decoder FFN wo / wi
+            if (shadow_wgrads(k) && bucket_events(k)) {
+                // data parallel: the last two decoder weight gradients (cross-attention q with o as its guest) run here, so that the
+                // decoder's buckets are complete -- and their exchange starts -- at the mid-point instead of at the very end
+                vlt5_gemm_desc co;
+                RC(dec_wgrad(ks, 2, &co));
+                RC(dec_wgrad(ks, 3, nullptr, 0, 0, &co));
+                for (int b = 0; b < Ld; ++b) RC(ks.record(b));
+            }
             for (int b = Ld + 1; b <= Ld + 1 + (Le - 1 - l); ++b) RC(ks.record(b));
         }
     }
@@ -1157,6 +1179,15 @@ int encoder_bwd(const Ctx& k) {
                              k.Gr + L.vis_img, k.Gr + L.vis_bf, d, c.n_images, k.st));
     RC(k.lin_wgrad(k.w<bf16_t>(p.vis_dG), d, k.w<bf16_t>(p.feats_bf16), c.feat_dim, k.Gr + L.vis_wf, B * s.V, d, c.feat_dim));
     RC(k.ln_flush());
+    if (s.grads_bf16) {
+        // bf16 staging copy of the last bucket without a pass over its 25 M elements: the two dense matrices (lm_head / shared, visual
+        // feature projection) were mirrored by their weight-gradient GEMMs; what is left are the norm weights, the small visual
+        // embedding parameters and the rows of `shared` the embedding backwards added to afterwards (token rows, object-order rows)
+        RC(k.mirror_small(L.dec_final_ln, L.vis_wf - L.dec_final_ln));
+        RC(k.mirror_small(L.vis_bf, L.shared - L.vis_bf));
+        RC(vlt5_mirror_rows_bf16(k.Gr + L.shared, (bf16_t*)s.grads_bf16 + L.shared, c.vocab, d, k.w<long long>(p.dec_ids), B * s.T,
+                                 s.input_ids, B * s.L, s.V < c.vocab ? s.V : c.vocab, k.st));
+    }
     RC(k.record(Ld + 1 + Le));                            // embeddings + norms + visual embedding: complete BEFORE the last weight-
                                                           // gradient GEMMs, so their all-reduce hides under those (data parallel)
     // (a third flush group of Le/4 layers was measured: batches of 3 layers fill the chip too poorly, +4 % step time)
@@ -1164,7 +1195,8 @@ int encoder_bwd(const Ctx& k) {
     RC(k.fork(2));
     {
         const Ctx ks = k.on_side();
-        RC(enc_wgrads(ks, 0, low_end, shadow_wgrads(k) ? 2 : -1, shadow_wgrads(k) ? 3 : -1));   // lower half (+ decoder cross o / q)
+        const bool guests = shadow_wgrads(k) && !bucket_events(k);
+        RC(enc_wgrads(ks, 0, low_end, guests ? 2 : -1, guests ? 3 : -1));   // lower half (+ decoder cross o / q)
         for (int b = Ld + 1 + (Le - low_end); b <= Ld + Le; ++b) RC(ks.record(b));
     }
     RC(k.join(3));                                        // every gradient is complete on the caller's stream from here on
@@ -1176,6 +1208,15 @@ int encoder_bwd(const Ctx& k) {
 extern "C" int vlt5_encoder_late_layers(int num_layers) { return num_layers > 1 ? enc_cut(num_layers) : num_layers; }
 extern "C" int vlt5_encoder_late_layers_tuned(int num_layers, const vlt5_tuning* t) {
     return num_layers > 1 ? enc_cut(num_layers, t ? t->enc_cut : 0) : num_layers;
+}
+
+// 1: with gradient-bucket events (vlt5_step.events) and vlt5_step.defer_decoder_wgrads the decoder-layer buckets [0, num_decoder_layers)
+// are signalled from INSIDE vlt5_encoder_bwd (at its mid-point, together with the upper half of the encoder) -- the caller must
+// enqueue its waits for them after that call; 0: they are signalled at the end of vlt5_decoder_bwd.  The stacked cross-K/V bucket
+// (index num_decoder_layers) is always signalled by vlt5_decoder_bwd.
+extern "C" int vlt5_decoder_buckets_late(const vlt5_config* c, const vlt5_tuning* t, int side_stream) {
+    if (!c) return 0;
+    return shadow_rule(*c, t, true, side_stream != 0) ? 1 : 0;
 }
 
 // A stream of the LOWEST priority for vlt5_step.side_stream: the weight-gradient GEMMs then only take the workgroup slots the

@@ -339,6 +339,37 @@ extern "C" int vlt5_proto_class_mean(const float* pool, const float* onehot, flo
     LAUNCH_CHECK();
     return VLT5_OK;
 }
+// Data parallel: the class statistics of both heads as ONE buffer for a single all-reduce, [sums Q | counts Q | sums V | counts V]
+// with sums = mean * max(count, 1) -- and the way back (means over the global batch).  One launch each instead of a dozen
+// element-wise torch launches in the middle of the forward.
+__global__ void proto_stats_kernel(float* __restrict__ curQ, float* __restrict__ numQ, float* __restrict__ curV, float* __restrict__ numV,
+                                   float* __restrict__ packed, int CQ, int CV, int d, int unpack) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = CQ * d, nv = CV * d;
+    float* pq = packed; float* pnq = packed + nq; float* pv = pnq + CQ; float* pnv = pv + nv;
+    if (i < nq) {
+        const float c = fmaxf(unpack ? pnq[i / d] : numQ[i / d], 1.f);
+        if (unpack) curQ[i] = pq[i] / c; else pq[i] = curQ[i] * c;
+    } else if (i < nq + nv) {
+        const int j = i - nq;
+        const float c = fmaxf(unpack ? pnv[j / d] : numV[j / d], 1.f);
+        if (unpack) curV[j] = pv[j] / c; else pv[j] = curV[j] * c;
+    } else if (i < nq + nv + CQ) {
+        const int j = i - nq - nv;
+        if (unpack) numQ[j] = pnq[j]; else pnq[j] = numQ[j];
+    } else if (i < nq + nv + CQ + CV) {
+        const int j = i - nq - nv - CQ;
+        if (unpack) numV[j] = pnv[j]; else pnv[j] = numV[j];
+    }
+}
+extern "C" int vlt5_proto_stats_pack(float* curQ, float* numQ, float* curV, float* numV, float* packed, int CQ, int CV, int d,
+                                     int unpack, void* stream) {
+    if (!curQ || !numQ || !curV || !numV || !packed || CQ <= 0 || CV <= 0 || d <= 0) return VLT5_ERR_ARG;
+    const int n = (CQ + CV) * (d + 1);
+    hipLaunchKernelGGL(proto_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, curQ, numQ, curV, numV, packed, CQ, CV, d, unpack ? 1 : 0);
+    LAUNCH_CHECK();
+    return VLT5_OK;
+}
 extern "C" int vlt5_proto_update(const float* curQ, const float* curV, const float* numQ, const float* numV, float* Qproto,
                                  float* Vproto, float* Qnum, float* Vnum, float* qmem, int qmem_initialised, int first, int task,
                                  float alpha, float beta, int CQ, int CV, int d, void* stream) {

@@ -572,6 +572,19 @@ class VLT5(nn.Module):
         return out
 
     # ------------------------------------------------------------------ backward ---------------------
+    def grad_release_plan(self):
+        """[(phase, lo, hi)]: the gradient-bucket ranges in the order a backward completes them -- phase 0: signalled by
+        vlt5_decoder_bwd, phase 1: by vlt5_encoder_bwd (upper half of the encoder mid-phase, then embeddings + norms + visual embedding
+        BEFORE the last weight-gradient GEMMs, then the lower half).  The decoder layers' buckets belong to phase 1 when their weight
+        gradients ride in the encoder phase's launches (vlt5_decoder_buckets_late).  A wait for a bucket's event must be enqueued
+        AFTER the call that records it; the data-parallel wrapper cuts its collectives -- and, sharded, its chunk ownership -- by this."""
+        c = self.cfg.c_struct()
+        Ld, Le, nb = self.cfg.num_decoder_layers, self.cfg.num_layers, self._nbuckets
+        cut = Ld + 1 + (Le - lib().vlt5_encoder_late_layers_tuned(Le, C.byref(self.tuning))) if Le > 1 else Ld + 1
+        late = lib().vlt5_decoder_buckets_late(C.byref(c), C.byref(self.tuning), int(self.side_stream_enabled)) == 1
+        head = [(0, Ld, Ld + 1), (1, 0, Ld)] if late else [(0, 0, Ld + 1)]
+        return head + [(1, Ld + 1, cut), (1, nb - 1, nb), (1, cut, nb - 1)]
+
     def _engine_backward(self, st, g, fused):
         c = self.cfg.c_struct()
         direct = all(p.grad is None for p in self._params_by_name.values())
@@ -598,7 +611,7 @@ class VLT5(nn.Module):
                 cs.gnorm_partials = ptr(self._gnorm)
             else:
                 fused_norm = False
-        cs.defer_decoder_wgrads = int(self.dp is None)      # (single process: the decoder's short weight gradients ride with the encoder's)
+        cs.defer_decoder_wgrads = 1           # the decoder's short weight gradients ride in the encoder phase's launches (vlt5_tuning.wgrad_shadow)
         gt = g.reshape(-1).to(torch.float32).contiguous()
         if fused:
             cs.gout = ptr(gt)
@@ -610,10 +623,9 @@ class VLT5(nn.Module):
             events = self.dp.make_events(self._nbuckets)
             # only the events the wrapper waits for (the last bucket of every merged slice) are recorded: a marker in the chain's
             # queue is not free, and 26 of them per backward bought nothing
-            Ld_, Le_, nb_ = self.cfg.num_decoder_layers, self.cfg.num_layers, self._nbuckets
-            cut_ = Ld_ + 1 + (Le_ - lib().vlt5_encoder_late_layers_tuned(Le_, C.byref(self.tuning))) if Le_ > 1 else Ld_ + 1
+            plan = self.grad_release_plan()
             need = set()
-            for lo_, hi_ in ((0, Ld_ + 1), (Ld_ + 1, cut_), (nb_ - 1, nb_), (cut_, nb_ - 1)):
+            for _, lo_, hi_ in plan:
                 need.update(last for _, _, _, last in self.dp.slices_of(lo_, hi_))
             arr = (L.vp * len(events))(*[L.vp(e.cuda_event) if i in need else L.vp() for i, e in enumerate(events)])
             cs.events, cs.n_events = arr, len(events)
@@ -638,17 +650,20 @@ class VLT5(nn.Module):
         stream = stream_ptr()
         check(lib().vlt5_decoder_bwd(C.byref(c), C.byref(cs), stream), "vlt5_decoder_bwd")
         if events is not None:
-            self.dp.reduce_range(self, events, 0, self.cfg.num_decoder_layers + 1, mirrored=mirrored)
+            # collectives are cut where the engine releases gradients (grad_release_plan); the wait for a bucket's event is enqueued
+            # after the engine call that records it (a wait enqueued earlier would see the PREVIOUS backward's record)
+            for phase, lo, hi in plan:
+                if phase == 0:
+                    self.dp.reduce_range(self, events, lo, hi, mirrored=mirrored)
         check(lib().vlt5_encoder_bwd(C.byref(c), C.byref(cs), stream), "vlt5_encoder_bwd")
         if events is not None:
-            # collectives are cut where the engine releases gradients: upper half of the encoder (mid-phase), then embeddings +
-            # norms + visual embedding (released BEFORE the last weight-gradient GEMMs: their all-reduce hides under those),
-            # then the lower half of the encoder -- the only group whose all-reduce stays exposed
-            Ld, Le, nb = self.cfg.num_decoder_layers, self.cfg.num_layers, self._nbuckets
-            cut = Ld + 1 + (Le - lib().vlt5_encoder_late_layers_tuned(Le, C.byref(self.tuning))) if Le > 1 else Ld + 1
-            self.dp.reduce_range(self, events, Ld + 1, cut, mirrored=mirrored)
-            self.dp.reduce_range(self, events, nb - 1, nb)                      # embeddings / norms: no GEMM output, cast as before
-            self.dp.reduce_range(self, events, cut, nb - 1, final=True, mirrored=mirrored)
+            # (decoder layers when their weight gradients rode in this phase,) upper half of the encoder (mid-phase), then embeddings +
+            # norms + visual embedding (released BEFORE the last weight-gradient GEMMs: their exchange hides under those; bf16
+            # buckets: the engine mirrored them too -- GEMM epilogues + vlt5_mirror_rows_bf16 -- no cast pass), then the lower half
+            # of the encoder -- the only group whose exchange stays exposed
+            late = [(lo, hi) for phase, lo, hi in plan if phase == 1]
+            for i, (lo, hi) in enumerate(late):
+                self.dp.reduce_range(self, events, lo, hi, final=(i == len(late) - 1), mirrored=mirrored)
             self.dp.finish()
         elif self.dp is not None:
             self.dp.reduce_flat(target)

@@ -107,14 +107,6 @@ class DataParallelVLT5:
         self.params_sharded = False         # the f32 master of the layer buckets is only current on the owning rank (zero1)
         self._slices_done = []              # slices reduce-scattered by the current backward, in issue order
         self._param_slices = []
-        # the ranges the engine releases gradients in (VLT5._engine_backward): decoder + cross k/v, upper half of the encoder,
-        # the last bucket (embeddings / norms), lower half of the encoder -- the slice plan, and with it the chunk every rank
-        # owns under zero1, only depends on these
-        import ctypes as C
-        from ._lib import lib
-        Ld, Le, nb = model.cfg.num_decoder_layers, model.cfg.num_layers, len(self.bucket_end)
-        cut = Ld + 1 + (Le - lib().vlt5_encoder_late_layers_tuned(Le, C.byref(model.tuning))) if Le > 1 else Ld + 1
-        self.release_ranges = ((0, Ld + 1), (Ld + 1, cut), (nb - 1, nb), (cut, nb - 1))
         # identical initial weights on every rank (what DDP's constructor would do)
         dist.broadcast(model._flat, src=0, group=process_group)
         model._bf16_version = -1
@@ -126,6 +118,14 @@ class DataParallelVLT5:
         return {"algo": self.algo, "grad_dtype": str(self.grad_dtype).replace("torch.", ""), "world": self.world,
                 "bucket_mb": self.bucket_bytes >> 20, "sharded_optimizer": bool(self.sharded_optimizer),
                 "gather_master": bool(self.gather_master)}
+
+    @property
+    def release_ranges(self):
+        """The bucket ranges the engine releases gradients in, in order (VLT5.grad_release_plan): stacked cross k/v, decoder layers,
+        upper half of the encoder, the last bucket (embeddings / norms), lower half of the encoder -- the slice plan, and with it the
+        chunk every rank owns under zero1, only depends on these (a function of the configuration and the tuning record, the same
+        on every rank)."""
+        return tuple((lo, hi) for _, lo, hi in self.module.grad_release_plan())
 
     def slice_plan(self):
         """Every merged slice a backward reduce-scatters, [(a, b)] in flat elements, in issue order."""

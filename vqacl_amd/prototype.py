@@ -53,8 +53,19 @@ class PrototypeHead:
     def _allreduce_stats(self, *stats):
         """Data parallel: class means over the GLOBAL batch = all-reduced sums / all-reduced counts, so every rank
         holds the prototypes a single process would compute on the concatenated batch.  The Q and V statistics
-        travel in ONE collective (277 KB): a small all-reduce is pure latency."""
+        travel in ONE collective (277 KB): a small all-reduce is pure latency.  Packing (mean x count | count) and unpacking are one
+        launch each (vlt5_proto_stats_pack); on the CPU (gloo tests of the host logic) the same arithmetic in torch."""
         import torch.distributed as dist
+        if len(stats) == 2 and stats[0][0].is_cuda:
+            (curQ, numQ), (curV, numV) = stats
+            n = (self.CQ + self.CV) * (self.d + 1)
+            if getattr(self, "_packed", None) is None or self._packed.numel() != n:
+                self._packed = torch.empty(n, device=curQ.device, dtype=torch.float32)
+            args = (ptr(curQ), ptr(numQ), ptr(curV), ptr(numV), ptr(self._packed), self.CQ, self.CV, self.d)
+            check(lib().vlt5_proto_stats_pack(*args, 0, stream_ptr()), "vlt5_proto_stats_pack")
+            dist.all_reduce(self._packed, group=self.dist_group)
+            check(lib().vlt5_proto_stats_pack(*args, 1, stream_ptr()), "vlt5_proto_stats_pack")
+            return (curQ, numQ), (curV, numV)
         parts = []
         for proto, cnt in stats:
             parts += [(proto * cnt.clamp(min=1).unsqueeze(1)).reshape(-1), cnt]
