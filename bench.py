@@ -524,6 +524,164 @@ def eager_gpu_baseline(dev, B=80, steps=5):
     return dict(unit="samples/s", kind="torch-eager restatement on the same GPU", batch=B, **out)
 
 
+# forward + backward GFLOP per sample (2*M*N*K per GEMM / bmm) of the BASELINE shapes
+OTHER_CONFIGS = [
+    # key, what, config overrides, B, L, V, T, GFLOP per sample
+    ("c1_b4", "VL-T5-base, B = 4 (BASELINE configs[0] shape)", {}, 4, 20, 36, 5, 37.90),
+    ("c4_v16", "VL-T5-base NExT-QA, 16 frames, L = 23, T = 6, B = 80 (configs[3])", dict(n_ques=8), 80, 23, 16, 6, 28.2),
+    ("c4_v32", "VL-T5-base NExT-QA, 32 frames, L = 23, T = 6, B = 80 (configs[3])", dict(n_ques=8), 80, 23, 32, 6, 36.2),
+    ("c5_large_b32", "VL-T5-large, B = 32 (configs[4])", dict(d_model=1024, num_heads=16, d_ff=4096, num_layers=24), 32, 20, 36, 5, 132.0),
+    ("c5_large_b80", "VL-T5-large, B = 80 per GPU (288 GB holds it)", dict(d_model=1024, num_heads=16, d_ff=4096, num_layers=24), 80, 20, 36, 5, 132.0),
+]
+
+
+def other_config_lines(dev, steps=5, warm=3):
+    """Side values (never `value`): the train step of the other BASELINE shapes -- 5 timed steps each after 3 warm-up steps on one
+    device-resident synthetic batch (dropout 0.1, fwd + bwd + clip + AdamW); ms/step, samples/s, the step as a fraction of the dense
+    bf16 MFMA peak, and the optimizer's share (event-timed in the same steps; for the large model also the update of ONE EIGHTH of the
+    parameters -- what a rank of the ZeRO-1 sharded step at N = 8 runs)."""
+    from vqacl_amd import VLT5VQA, VLT5Config, FusedAdamW, reference_param_groups
+    from vqacl_amd import _lib as L
+    from vqacl_amd._lib import lib
+    out = {}
+    for key, what, kw, B, Lq, V, T, gflop in OTHER_CONFIGS:
+        cfg = VLT5Config(dropout_rate=0.1, **kw)
+        torch.manual_seed(1)
+        model = VLT5VQA(cfg, device=dev)
+        model.train()
+        opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-4, eps=1e-6, max_grad_norm=5.0)
+        batch = synthetic_batch(B, Lq, V, T, seed=3)
+        if cfg.n_ques != N_QUES:
+            batch["ques_labels"] = batch["ques_labels"][:, :cfg.n_ques].contiguous()
+        batch = {k: v.to(dev) for k, v in batch.items()}
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+
+        def step(i=None):
+            model.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
+            if i is not None:
+                ev[i][0].record()
+            opt.step()
+            if i is not None:
+                ev[i][1].record()
+            for p in model.parameters():
+                p.grad = None
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        adam = sorted(a.elapsed_time(b) for a, b in ev)[steps // 2]
+        n_par = int(opt._used_end)
+        rec = {"what": what, "batch": B, "ms_per_step": round(ms, 3), "samples_per_sec": round(B * 1e3 / ms, 1),
+               "gflop_per_sample": gflop, "step_tflops": round(gflop * B / ms, 1),
+               "step_frac_of_mfma_peak": round(gflop * B / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+               "params_m": round(n_par / 1e6, 1), "clip_adamw_ms": round(adam, 3), "clip_adamw_share": round(adam / ms, 3)}
+        if key.startswith("c5"):
+            # the update of one eighth of the flat buffers (lr = 0: the weights stay as they are): the optimizer pass of a ZeRO-1 rank at N = 8
+            n8 = n_par // 8 // 64 * 64
+            flat, grad, bf = model._flat, model._flat_grad, model._flat_bf16
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            args = (L.vp(flat.data_ptr()), L.vp(grad.data_ptr()), L.vp(opt._m.data_ptr()), L.vp(opt._v.data_ptr()), L.vp(bf.data_ptr()), n8,
+                    0.0, 0.9, 0.999, 1e-6, 0.0, 5, L.vp(opt._total_sq.data_ptr()), 5.0, 1)
+            for rep in range(3):
+                if rep == 2:
+                    a0.record()
+                assert lib().vlt5_adamw_step(*args, L.stream_ptr()) == 0
+            a1.record()
+            a1.synchronize()
+            rec["adamw_ms_one_eighth_shard"] = round(a0.elapsed_time(a1), 3)
+            rec["ms_per_step_with_sharded_update_estimate"] = round(ms - adam + a0.elapsed_time(a1), 3)
+        out[key] = rec
+        del model, opt, batch
+        torch.cuda.empty_cache()
+    return out
+
+
+def feed_figures(store, slots_list, cfg, B, V, dev, trace_us=None):
+    """feat_gather_kernel against the HBM roofline.  `us_cold` (-> frac): every launch gathers a DIFFERENT random batch after a 1 GB
+    write has pushed the store's rows out of the Infinity Cache -- what a train step sees, each launch timed with its own event
+    pair; `us_replay`: 200 back-to-back gathers of the same 80 slots (23.7 MB, cache resident: an upper bound, the round-4 figure)."""
+    from vqacl_amd._lib import lib, ptr, stream_ptr
+    of = torch.empty(B, V, cfg.feat_dim, dtype=torch.bfloat16, device=dev)
+    ob = torch.empty(B, V, 4, device=dev)
+    fn = lib().vlt5_feat_gather
+
+    def gargs(slots):
+        return (ptr(store.feats), ptr(store.boxes), ptr(slots), store.capacity, ptr(of), ptr(ob), B, V, cfg.feat_dim, stream_ptr())
+    a = gargs(slots_list[0])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(10):
+        fn(*a)
+    e0.record()
+    for _ in range(200):
+        fn(*a)
+    e1.record()
+    e1.synchronize()
+    us_replay = e0.elapsed_time(e1) / 200 * 1e3
+    flush = torch.empty(1 << 28, dtype=torch.float32, device=dev)          # 1 GB > 256 MB of Infinity Cache
+    cold = []
+    for slots in slots_list[1:]:
+        flush.fill_(1.0)
+        a = gargs(slots)
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        fn(*a)
+        s1.record()
+        s1.synchronize()
+        cold.append(s0.elapsed_time(s1) * 1e3)
+    # the event pair itself: an empty pair on the same stream
+    pair = []
+    for _ in range(20):
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        s1.record()
+        s1.synchronize()
+        pair.append(s0.elapsed_time(s1) * 1e3)
+    del flush
+    cold.sort()
+    pair.sort()
+    us_cold = max(cold[len(cold) // 2] - pair[len(pair) // 2], 0.1)
+    gbytes = 2 * B * V * (cfg.feat_dim * 2 + 16) / 1e9
+    rec = {"kernel": "feat_gather_kernel", "bound": "hbm", "bytes_per_launch": int(gbytes * 1e9), "us": round(us_cold, 2),
+           "achieved": round(gbytes / (us_cold * 1e-6), 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbytes / (us_cold * 1e-6) / 8000.0, 4),
+           "how": "cold: a fresh random batch per launch after a 1 GB write evicted the Infinity Cache, per-launch events minus the empty event pair "
+                  f"({pair[len(pair) // 2]:.2f} us), median of {len(cold)}",
+           "us_replay_cache_resident": round(us_replay, 2), "frac_replay_cache_resident": round(gbytes / (us_replay * 1e-6) / 8000.0, 4),
+           "store_images": store.capacity, "store_gb": round(store.capacity * V * (cfg.feat_dim * 2 + 16) / 1e9, 3)}
+    if trace_us:
+        rec["us_in_step_trace"] = trace_us[0]
+        rec["frac_in_step_trace"] = round(gbytes / (trace_us[0] * 1e-6) / 8000.0, 4)
+        rec["trace_source"] = trace_us[1]
+    return rec
+
+
+def trace_kernel_us(name):
+    """Average duration (us) of kernel `name` in the committed same-build kernel trace of the bench command, or None."""
+    from vqacl_amd.build import source_hash
+    f = committed_profile("kernel_stats_bench_b80.txt")
+    if not f:
+        return None
+    sha, col = None, None
+    for line in open(f):
+        if line.startswith("# source_sha16"):
+            sha = line.split()[2]
+        if line.startswith("kernel "):
+            hdr = line.split()
+            col = hdr.index("avg_us") - len(hdr) if "avg_us" in hdr else None
+            continue
+        if line.startswith("#") or col is None:
+            continue
+        if name in line and sha == source_hash():
+            try:
+                return float(line.split()[col]), f"profiles/{os.path.basename(f)}"
+            except ValueError:
+                return None
+    return None
+
+
 def main():
     args = parse_args()
 
@@ -678,47 +836,41 @@ def main():
             torch.cuda.synchronize()
             out[tag] = round(n * B / (time.perf_counter() - t1), 2)
         # the gather kernel against the HBM roofline: algorithmic bytes = rows read + rows written (bf16 features + f32 boxes)
-        from vqacl_amd._lib import lib, ptr, stream_ptr
-        slots = store.slots(feeds[0]["img_ids"])
-        of = torch.empty(B, V, cfg.feat_dim, dtype=torch.bfloat16, device=dev)
-        ob = torch.empty(B, V, 4, device=dev)
-        gargs = (ptr(store.feats), ptr(store.boxes), ptr(slots), store.capacity, ptr(of), ptr(ob), B, V, cfg.feat_dim, stream_ptr())
-        fn = lib().vlt5_feat_gather                      # pre-bound arguments: the launch loop must not be host-bound (a launch is ~6 us)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(10):
-            fn(*gargs)
-        e0.record()
-        for _ in range(200):
-            fn(*gargs)
-        e1.record()
-        e1.synchronize()
-        us = e0.elapsed_time(e1) / 200 * 1e3
-        gbytes = 2 * B * V * (cfg.feat_dim * 2 + 16) / 1e9
-        out["feed"] = {"kernel": "feat_gather_kernel", "bound": "hbm", "bytes_per_launch": int(gbytes * 1e9), "us": round(us, 2),
-                       "achieved": round(gbytes / (us * 1e-6), 1), "peak": 8000.0, "unit": "GB/s",
-                       "frac": round(gbytes / (us * 1e-6) / 8000.0, 4), "store_images": n_img,
-                       "store_gb": round(n_img * V * (cfg.feat_dim * 2 + 16) / 1e9, 3)}
+        out["feed"] = feed_figures(store, [store.slots(f["img_ids"]) for f in feeds[:21]], cfg, B, V, dev, trace_kernel_us("feat_gather_kernel"))
         # greedy decoding of the same batch shape through test_step's path (key/value cache, decode kernels): the
         # encoder + prototype retrieval + cross-K/V once, then one token per step; eos = -1 so that every row decodes the full length
-        def decode_ms(max_length, reps=3):
+        def decode_ms(bt, max_length, reps=3):
             model.eval()
             try:
                 for _ in range(2):
-                    model.greedy_generate(resident["input_ids"], (resident["vis_feats"], resident["boxes"]), max_length=max_length, eos_token_id=-1)
+                    model.greedy_generate(bt["input_ids"], (bt["vis_feats"], bt["boxes"]), max_length=max_length, eos_token_id=-1)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for _ in range(reps):
-                    model.greedy_generate(resident["input_ids"], (resident["vis_feats"], resident["boxes"]), max_length=max_length, eos_token_id=-1)
+                    model.greedy_generate(bt["input_ids"], (bt["vis_feats"], bt["boxes"]), max_length=max_length, eos_token_id=-1)
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t1) / reps * 1e3
             finally:
                 model.train()
-        t2, t20 = decode_ms(2), decode_ms(20)
+        wbytes = decode_weight_bytes(cfg)
+        t2, t20 = decode_ms(resident, 2), decode_ms(resident, 20)
         out["decode"] = {"what": "VLT5VQA.greedy_generate (test_step), B = %d, 19 tokens per row, random weights" % B,
                          "ms_per_batch": round(t20, 3), "ms_encoder_and_first_token": round(t2, 3),
                          "ms_per_token_step": round((t20 - t2) / 18, 4), "tokens_per_sec": round(B * 19 / (t20 * 1e-3), 1),
-                         "weight_bytes_per_token_step": decode_weight_bytes(cfg),
-                         "weight_gb_per_s": round(decode_weight_bytes(cfg) / ((t20 - t2) / 18 * 1e-3) / 1e9, 1)}
+                         "weight_bytes_per_token_step": wbytes,
+                         "weight_gb_per_s": round(wbytes / ((t20 - t2) / 18 * 1e-3) / 1e9, 1),
+                         "frac_of_hbm_peak": round(wbytes / ((t20 - t2) / 18 * 1e-3) / 8e12, 4)}
+        # rows per launch is the lever of a launch-bound loop: the same token-step over larger evaluation batches (the reference's
+        # --valid_batch_size is a free parameter of its scripts); weights are read once per step whatever the rows
+        sweep = {}
+        for rows in (160, 320, 512):
+            bt = {k: v.to(dev) for k, v in synthetic_batch(rows, L, V, T, seed=4242).items()}
+            a2, a20 = decode_ms(bt, 2, reps=2), decode_ms(bt, 20, reps=2)
+            per = (a20 - a2) / 18
+            sweep[str(rows)] = {"ms_per_token_step": round(per, 4), "tokens_per_sec": round(rows * 19 / (a20 * 1e-3), 1),
+                                "weight_gb_per_s": round(wbytes / (per * 1e-3) / 1e9, 1), "ms_per_batch": round(a20, 3)}
+            del bt
+        out["decode"]["rows_sweep"] = sweep
     if not args.no_roofline:
         # in-situ roofline of the dominant kernel family: real steps, every GEMM dispatch timed.  Under data parallelism EVERY rank
         # runs the same extra steps (their collectives have to pair up); rank 0's records are the ones reported
@@ -739,6 +891,8 @@ def main():
                 out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"
                 out["roofline"]["traffic_build_matches"] = bool(meta and meta[0]["source_sha16"] == source_hash())
 
+    if solo and not args.no_side_values:
+        out["configs"] = other_config_lines(dev)
     if solo and not args.no_side_values and "roofline" in out:
         warm, warm_ms = time_gemms_warm(cfg, B, L, V, T, dev)
         out["roofline"]["frac_warm"] = round(warm / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)

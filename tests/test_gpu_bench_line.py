@@ -36,10 +36,21 @@ def test_bench_line_contract_short_run():
     assert 0.2 < dec["ms_per_token_step"] < 3.0 and dec["tokens_per_sec"] > 1e4
     assert d["feed"]["bound"] == "hbm" and 0.0 < d["feed"]["frac"] <= 1.0
     assert d["samples_per_sec_pcie_inclusive"] <= d["samples_per_sec_resident_batch"] * 1.05
+    # round 5: the cold (in-step-like) feed figure is the one quoted, the cache-resident replay is the side value
+    assert d["feed"]["us"] >= d["feed"]["us_replay_cache_resident"] * 0.9 and d["feed"]["frac"] <= d["feed"]["frac_replay_cache_resident"] * 1.1
+    assert set(d["configs"]) == {"c1_b4", "c4_v16", "c4_v32", "c5_large_b32", "c5_large_b80"}
+    for k, c in d["configs"].items():
+        assert c["ms_per_step"] > 0 and abs(c["samples_per_sec"] - c["batch"] * 1e3 / c["ms_per_step"]) < 0.01 * c["samples_per_sec"]
+        assert 0.0 < c["step_frac_of_mfma_peak"] < 0.5 and 0.0 < c["clip_adamw_share"] < 0.9
+    assert d["configs"]["c5_large_b32"]["adamw_ms_one_eighth_shard"] < d["configs"]["c5_large_b32"]["clip_adamw_ms"]
+    sw = dec["rows_sweep"]
+    assert set(sw) == {"160", "320", "512"} and all(v["ms_per_token_step"] > 0 for v in sw.values())
+    assert sw["512"]["tokens_per_sec"] > dec["tokens_per_sec"]                 # more rows per launch: more tokens per second
+    assert dec["weight_bytes_per_token_step"] == 2 * (12 * (6 * 768 * 768 + 2 * 768 * 3072) + 32200 * 768)
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("n,algo", [(2, "auto"), (4, "auto"), (8, "auto"), (2, "allreduce"), (4, "rs_ag")])
+@pytest.mark.parametrize("n,algo", [(2, "auto"), (4, "auto"), (8, "auto"), (2, "allreduce")])
 def test_bench_rehearsal_n_ranks_on_one_gpu(n, algo):
     """Dress rehearsal of the whole multi-rank bench path on the one GPU of the box: `bench.py --gpus N --rehearsal` -> launcher -> N rank
     processes sharing cuda:0 -> gloo rendezvous on 127.0.0.1 -> DataParallelVLT5 (zero1 for N in {2, 4, 8}) -> store-fed train steps with
@@ -49,17 +60,20 @@ def test_bench_rehearsal_n_ranks_on_one_gpu(n, algo):
     if not torch.cuda.is_available():
         pytest.skip("needs the GPU")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VQACL_FORCE_DIST")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--rehearsal", "--steps", "2", "--warmup", "1", "--batch", "16",
-           "--store-images", "256", "--dp-algo", algo, "--no-cpu-baseline", "--no-parity", "--launch-timeout", "1200"]
+    # (gloo moves ~2 GB per rank and step through the host: a step of 8 ranks takes about a minute -- the wide runs are kept short)
+    steps = 2 if n <= 2 else 1
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--rehearsal", "--steps", str(steps), "--warmup", "1", "--batch", "16",
+           "--store-images", "256", "--dp-algo", algo, "--no-cpu-baseline", "--no-parity", "--launch-timeout", "1200"] + (["--no-roofline"] if n > 4 else [])
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=1400, env=env, cwd=ROOT)
     assert p.returncode == 0, (p.stderr[-3000:], p.stdout[-500:])
     d = json.loads(p.stdout.strip().splitlines()[-1])
     assert d["rehearsal"] is True and d["value"] is None and d["backend"] == "gloo"
-    assert d["n_gpus"] == n and d["ranks_seen"] == n and d["launcher"] == "bench.py" and d["steps"] == 2
+    assert d["n_gpus"] == n and d["ranks_seen"] == n and d["launcher"] == "bench.py" and d["steps"] == steps
     want = algo if algo != "auto" else "zero1"
     assert d["grad_exchange"]["algo"] == want and d["grad_exchange"]["world"] == n
     assert d["grad_exchange"]["sharded_optimizer"] == (want == "zero1")
     assert d["weights_in_sync"] is True
     assert d["config"]["global_batch"] == 16 * n and "REHEARSAL" in d["config"]["parallelism"]
     assert d["rehearsal_samples_per_sec"] > 0 and d["final_loss"] == d["final_loss"]          # (finite)
-    assert d["roofline"]["launches_per_step"] > 100                                             # rank 0's in-situ records of the extra steps
+    if n <= 4:
+        assert d["roofline"]["launches_per_step"] > 100                                         # rank 0's in-situ records of the extra steps
