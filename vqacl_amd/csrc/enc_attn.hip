@@ -355,10 +355,10 @@ extern "C" int vlt5_qkv_attn_fwd(const void* xn_bf16, const void* wqkv_bf16, voi
 }
 // the same kernel with the T5 RMS norm in front of the projection folded in: xw_bf16 = bf16(x * w_norm) and the per-row partial
 // sums of squares of x as the producing GEMM's epilogue left them (vlt5_gemm_desc.emit_*); the q|k|v rows are scaled by rstd on
-// their way out of the accumulators and rstd goes to norm_rstd_out [B*S] for the backward.  norm_nparts <= 16.
+// their way out of the accumulators and rstd goes to norm_rstd_out [B*S] for the backward.  norm_nparts <= 32 (SSQ_STRIDE).
 extern "C" int vlt5_qkv_attn_fwd_norm(const void* xw_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model,
                                       const float* norm_partials, int norm_nparts, float norm_eps, float* norm_rstd_out, void* stream) {
-    if (!norm_partials || norm_nparts < 1 || norm_nparts > 16 || (((uintptr_t)norm_partials) & 15)) return VLT5_ERR_ARG;
+    if (!norm_partials || norm_nparts < 1 || norm_nparts > 32 || (((uintptr_t)norm_partials) & 15)) return VLT5_ERR_ARG;
     return qkv_attn_launch(xw_bf16, wqkv_bf16, qkv_bf16, core, d_model, norm_partials, norm_nparts, norm_eps, norm_rstd_out, stream);
 }
 static int qkv_attn_launch(const void* xn_bf16, const void* wqkv_bf16, void* qkv_bf16, const vlt5_attn_desc* core, int d_model,

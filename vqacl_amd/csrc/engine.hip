@@ -303,10 +303,14 @@ struct Ctx {
     // y = resid + dropout(x W^T), and for the norm that consumes y next: bf16(y * w_norm) -> xw, partial sums of squares -> ssq;
     // *nparts = partials per row
     int lin_fwd_emit(const bf16_t* X, const bf16_t* W, float* Y, int M, int N, int K, float dp, uint32_t dseed, const float* resid,
-                     long long w_norm, void* xw, float* ssq, int* nparts) const {
+                     long long w_norm, void* xw, float* ssq, int* nparts, bool wide_consumer = false) const {
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);
         g.tuning = &tun;
+        // (vlt5_tuning.gemm_rmrm_f32_tile = 2: 128 x 64 tiles where the consumer takes the 24 partials per row they leave)
+        if (tun.gemm_rmrm_f32_tile == 2 && wide_consumer && (long)((M + 63) / 64) * ((N + 127) / 128) >= 256 && 2 * ((N + 63) / 64) <= 32) {
+            g.tile_m = 128; g.tile_n = 64;
+        }
         g.A = X; g.B = W; g.C = Y; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
         g.alpha = 1.f; g.drop_p = dp; g.drop_seed = dseed; g.resid = resid; g.ldr = N; g.out_f32 = 1;
         g.emit_norm_w = P + w_norm; g.emit_xw_bf16 = xw; g.emit_partials = ssq;
@@ -572,7 +576,7 @@ int encoder_fwd(const Ctx& k) {
                                 k.w<void>(p.xn_a[l]), nullptr, k.w<float>(p.xr[2 * l]), M, 0.f, 0, 0, 0));
         NormIn nin_a;
         if (np_a > 0) { nin_a.part = k.w<float>(p.ssq_e[2 * l]); nin_a.n = np_a; nin_a.rstd_out = k.w<float>(p.xr[2 * l]); }
-        if (fused_attn_ok(k) && np_a <= 16) {
+        if (fused_attn_ok(k) && np_a <= 32) {
             vlt5_attn_desc a;
             memset(&a, 0, sizeof a);
             a.q = qkv; a.k = qkv + inner; a.v = qkv + 2 * inner;
@@ -596,7 +600,7 @@ int encoder_fwd(const Ctx& k) {
         if (k.fold_on()) {
             int np_f = 0;
             RC(k.lin_fwd_emit(k.w<bf16_t>(p.ctx[l]), k.Pb + E.so, xf, M, d, inner, k.pdrop, k.seed(sb + E_ATTN_OUT), xa, E.ln_f,
-                              k.w<void>(p.xn_f[l]), k.w<float>(p.ssq_e[2 * l + 1]), &np_f));
+                              k.w<void>(p.xn_f[l]), k.w<float>(p.ssq_e[2 * l + 1]), &np_f, true));
             nin_f.part = k.w<float>(p.ssq_e[2 * l + 1]); nin_f.n = np_f; nin_f.rstd_out = k.w<float>(p.xr[2 * l + 1]);
         } else {
             RC(k.lin_fwd(k.w<bf16_t>(p.ctx[l]), k.Pb + E.so, xf, M, d, inner, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + E_ATTN_OUT), xa));
@@ -607,7 +611,7 @@ int encoder_fwd(const Ctx& k) {
         if (l + 1 < c.num_layers && k.fold_enc_first(l + 1)) {
             pending = 0;
             RC(k.lin_fwd_emit(k.w<bf16_t>(p.h[l]), k.Pb + E.wo, xo, M, d, ff, k.pdrop, k.seed(sb + E_FFN_OUT), xf, L.enc[l + 1].ln_s,
-                              k.w<void>(p.xn_a[l + 1]), k.w<float>(p.ssq_e[2 * l + 2]), &np_a));
+                              k.w<void>(p.xn_a[l + 1]), k.w<float>(p.ssq_e[2 * l + 2]), &np_a, true));
         } else {
             RC(k.lin_fwd_for_norm(k.w<bf16_t>(p.h[l]), k.Pb + E.wo, xo, M, d, ff, k.pdrop, k.seed(sb + E_FFN_OUT), xf, &pending));
         }

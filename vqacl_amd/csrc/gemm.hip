@@ -136,7 +136,17 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         else if (tiles(64, 128) >= 256) {                              // 3-stage ring, 2 workgroups per CU
             // input-gradient layout (row-major dY, k-major W): the tall tile reads the transpose-read operand half as often per
             // flop (sweep r01_f: 26.0 vs 27.5 us on 4480x768x2304, 171.6 vs 182.3 on 4640x768x18432)
-            if (!d->a_kmajor && d->b_kmajor) { bm = 128; bn = 64; } else { bm = 64; bn = 128; }
+            // (round 5, step-faithful sweep: warm, the opposite choices win by ~10 % on the 4480-row launches -- in-step A/B runs decide:
+            // vlt5_tuning.gemm_rmkm_tile / gemm_rmrm_f32_tile)
+            if (!d->a_kmajor && d->b_kmajor) {
+                if (tn && tn->gemm_rmkm_tile == 2) { bm = 64; bn = 128; } else { bm = 128; bn = 64; }
+            } else {
+                bm = 64; bn = 128;
+                // an f32 sublayer output: 128x64 (a producer of a folded norm's partials gets its tile from the engine, which knows
+                // whether the consumer takes 24 partials per row -- two per 64-column tile -- or, the fused encoder attention kernel, 16)
+                if (tn && tn->gemm_rmrm_f32_tile == 2 && !d->a_kmajor && !d->b_kmajor && d->out_f32 &&
+                    !emit) { bm = 128; bn = 64; }
+            }
         }
         else {
             bm = 64; bn = 64;                                          // small-M (decoder) problems: most workgroups
@@ -229,7 +239,8 @@ extern "C" int vlt5_gemm_auto_split_tuned(int M, int N, int Kred, long long slab
         const int kmin = tuning && tuning->gemm_split_kmin > 0 ? tuning->gemm_split_kmin : 768;
         if (Kred < kmin || tiles >= 128) return 1;
         sk = (int)((512 + tiles / 2) / tiles);
-        if (sk > 8) sk = 8;
+        const int cap = tuning && tuning->gemm_split_cap > 0 ? tuning->gemm_split_cap : 8;
+        if (sk > cap) sk = cap;
         if (sk > ksteps / 4) sk = ksteps / 4;
     }
     while (sk > 1 && (long long)sk * M * N * 4 > slab_bytes) --sk;
