@@ -61,7 +61,7 @@ typedef struct {
                                2: 64x128 (round-5 step-faithful sweep: 34.1 -> 30.4 us warm on 4480x768x3072); 0: the default */
     int gemm_rmrm_f32_tile; /* row-major A and B with an f32 output (sublayer outputs), same branch: 1: 64x128; 2: 128x64 -- only where the
                                consumer of a folded norm's partials takes 24 of them (not in front of the fused encoder attention kernel) */
-    int gemm_split_cap;     /* > 0: largest automatic split-K factor of the small-output policy (default 8) */
+    int gemm_split_cap;     /* > 0: largest automatic split-K factor of the small-output policy (default 4; 8 until round 5) */
     int reserved[2];
 } vlt5_tuning;
 

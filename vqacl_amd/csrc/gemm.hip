@@ -239,7 +239,9 @@ extern "C" int vlt5_gemm_auto_split_tuned(int M, int N, int Kred, long long slab
         const int kmin = tuning && tuning->gemm_split_kmin > 0 ? tuning->gemm_split_kmin : 768;
         if (Kred < kmin || tiles >= 128) return 1;
         sk = (int)((512 + tiles / 2) / tiles);
-        const int cap = tuning && tuning->gemm_split_cap > 0 ? tuning->gemm_split_cap : 8;
+        // (cap 4 since round 5: in-step A/B 8.53 -> 8.48 ms per step against 8 -- the consumer norms sum half the slabs;
+        // profiles/r05_c_ab_tile_policy.txt)
+        const int cap = tuning && tuning->gemm_split_cap > 0 ? tuning->gemm_split_cap : 4;
         if (sk > cap) sk = cap;
         if (sk > ksteps / 4) sk = ksteps / 4;
     }
