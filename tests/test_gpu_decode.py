@@ -445,6 +445,30 @@ def test_greedy_generate_base_model_vs_oracle_and_bookkeeping(dev):
         assert row[:cut + 1] == free[:cut + 1] and all(x == model.cfg.pad_token_id for x in row[cut + 1:])
 
 
+def test_greedy_generate_at_the_evaluation_batch_size_vs_oracle(dev):
+    """The decode kernels at the benched evaluation shape (B = 80, L = 20) against the ORACLE's greedy loop -- not only against the tiled
+    HIP path: every token whose top-2 logit margin exceeds twice the logits tolerance must be the oracle's (decode weights un-boosted
+    rows included: the assertion is on the count of gated tokens, most of the 80 x 5)."""
+    from test_gpu_model import check_greedy_tokens, oracle_greedy, parity_log
+    R, ocfg, params, batch, model = _base_model(dev, 79, 80, L=20, boost=8.0)
+    model.train()
+    model.train_step(batch, 0, 0.5, 0.3)          # populate the prototypes
+    model.eval()
+    fb = (batch["vis_feats"], batch["boxes"])
+    steps = 5
+    st = R.PrototypeState(Q_prototype=model.Q_prototype.cpu().clone(), V_prototype=model.V_prototype.cpu().clone())
+    torch.set_num_threads(16)
+    ref_tok, margins = oracle_greedy(R, dict(params), st, ocfg, batch, steps)
+    model.tuning.decode_fast = 2
+    a = model.greedy_generate(batch["input_ids"], fb, max_length=steps + 1, eos_token_id=-1)
+    model.tuning.decode_fast = 0
+    assert a.shape == (80, steps + 1)
+    ca, cut_a = check_greedy_tokens(a, ref_tok, margins, 4e-2, eos=-1, what="decode kernels vs oracle, B=80")
+    parity_log(f"greedy decode (base, B=80, {steps} steps): decode kernels {ca} of {80 * steps} tokens bit-exact under the margin rule "
+               f"({cut_a} rows left the band)")
+    assert ca >= 200, (ca, cut_a)
+
+
 def test_greedy_loop_replayed_from_a_graph_equals_the_enqueued_loop(dev):
     """greedy_generate replays the token-step from a HIP graph (device-side step index): the same tokens as enqueueing the launches every
     step, on repeated calls (the graph and its buffers are reused), with another batch in between, with an EOS that stops rows early, and

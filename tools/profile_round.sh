@@ -30,6 +30,16 @@ python3 bench.py --gpus 1 --force-dist --steps 20 --warmup 5 --no-cpu-baseline -
 cd /tmp
 WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 rocprofv3 --kernel-trace -d $OUT/${TAG}_dd -o r -- python3 $ROOT/bench.py --gpus 1 --force-dist --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-parity --no-side-values > $OUT/${TAG}_dd.log 2>&1
 python3 $ROOT/tools/rocpd_stats.py $(find $OUT/${TAG}_dd -name "*.db" | head -1) > $OUT/${TAG}_kernel_stats_force_dist.txt
+cd $ROOT && python3 tools/dp_overhead_table.py $OUT/${TAG}_kernel_stats_bench_b80.txt $OUT/${TAG}_kernel_stats_force_dist.txt > $OUT/${TAG}_dp_overhead.txt 2>&1
+# round 5: the step-faithful GEMM sweep, the dress rehearsal of the N-rank bench path on this one GPU (flagged lines, no value), the
+# accuracy proxy against the oracle on the same GPU, the step-graph probe (small batches: host-bound or not)
+python3 tools/gemm_step_sweep.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_gemm_step_sweep.txt
+for N in 2 4 8; do
+  python3 bench.py --gpus $N --rehearsal --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $OUT/${TAG}_rehearsal_n$N.json 2> $OUT/${TAG}_rehearsal_n$N.err
+done
+python3 tools/trajectory.py --steps-per-stage 100 --out gpurun_out/${TAG}_trajectory.txt > /dev/null 2>&1
+python3 tools/step_graph_probe.py 4 8 16 32 80 2>&1 | grep -v "amdgpu.ids\|UserWarning\|detach()\|print(f" > $OUT/${TAG}_step_graph_probe.txt
+cd /tmp
 rm -rf $OUT/${TAG}_dk $OUT/${TAG}_dd
 # the raw rocpd databases are tens of MB each and gpurun only copies 64 MiB back: keep the summaries, drop the databases
 rm -rf $OUT/${TAG}_kt $OUT/${TAG}_pf $OUT/${TAG}_pw $OUT/${TAG}_pm

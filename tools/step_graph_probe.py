@@ -79,7 +79,7 @@ def main():
             opt.step()
         torch.cuda.synchronize()
         adam = (time.perf_counter() - t0) / n * 1e3
-        print(f"{B:3d}   {eager:7.3f} ({host:6.3f})               {replay:7.3f}                                   {only:7.3f}               {adam:7.3f}   loss {float(loss):.4f}", flush=True)
+        print(f"{B:3d}   {eager:7.3f} ({host:6.3f})               {replay:7.3f}                                   {only:7.3f}               {adam:7.3f}   loss {float(loss.detach()):.4f}", flush=True)
         clear()
         del g, batch
 
