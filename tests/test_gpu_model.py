@@ -757,6 +757,25 @@ def test_data_parallel_overlap_path_on_one_gpu_and_rank_equivalence(dev):
             torch.cuda.synchronize()
             outs.append((m3.flat_params().clone(), float(opt3.grad_norm())))
         assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+        # the sharded exchange (what `auto` picks at world 2 / 4 / 8) over RCCL with one rank: in-place reduce-scatter (the output chunk
+        # is a slice of the input), sharded clip + AdamW, in-place all-gathers of the bf16 shadow / f32 master, per-bucket events the next
+        # forward waits for -- the same weights as the all-reduce path above (one rank owns every chunk), and the master is readable
+        m4 = make_model(ocfg, params, dev)
+        m4.train()
+        dp4 = DataParallelVLT5(m4, bucket_mb=0.05, algo="zero1")
+        opt4 = FusedAdamW(reference_param_groups(m4, 0.01), m4, lr=1e-3, eps=1e-6, max_grad_norm=0.05)
+        assert dp4.algo == "zero1" and dp4.sharded_optimizer
+        for it in range(2):
+            dp4.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
+            assert dp4.shards_valid
+            opt4.step()
+            assert not dp4.shards_valid and not dp4.params_sharded
+            for p in m4.parameters():
+                p.grad = None
+        torch.cuda.synchronize()
+        # (the squared norm is summed chunk by chunk instead of over the whole buffer: the clip factor may differ in its last bit)
+        assert torch.allclose(m4.flat_params(), outs[0][0], rtol=0.0, atol=2e-6), "zero1 over one RCCL rank == all-reduce + whole-buffer update"
+        assert abs(float(opt4.grad_norm()) - outs[0][1]) <= 1e-5 * max(outs[0][1], 1e-6)
     finally:
         dist.destroy_process_group()
 
