@@ -986,7 +986,7 @@ def test_benched_shape_b80_against_the_oracle(dev):
     res["loss_reduced"].backward()
     lo = R.train_step_loss(o["loss"], sub["target_ids"], sub["scores"])
     lo.backward()
-    assert abs(float(res["loss_reduced"].detach()) - float(lo)) < 1e-2
+    assert abs(float(res["loss_reduced"].detach()) - float(lo.detach())) < 1e-2
     worst = check_grads(model, {k: p.grad for k, p in oracle.P.items()})
     parity_log(f"base B=80 (benched shape, samples {pick}): logits rel max err {e:.4g}, per-token loss err {le:.3g}, prototype indices "
                f"{exact} of {gated} margin-gated equal; B=4 gradients worst cosine {worst[0]:.5f} ({worst[1]})")
