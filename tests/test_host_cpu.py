@@ -221,3 +221,36 @@ def test_workspace_plan_is_consistent(built):
     b = L.vlt5_workspace_offset(C.byref(c), 80, 20, 36, 9, built.WS_ENC_EXT)
     assert a == b
     assert L.vlt5_workspace_bytes(C.byref(c), 0, 20, 36, 5) < 0
+
+
+def test_gradient_release_plan_covers_every_bucket_once_and_follows_the_tuning(built):
+    """VLT5.grad_release_plan (what the data-parallel wrapper cuts its collectives and -- sharded -- its chunk ownership by): every gradient
+    bucket exactly once, the stacked cross-K/V bucket always in the decoder phase, the decoder layers' buckets in the encoder phase exactly when
+    the engine lets their weight gradients ride in that phase's launches (vlt5_decoder_buckets_late: a function of configuration + tuning)."""
+    from vqacl_amd import VLT5VQA, VLT5Config
+    from vqacl_amd import _lib as L
+    cfg = VLT5Config(d_model=64, d_kv=16, num_heads=4, d_ff=128, num_layers=4, num_decoder_layers=3, vocab_size=400, feat_dim=64)
+    m = VLT5VQA(cfg, device=torch.device("cpu"))
+    Ld, nb = 3, m._nbuckets
+    assert nb == 3 + 1 + 4 + 1
+
+    def covered(plan):
+        seen = []
+        for phase, lo, hi in plan:
+            assert phase in (0, 1) and 0 <= lo <= hi <= nb
+            seen += list(range(lo, hi))
+        return seen
+    plan = m.grad_release_plan()
+    assert sorted(covered(plan)) == list(range(nb))
+    assert (0, Ld, Ld + 1) in plan and (1, 0, Ld) in plan, plan            # default: shadowed, decoder layers released by the encoder phase
+    assert plan[-1][2] == nb - 1 and plan[-2][1:] == (nb - 1, nb), "embeddings + norms before the lower half of the encoder, which comes last"
+    for setting in (1, 3):                                                    # own launches / own launches under bucket events: the round-4 plan
+        m.tuning = L.make_tuning(wgrad_shadow=setting)
+        p2 = m.grad_release_plan()
+        assert p2[0] == (0, 0, Ld + 1) and sorted(covered(p2)) == list(range(nb)), p2
+    m.tuning = L.make_tuning()
+    m.side_stream_enabled = True                                              # a side stream for the weight gradients: no shadowing either
+    assert m.grad_release_plan()[0] == (0, 0, Ld + 1)
+    one = VLT5VQA(VLT5Config(d_model=64, d_kv=16, num_heads=4, d_ff=128, num_layers=1, num_decoder_layers=2, vocab_size=400, feat_dim=64),
+                  device=torch.device("cpu"))
+    assert sorted(covered(one.grad_release_plan())) == list(range(one._nbuckets)) and one.grad_release_plan()[0] == (0, 0, 3)

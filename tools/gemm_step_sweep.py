@@ -8,7 +8,7 @@ gradients (one launch per weight kind over 6 or 12 layers, some with a second pr
 outputs (split-K slabs summed by the norm behind them) -- this tool takes the launch list from the engine's own dispatch records
 (vlt5_gemm_timing_*), so "auto" IS the step's configuration and "best" / "torch" are alternatives for the same launch.
 
-    python tools/gemm_step_sweep.py [--batch 80] [--quick]
+    python tools/gemm_step_sweep.py [--batch 80] [--large] [--quick]
 
 Columns: in-step (event-timed inside real steps, cold operands), auto (the step's configuration, warm replay), best alternative,
 torch.  Footer: GEMM ms per step auto / best-per-launch / torch-where-it-wins, and the launches more than 3 % behind torch.
@@ -29,9 +29,10 @@ BF = torch.bfloat16
 TILES = ((256, 256), (224, 256), (160, 256), (128, 128), (128, 64), (64, 128), (64, 64))
 
 
-def step_records(B, steps=4):
+def step_records(B, steps=4, large=False):
     dev = torch.device("cuda")
-    model = VLT5VQA(VLT5Config(dropout_rate=0.1), device=dev)
+    kw = dict(d_model=1024, num_heads=16, d_ff=4096, num_layers=24) if large else {}        # VL-T5-large (BASELINE configs[4])
+    model = VLT5VQA(VLT5Config(dropout_rate=0.1, **kw), device=dev)
     model.train()
     opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-4, eps=1e-6, max_grad_norm=5.0)
     batch = {k: v.to(dev) for k, v in synthetic_batch(B, seed=1).items()}
@@ -116,13 +117,14 @@ class Problem:
 
 
 def main():
-    B = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 80
+    large = "--large" in sys.argv
+    B = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else (32 if large else 80)
     quick = "--quick" in sys.argv
     dev = torch.device("cuda")
-    recs = step_records(B)
+    recs = step_records(B, large=large)
     fn = lib().vlt5_gemm_bf16
     rows = []
-    print(f"# {sum(c for c, _ in recs.values()):.0f} GEMM-family launches per step at B = {B}; one line per distinct launch configuration", flush=True)
+    print(f"# {'VL-T5-large' if large else 'VL-T5-base'}: {sum(c for c, _ in recs.values()):.0f} GEMM-family launches per step at B = {B}; one line per distinct launch configuration", flush=True)
     for key, (calls, insitu_us) in sorted(recs.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
         tm, tn, M, N, K, bt, akm, bkm, sp, f32, M2, N2, K2, bt2 = key
         if (tm, tn) == (128, 384):
