@@ -47,6 +47,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     attn_fwd_rows<DK64>(p, Qs, Ks, Vs, b, h, i0, lane, add);
 }
 
+// -DATTN_BWD_NO_STORE (experiment builds only, tools/r05_attn_bwd_fusion_bound.sh): the dq / dk / dv stores of the ENCODER-shaped launches
+// (Tq == Tk > 32, not causal) are predicated off at run time -- all the arithmetic stays (the compiler cannot drop it), the 20.6 MB per layer
+// never leave the chip: the producer-side upper bound of fusing this kernel with the q|k|v input-gradient GEMM behind it.  Results are WRONG.
+#ifdef ATTN_BWD_NO_STORE
+#define BWD_STORE_OK(p) (!((p).Tq == (p).Tk && (p).Tq > 32 && !(p).causal && (p).lse != nullptr && (p).H > 0) || (p).B < 0)
+#else
+#define BWD_STORE_OK(p) true
+#endif
 // ---- backward building blocks (one wave each) -------------------------------------------------------------------------------
 // phase A, query rows i0 .. i0+15: recompute P from the saved log-sum-exp, dP = dO V^T, dS = P (dP - sum_j dP P); leaves
 // Pd = dropout(P) and dS in registers (pd, ds; the swapped score layout), stores the dQ rows and the bias-block gradient
@@ -117,7 +125,7 @@ __device__ __forceinline__ void attn_bwd_rows(const AttnArgs& p, const bf16_t* Q
             }
         }
         const int d = db * 16 + g * 4;
-        if (i < p.Tq && d < p.dk) {
+        if (i < p.Tq && d < p.dk && BWD_STORE_OK(p)) {
             uint2 pk;
             pk.x = pack_bf16x2(o[0], o[1]);
             pk.y = pack_bf16x2(o[2], o[3]);
@@ -161,7 +169,7 @@ __device__ __forceinline__ void attn_bwd_keys(const AttnArgs& p, const bf16_t* P
             ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, fs, ak, 0, 0, 0);
         }
         const int d = db * 16 + g * 4;
-        if (j < p.Tk && d < p.dk) {
+        if (j < p.Tk && d < p.dk && BWD_STORE_OK(p)) {
             uint2 pk;
             pk.x = pack_bf16x2(av[0], av[1]);
             pk.y = pack_bf16x2(av[2], av[3]);

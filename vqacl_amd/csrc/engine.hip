@@ -1146,7 +1146,21 @@ int encoder_bwd(const Ctx& k) {
                      k.seed(sb + E_PROBS), dctx, dqkv, (long long)S * 3 * inner, 3 * inner, dqkv + inner, dqkv + 2 * inner,
                      (long long)S * 3 * inner, 3 * inner, k.w<float>(p.dS_enc) + (size_t)l * B * k.H * s.L * s.L));
         int ns_e = 1;
+#ifdef ENC_DGRAD_HOT_A
+        // experiment builds only (tools/r05_attn_bwd_fusion_bound.sh): the q|k|v input-gradient GEMM reads ONE 4.6 KB row of dq|dk|dv for every
+        // row of its A operand (leading dimension 0: always cache resident) -- the consumer-side upper bound of a fusion that hands the operand
+        // over on chip.  Results are WRONG.
+        {
+            vlt5_gemm_desc g;
+            memset(&g, 0, sizeof g);
+            g.tuning = &k.tun;
+            g.A = dqkv; g.B = k.Pb + E.sqkv; g.C = tmp; g.M = M; g.N = d; g.K = 3 * inner; g.lda = 0; g.ldb = d; g.ldc = d; g.b_kmajor = 1;
+            g.alpha = 1.f; g.out_f32 = 1;
+            RC(vlt5_gemm_bf16(&g, k.st));
+        }
+#else
         RC(k.lin_dgrad(dqkv, k.Pb + E.sqkv, tmp, M, 3 * inner, d, 1, 1.f, nullptr, 1.f, &ns_e));
+#endif
         RC(k.ln_bwd(tmp, k.w<float>(p.x[2 * l]), E.ln_s, k.w<float>(p.xr[2 * l]), dx, M, 1, 0.f, 0, 0, 0,
                     l > 0 ? k.w<bf16_t>(p.e_dyd_f[l - 1]) : nullptr, l > 0 ? k.seed(SITE_ENC_BASE + (l - 1) * 8 + E_FFN_OUT) : 0u, ns_e,
                     (long long)M * d, k.fold_enc_first(l) ? k.w<bf16_t>(p.xn_a[l]) : nullptr));
