@@ -169,6 +169,103 @@ def _worker(rank, world, port, q, grad_dtype, algo="allreduce", backend="gloo"):
         q.put((rank, traceback.format_exc()))
 
 
+def _long_worker(rank, world, port, q, steps):
+    """`steps` optimizer steps through the sharded default path with what a continual run does in between: a task switch (the prototype
+    state machine's other branches), a NEW optimizer half-way (the Trainer builds one per category group: fresh Adam moments against
+    weights whose non-owned master chunks arrived by all-gather), a rehearsal-style batch with mixed question types -- against one
+    process on the concatenated batches."""
+    try:
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle import ref_cpu as R
+        from vqacl_amd import FusedAdamW, reference_param_groups
+        from vqacl_amd.parallel import DataParallelVLT5
+        ocfg = R.tiny_cfg()
+        params = R.init_params(ocfg, seed=78)
+        b = 2
+        batches, tasks = [], []
+        for i in range(steps):
+            task = 0 if i < steps // 3 else 1
+            bt = R.synthetic_batch(ocfg, B=b * world, L=12, V=36, T=4, seed=100 + i, task_id=task)
+            if task == 1 and i % 2 == 1:                      # rehearsal batch: question types of the earlier task, run under the current task id
+                bt["ques_labels"] = R.synthetic_batch(ocfg, B=b * world, L=12, V=36, T=4, seed=100 + i, task_id=0)["ques_labels"]
+            batches.append(bt)
+            tasks.append(task)
+
+        def run(model, handle, sl):
+            opt, losses = None, []
+            for i, (bt, task) in enumerate(zip(batches, tasks)):
+                if i in (0, steps // 2):
+                    opt = FusedAdamW(reference_param_groups(model, 0.01), handle, lr=1e-3, eps=1e-6, max_grad_norm=5.0)
+                mine = {k: v[sl] for k, v in bt.items()}
+                res = handle.train_step(mine, task, 0.5, 0.3)
+                res["loss"].backward()
+                opt.step()
+                for p in model.parameters():
+                    p.grad = None
+                losses.append(float(res["loss"].detach()))
+            torch.cuda.synchronize()
+            return losses
+        model = _model(ocfg, params, dev)
+        model.train()
+        dp = DataParallelVLT5(model, bucket_mb=0.05)
+        assert dp.algo == "zero1" and dp.grad_dtype is torch.bfloat16
+        losses = run(model, dp, slice(rank * b, (rank + 1) * b))
+        flat = model.flat_params().clone()
+        other = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(other, flat)
+        assert all(torch.equal(o, other[0]) for o in other), "ranks diverged over the long run"
+        lt = torch.tensor(losses, device=dev)
+        dist.all_reduce(lt)
+        if rank == 0:
+            ref = _model(ocfg, params, dev)
+            ref.train()
+            rl = run(ref, ref, slice(0, b * world))
+            mean = (lt / world).tolist()
+            worst = max(abs(a - c) for a, c in zip(mean, rl))
+            assert worst < 5e-2, (worst, mean, rl)
+            assert max(abs(a - c) for a, c in zip(mean[:6], rl[:6])) < 1e-2
+            a, c = flat, ref.flat_params()
+            cosw = float(torch.dot(a, c) / (a.norm() * c.norm()))
+            assert cosw > 0.99999, cosw
+            assert torch.allclose(model.Q_prototype, ref.Q_prototype, atol=5e-2) and torch.allclose(model.V_prototype, ref.V_prototype, atol=5e-2)
+            assert all(x == x and x < 20.0 for x in rl)                                    # finite (fresh random batches every step: no trend to assert)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4])
+def test_many_steps_of_the_sharded_path_track_one_process(world):
+    """24 optimizer steps at world 2 and 4 (zero1, bf16 buckets, real kernels) with a task switch, rehearsal-style batches and a new optimizer
+    half-way: the mean loss of the ranks tracks one process on the concatenated batches step by step, the ranks end bit-identical, the weights
+    agree with the single process to cosine > 0.99999."""
+    assert torch.cuda.is_available()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_long_worker, args=(r, world, port, q, 24)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=600) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
 def _run_two(grad_dtype, algo, backend, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
