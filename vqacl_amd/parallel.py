@@ -63,6 +63,20 @@ def pick_algo(world, algo="auto"):
     return algo
 
 
+def merge_buckets(bucket_start, bucket_end, lo, hi, bucket_bytes):
+    """Buckets [lo, hi) merged into slices of >= bucket_bytes (f32 size): [(a, b, first_bucket, last_bucket)] in flat elements.  The
+    remainder of a range stays a slice of its own on purpose: buckets are laid out in backward-completion order, so the remainder of the
+    LAST released range is the bottom encoder layer -- the one reduce-scatter that cannot hide under backward and, under zero1, the first
+    layer slice the next forward waits for: 14 MB there instead of 85 (tools/link_budget.py prints the plan)."""
+    out, start = [], lo
+    for b in range(lo, hi):
+        size = (bucket_end[b] - bucket_start[start]) * 4
+        if size >= bucket_bytes or b == hi - 1:
+            out.append((bucket_start[start], bucket_end[b], start, b))
+            start = b + 1
+    return out
+
+
 class DataParallelVLT5:
     def __init__(self, model, process_group=None, bucket_mb=128, average=True, grad_dtype=None, algo="auto", small_group=True,
                  gather_master=True):
@@ -134,13 +148,7 @@ class DataParallelVLT5:
     # ---- slice plan -----------------------------------------------------------------------------------
     def slices_of(self, lo, hi):
         """Buckets [lo, hi) merged into slices of >= bucket_bytes: [(a, b, first_bucket, last_bucket)] in flat elements."""
-        out, start = [], lo
-        for b in range(lo, hi):
-            size = (self.bucket_end[b] - self.bucket_start[start]) * 4
-            if size >= self.bucket_bytes or b == hi - 1:
-                out.append((self.bucket_start[start], self.bucket_end[b], start, b))
-                start = b + 1
-        return out
+        return merge_buckets(self.bucket_start, self.bucket_end, lo, hi, self.bucket_bytes)
 
     def chunk(self, a, b, rank=None):
         """Rank `rank`'s chunk of slice [a, b): equal parts (slice lengths are multiples of 64 elements)."""
