@@ -77,3 +77,29 @@ def test_bench_rehearsal_n_ranks_on_one_gpu(n, algo):
     assert d["rehearsal_samples_per_sec"] > 0 and d["final_loss"] == d["final_loss"]          # (finite)
     if n <= 4:
         assert d["roofline"]["launches_per_step"] > 100                                         # rank 0's in-situ records of the extra steps
+
+
+@pytest.mark.timeout(900)
+def test_bench_rehearsal_under_torch_distributed_run():
+    """The command shape the driver uses for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- with `--rehearsal` added so that both ranks can share the one GPU: bench.py must recognise that it
+    IS a rank (WORLD_SIZE inherited), not start ranks of its own, and rank 0 must print the one JSON line."""
+    import socket
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VQACL_FORCE_DIST")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearsal", "--steps", "2", "--warmup", "1", "--batch", "16", "--store-images", "256",
+           "--no-cpu-baseline", "--no-parity", "--no-roofline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert p.returncode == 0, (p.stderr[-3000:], p.stdout[-500:])
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, p.stdout[-2000:]                       # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["rehearsal"] is True and d["value"] is None
+    assert d["launcher"] == "external" and d["weights_in_sync"] is True and d["grad_exchange"]["algo"] == "zero1"
