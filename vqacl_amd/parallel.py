@@ -112,7 +112,16 @@ class DataParallelVLT5:
                 ends[bucket] = max(ends.get(bucket, 0), (off + n + 63) // 64 * 64)
         self.bucket_end = [ends[b] for b in sorted(ends)]
         self.bucket_start = [0] + self.bucket_end[:-1]
-        self.comm_stream = torch.cuda.Stream(priority=-1) if model._flat.is_cuda else None   # high priority: short casts + collectives must not queue behind the backward GEMMs
+        # The stream the waits for bucket events and the collectives are issued on.  NORMAL priority since round 5: with bf16 buckets
+        # mirrored by the GEMM epilogues it carries no kernels of its own (event waits only; the collectives themselves run on the
+        # process group's internal stream, which bench.py / the launcher create at high priority), and a HIGH-priority stream that sits
+        # on a pending event wait costs the compute queue dearly on this runtime: +0.23 ms per step at world size 1 in same-box A/B runs
+        # (9.20 -> 8.97 ms), and a persistent 3x slowdown of the whole step (26 ms) when the GPU was touched before
+        # init_process_group() -- profiles/r05_w_comm_stream_priority.txt.  VQACL_COMM_PRIORITY=-1 restores the round-1 choice (made when
+        # every bucket was cast on this stream: at normal priority those casts only ran once backward had finished).
+        import os
+        prio = int(os.environ.get("VQACL_COMM_PRIORITY", "0"))
+        self.comm_stream = torch.cuda.Stream(priority=prio) if model._flat.is_cuda else None
         self._events = None
         self.defer_cast_back = False        # set by FusedAdamW: the optimizer reads the reduced bf16 buckets itself
         self.g16_valid = False              # the staging buffer holds this backward's reduced gradients, not yet cast back
