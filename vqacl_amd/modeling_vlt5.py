@@ -638,9 +638,12 @@ class VLT5(nn.Module):
         if self.side_stream_enabled:
             # the batched weight-gradient GEMMs run on a second stream beside the input-gradient chain; vlt5_encoder_bwd joins it
             if self._side is None:
-                raw = L.vp()
-                check(lib().vlt5_side_stream_create(C.byref(raw)), "vlt5_side_stream_create")      # lowest priority
-                self._side = torch.cuda.ExternalStream(raw.value, device=self._device)
+                if os.environ.get("VQACL_SIDE_STREAM_PRIO", "low") == "normal":
+                    self._side = torch.cuda.Stream(device=self._device)                                 # normal priority (round-5 A/B)
+                else:
+                    raw = L.vp()
+                    check(lib().vlt5_side_stream_create(C.byref(raw)), "vlt5_side_stream_create")      # lowest priority
+                    self._side = torch.cuda.ExternalStream(raw.value, device=self._device)
                 self._side_events = [torch.cuda.Event() for _ in range(4)]
                 for e in self._side_events:                 # force creation of the underlying hipEvent_t
                     e.record()
