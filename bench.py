@@ -798,6 +798,7 @@ def main():
         out["rehearsal_samples_per_sec"] = out["value"]
         out["rehearsal_ms_per_step"] = out["ms_per_step"]
         out["value"] = None
+        out["ms_per_step"] = None
         out["samples_per_sec_per_gpu"] = None
         out["step_tflops_per_gpu"] = out["step_frac_of_mfma_peak"] = None
         out["backend"] = "gloo"

@@ -67,7 +67,7 @@ def test_bench_rehearsal_n_ranks_on_one_gpu(n, algo):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=1400, env=env, cwd=ROOT)
     assert p.returncode == 0, (p.stderr[-3000:], p.stdout[-500:])
     d = json.loads(p.stdout.strip().splitlines()[-1])
-    assert d["rehearsal"] is True and d["value"] is None and d["backend"] == "gloo"
+    assert d["rehearsal"] is True and d["value"] is None and d["ms_per_step"] is None and d["backend"] == "gloo"
     assert d["n_gpus"] == n and d["ranks_seen"] == n and d["launcher"] == "bench.py" and d["steps"] == steps
     want = algo if algo != "auto" else "zero1"
     assert d["grad_exchange"]["algo"] == want and d["grad_exchange"]["world"] == n
