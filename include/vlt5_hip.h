@@ -62,7 +62,9 @@ typedef struct {
     int gemm_rmrm_f32_tile; /* row-major A and B with an f32 output (sublayer outputs), same branch: 1: 64x128; 2: 128x64 -- only where the
                                consumer of a folded norm's partials takes 24 of them (not in front of the fused encoder attention kernel) */
     int gemm_split_cap;     /* > 0: largest automatic split-K factor of the small-output policy (default 4; 8 until round 5) */
-    int reserved[2];
+    int decode_nfrag;       /* decode kernels: 1, 2 or 4 forces the column-tile width of the projections to 16 x this many columns; 16: the
+                               round-4 geometry rule (widest tile that fills the chip) at every row count; 0: the launch geometry's own choice */
+    int reserved[1];
 } vlt5_tuning;
 
 /* ---- GEMM: C[M,N] = epi(alpha * sum_k A[m,k] B[n,k]) -------------------------------------------

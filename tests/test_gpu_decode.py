@@ -43,6 +43,14 @@ def rel_max_err(a, b):
     (80, 768, 768, "norm_relu"),         # norm -> cross-attention q (one fragment per column tile)
     (80, 1024, 4096, "bf16_resid"),      # t5-large wo
     (32, 4096, 1024, "norm_relu"),       # t5-large wi
+    (100, 2304, 768, "norm_split"),      # the reference's --valid_batch_size: seven row blocks (one ragged) -> the narrow-tile geometry of round 5
+    (100, 768, 768, "bf16_resid"),       #   (two fragments per tile: 24 x 7 workgroups = one round of the chip)
+    (100, 3072, 768, "norm_relu"),       #   (one fragment per tile)
+    (100, 768, 3072, "bf16_resid"),
+    (100, 32200, 768, "norm_argmax"),    #   (the vocabulary projection keeps its resident form up to eight row blocks)
+    (160, 768, 768, "norm_relu"),        # ten row blocks
+    (320, 3072, 768, "norm_relu"),
+    (160, 32200, 768, "norm_argmax"),    # more than eight row blocks: the row-walking form of the vocabulary projection
     (5, 192, 64, "norm_split"),          # tiny configuration, ragged row block
     (33, 64, 128, "bf16_resid"),
     (17, 400, 64, "norm_argmax"),
@@ -357,7 +365,7 @@ def _step_logits(model, batch, dec_in, dev, fast):
     return outs, ids_out, cache
 
 
-@pytest.mark.parametrize("B", [4, 80])
+@pytest.mark.parametrize("B", [4, 80, 100])
 def test_decode_kernels_against_the_tiled_path_at_base_size(dev, B):
     """VL-T5-base, the decode kernels against the tiled GEMM / attention launches of the training path on the same decoder inputs, step
     by step: logits within the stated bf16 tolerance of each other, the cache contents equal up to bf16 rounding, next-token ids equal

@@ -26,6 +26,7 @@ struct DecLinArgs {
     const float* nx_w; bf16_t* nx_b; long long ld_nx; float* nx_ssq; int nx_parts;
     const float* rs_part; int rs_n;           // rs_n a multiple of 4, <= 64
     int* t_inc;                               // optional device-side step index incremented by this launch when it ends (t_ptr must be null)
+    int force_nfrag;                          // > 0: column-tile width in 16-column fragments (vlt5_tuning.decode_nfrag; ignored with pmax)
     int RB, CT, ct_per_xcd;                   // filled by vlt5_declin_launch
     long long* tl;                            // -DDECLIN_TIMELINE builds: [workgroup][8] shader-clock stamps of wave 0 (tools/declin_timeline.py)
 };

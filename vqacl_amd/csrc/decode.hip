@@ -843,8 +843,16 @@ static bool declin_split(int K, bool af32, int nfrag, int* kt, int* nw) {
 }
 
 // the launch geometry of (rows, N, K): k-tiles per wave and phase, waves, fragments per column tile
-static bool declin_geometry(int rows, int N, int K, bool af32, int* kt, int* nw, int* nfrag) {
+static bool declin_geometry(int rows, int N, int K, bool af32, int* kt, int* nw, int* nfrag, int rule = 0) {
     const int RB = (rows + 15) / 16;
+    // More than five row blocks (> 80 rows; the reference evaluates with --valid_batch_size 100): a wide tile then means MORE than one round
+    // of heavy workgroups, and narrow tiles win -- two fragments if that makes the grid one round of the chip, else one (round 5, rows 96 ... 320:
+    // -8 % per batch at 100 rows, -13 % at 320; profiles/r05_y_decode_rules.txt).  The vocabulary projection keeps its own forms.
+    if (RB >= 6 && N < 8192 && rule != 16) {
+        const int f = ((N + 31) / 32) * RB <= 256 ? 2 : 1;
+        *nfrag = f;
+        return declin_split(K, af32, f, kt, nw);
+    }
     for (int f = 4; f >= 1; --f) {          // widest column tile that still fills the chip (>= ~200 workgroups)
         const int ctf = (N + 16 * f - 1) / (16 * f);
         if (ctf * RB >= 200 || f == 1) { *nfrag = f; return declin_split(K, af32, f, kt, nw); }
@@ -875,7 +883,13 @@ int vlt5_declin_launch(DecLinArgs a, hipStream_t st) {
     if (a.nx_b && (!a.nx_w || !a.nx_ssq || a.relu || a.nx_parts != a.N / 16 || (a.N & 15) || (a.ld_nx & 3))) return VLT5_ERR_ARG;
     if ((a.ldx & 7) || (a.K & 63)) return VLT5_ERR_ALIGN;
     int kt, nw, nfrag;
-    if (!declin_geometry(a.rows, a.N, a.K, af32, &kt, &nw, &nfrag)) return VLT5_ERR_ARG;
+    if (!declin_geometry(a.rows, a.N, a.K, af32, &kt, &nw, &nfrag, a.pmax ? 0 : a.force_nfrag)) return VLT5_ERR_ARG;
+    if (a.force_nfrag > 0 && !a.pmax && (a.force_nfrag == 1 || a.force_nfrag == 2 || a.force_nfrag == 4)) {      // experiment switch
+        int kt2, nw2;
+        if (declin_split(a.K, af32, a.force_nfrag, &kt2, &nw2) && (af32 ? declin_pick<true>(kt2, a.force_nfrag) : declin_pick<false>(kt2, a.force_nfrag))) {
+            nfrag = a.force_nfrag; kt = kt2; nw = nw2;
+        }
+    }
     a.RB = (a.rows + 15) / 16;
     a.CT = (a.N + 16 * nfrag - 1) / (16 * nfrag);
     a.ct_per_xcd = (a.CT + 7) / 8;

@@ -836,6 +836,7 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
         memset(&a, 0, sizeof a);
         a.xf = xf; a.xb = xb; a.ldx = K; a.ln_w = xf ? k.P + ln_w : nullptr; a.eps = c.eps; a.W = W; a.rows = B; a.N = N; a.K = K;
         a.alpha = 1.f; a.out_b = ob; a.ldo = ldo; a.split_col = 0x7fffffff; a.out_f = of; a.ldf = N; a.resid = resid; a.ldr = N; a.relu = relu;
+        a.force_nfrag = k.tun.decode_nfrag;
         return a;
     };
     // the projection behind a norm: the bf16 operand + partials its producer left (split_norm), or the f32 row with the norm folded in
