@@ -856,7 +856,7 @@ def main():
         # rows per launch is the lever of a launch-bound loop: the same token-step over larger evaluation batches (the reference's
         # --valid_batch_size is a free parameter of its scripts); weights are read once per step whatever the rows
         sweep = {}
-        for rows in (160, 320, 512):
+        for rows in (100, 160, 320, 512):                 # (100: the reference's --valid_batch_size)
             bt = {k: v.to(dev) for k, v in synthetic_batch(rows, L, V, T, seed=4242).items()}
             a2, a20 = decode_ms(bt, 2, reps=2), decode_ms(bt, 20, reps=2)
             per = (a20 - a2) / 18

@@ -44,7 +44,7 @@ def test_bench_line_contract_short_run():
         assert 0.0 < c["step_frac_of_mfma_peak"] < 0.5 and 0.0 < c["clip_adamw_share"] < 0.9
     assert d["configs"]["c5_large_b32"]["adamw_ms_one_eighth_shard"] < d["configs"]["c5_large_b32"]["clip_adamw_ms"]
     sw = dec["rows_sweep"]
-    assert set(sw) == {"160", "320", "512"} and all(v["ms_per_token_step"] > 0 for v in sw.values())
+    assert set(sw) == {"100", "160", "320", "512"} and all(v["ms_per_token_step"] > 0 for v in sw.values())
     assert sw["512"]["tokens_per_sec"] > dec["tokens_per_sec"]                 # more rows per launch: more tokens per second
     assert dec["weight_bytes_per_token_step"] == 2 * (12 * (6 * 768 * 768 + 2 * 768 * 3072) + 32200 * 768)
 
