@@ -15,7 +15,9 @@ from vqacl_amd import VLT5Config, VLT5VQA  # noqa: E402
 B = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 80
 dev = torch.device("cuda")
 torch.manual_seed(1)
-model = VLT5VQA(VLT5Config(dropout_rate=0.1), device=dev)
+LARGE = "--large" in sys.argv                       # VL-T5-large (BASELINE configs[4]): d = 1024, 16 heads, d_ff = 4096, 24 + 24 layers
+kw = dict(d_model=1024, num_heads=16, d_ff=4096, num_layers=24) if LARGE else {}
+model = VLT5VQA(VLT5Config(dropout_rate=0.1, **kw), device=dev)
 model.eval()
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synthetic_batch(Cfg(), B=B, L=20, V=36, T=5, seed=3, task_id=0).items()}
 fb = (batch["vis_feats"], batch["boxes"])
