@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Does the order of dist.init_process_group() and the first GPU touch change the speed of a DataParallelVLT5 step?  (Round 5: with a HIGH-priority
+communication stream a step took 26 ms instead of 9.2 whenever the GPU had been touched before init; profiles/r05_w_comm_stream_priority.txt.)
+    python tools/dp_first_model_probe.py {init_first | touch_then_init | import_then_init | init_late | extra_gpu_work}
+environment: PROBE_PG_PRIO=0 (process group stream at normal priority), PROBE_EAGER=0 (no device_id), PROBE_COMM_PRIO=0 (wrapper stream forced normal)."""
 import os, sys, time, socket
 sys.path.insert(0, "/root/repo")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -40,5 +45,6 @@ for rep in range(3):
     for _ in range(5): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): step()
-    torch.cuda.synchronize(); print(mode, "block", rep, round((time.perf_counter() - t0) / 20 * 1e3, 2), "ms/step", flush=True)
+    torch.cuda.synchronize(); ms = round((time.perf_counter() - t0) / 20 * 1e3, 2); print(mode, "block", rep, ms, "ms/step", flush=True)
+print("RESULT", mode, ms, getattr(dp.comm_stream, "priority", None), flush=True)
 dist.destroy_process_group()
