@@ -4,7 +4,7 @@ communication stream a step took 26 ms instead of 9.2 whenever the GPU had been 
     python tools/dp_first_model_probe.py {init_first | touch_then_init | import_then_init | init_late | extra_gpu_work}
 environment: PROBE_PG_PRIO=0 (process group stream at normal priority), PROBE_EAGER=0 (no device_id), PROBE_COMM_PRIO=0 (wrapper stream forced normal)."""
 import os, sys, time, socket
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch
 mode = sys.argv[1]
