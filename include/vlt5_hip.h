@@ -421,6 +421,11 @@ typedef struct {
     long long *idxQ, *idxV;                     /* out: [B] argmax indices */
     float* out_f32; long long out_sb; void* out_bf16; long long out_sb_bf16;
     float* scratch;
+    /* data parallel (round 5): the head in two halves around ONE all-reduce of `packed` -- [class sums Q (CQ*d) | counts Q (CQ) | class sums
+     * V (CV*d) | counts V (CV)], (CQ + CV) * (d + 1) floats.  phase 1: pooling + the batch's class SUMS and counts into `packed` (no state
+     * change, no retrieval); phase 2: class means of the GLOBAL batch = packed sums / max(count, 1), the state update, the normalised
+     * copies and the retrieval of both heads.  phase 0 (default): the single-process head, `packed` unused. */
+    float* packed; int phase;
 } vlt5_proto_head_desc;
 int vlt5_proto_head_fwd(const vlt5_proto_head_desc* h, void* stream);
 

@@ -1143,3 +1143,68 @@ def test_mirror_rows_bf16_and_proto_stats_pack(dev):
     assert torch.equal(numQ, want[CQ * dm:CQ * dm + CQ] * 2) and torch.equal(numV, want[-CV:] * 2)
     assert torch.allclose(curQ, 2 * q0 * (numQ / 2).clamp(min=1)[:, None] / numQ.clamp(min=1)[:, None], rtol=1e-6, atol=1e-7)
     assert torch.allclose(curV, 2 * v0 * (numV / 2).clamp(min=1)[:, None] / numV.clamp(min=1)[:, None], rtol=1e-6, atol=1e-7)
+
+
+def test_prototype_head_in_two_halves_equals_the_single_process_head(dev):
+    """vlt5_proto_head_fwd with phase 1 (pooling + class sums / counts -> packed) and phase 2 (update + normalise + retrieve from packed) -- the
+    data-parallel form -- against the single-process head on the same batch: with nothing reduced in between the prototypes, counts, memory
+    tensor and retrieved indices are bit-identical, over a scripted task sequence (first batch of task 0, a second batch, first and second
+    batch of task 1: every branch of update_prototype).  Doubling `packed` in between = two ranks with the same batch: same means, twice the counts."""
+    import ctypes as C
+    from vqacl_amd import _lib as L
+    from vqacl_amd._lib import check, lib, ptr, stream_ptr
+    from vqacl_amd.prototype import PrototypeHead
+    g = torch.Generator().manual_seed(11)
+    B, S, d, split, CQ, CV = 12, 30, 64, 20, 10, 80
+    ref, two, dbl = (PrototypeHead(CQ, CV, d, dev) for _ in range(3))
+
+    def halves(head, enc, encb, ql, cl, task, scale=1.0):
+        h = L.ProtoHeadDesc()
+        poolQ, poolV = torch.empty(B, d, device=dev), torch.empty(B, d, device=dev)
+        idxQ, idxV = torch.empty(B, dtype=torch.long, device=dev), torch.empty(B, dtype=torch.long, device=dev)
+        scratch = torch.empty((CQ + CV) * d, device=dev)
+        packed = torch.empty((CQ + CV) * (d + 1), device=dev)
+        first = task not in head.seen_tasks
+        qmem, qinit = None, 0
+        if not first and task != 0:
+            if task in head.Q_task_mem_proto:
+                qmem, qinit = head.Q_task_mem_proto[task], 1
+            else:
+                qmem = torch.empty_like(head.Q_prototype)
+                head.Q_task_mem_proto[task] = qmem
+        h.hidden, h.hidden_sb, h.B, h.S, h.d, h.split = ptr(enc), enc.stride(0), B, S, d, split
+        h.poolQ, h.poolV, h.idxQ, h.idxV = ptr(poolQ), ptr(poolV), ptr(idxQ), ptr(idxV)
+        h.Qproto, h.Vproto, h.Qnum, h.Vnum = ptr(head.Q_prototype), ptr(head.V_prototype), ptr(head.Q_prototype_num), ptr(head.V_prototype_num)
+        h.CQ, h.CV, h.alpha, h.beta = CQ, CV, 0.5, 0.3
+        h.out_f32, h.out_sb, h.out_bf16, h.out_sb_bf16 = ptr(enc[:, S]), (S + 2) * d, ptr(encb[:, S]), (S + 2) * d
+        h.scratch, h.packed = ptr(scratch), ptr(packed)
+        h.onehotQ, h.onehotV, h.qmem, h.qmem_initialised = ptr(ql), ptr(cl), ptr(qmem), qinit
+        h.first, h.task, h.update, h.phase = int(first), task, 1, 1
+        check(lib().vlt5_proto_head_fwd(C.byref(h), stream_ptr()), "phase 1")
+        if scale != 1.0:
+            packed.mul_(scale)
+        h.phase = 2
+        check(lib().vlt5_proto_head_fwd(C.byref(h), stream_ptr()), "phase 2")
+        head.seen_tasks.add(task)
+        torch.cuda.synchronize()
+        return idxQ, idxV
+    for step, task in enumerate((0, 0, 1, 1)):
+        enc = torch.randn(B, S + 2, d, generator=g).to(dev)
+        encs = [enc.clone() for _ in range(3)]
+        encb = [torch.zeros(B, S + 2, d, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+        ql = torch.zeros(B, CQ).scatter_(1, torch.full((B, 1), task), 1.0)
+        if step == 3:
+            ql = torch.zeros(B, CQ).scatter_(1, torch.randint(0, 2, (B, 1), generator=g), 1.0)     # rehearsal-style: both question types
+        cl = torch.zeros(B, CV).scatter_(1, torch.randint(0, 16, (B, 1), generator=g), 1.0)
+        ql, cl = ql.to(dev), cl.to(dev)
+        _, _, iq, iv = ref.forward(encs[0], encb[0], S, split, ql, cl, task, 0.5, 0.3, update=True)
+        jq, jv = halves(two, encs[1], encb[1], ql, cl, task)
+        halves(dbl, encs[2], encb[2], ql, cl, task, scale=2.0)
+        torch.cuda.synchronize()
+        assert torch.equal(ref.Q_prototype, two.Q_prototype) and torch.equal(ref.V_prototype, two.V_prototype), step
+        assert torch.equal(ref.Q_prototype_num, two.Q_prototype_num) and torch.equal(ref.V_prototype_num, two.V_prototype_num)
+        assert torch.equal(iq, jq) and torch.equal(iv, jv)
+        assert torch.equal(encs[0][:, S:], encs[1][:, S:]) and torch.equal(encb[0][:, S:], encb[1][:, S:])     # the retrieved rows
+        assert torch.allclose(dbl.Q_prototype, ref.Q_prototype, rtol=1e-6, atol=1e-7) and torch.allclose(dbl.V_prototype, ref.V_prototype, rtol=1e-6, atol=1e-7)
+        assert torch.equal(dbl.V_prototype_num, 2 * ref.V_prototype_num)
+    assert 1 in two.Q_task_mem_proto and torch.equal(ref.Q_task_mem_proto[1], two.Q_task_mem_proto[1])

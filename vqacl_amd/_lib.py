@@ -110,7 +110,7 @@ class ProtoHeadDesc(C.Structure):
                 ("onehotQ", vp), ("onehotV", vp), ("Qproto", vp), ("Vproto", vp), ("Qnum", vp), ("Vnum", vp), ("qmem", vp),
                 ("qmem_initialised", c_i), ("first", c_i), ("task", c_i), ("update", c_i), ("alpha", c_f), ("beta", c_f),
                 ("CQ", c_i), ("CV", c_i), ("idxQ", vp), ("idxV", vp), ("out_f32", vp), ("out_sb", c_ll), ("out_bf16", vp),
-                ("out_sb_bf16", c_ll), ("scratch", vp)]
+                ("out_sb_bf16", c_ll), ("scratch", vp), ("packed", vp), ("phase", c_i)]
 
 
 class GemmTimingRec(C.Structure):

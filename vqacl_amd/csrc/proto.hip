@@ -196,7 +196,15 @@ struct HeadArgs {
     int qmem_init, first, task, update;
     float alpha, beta;
     int B, CQ, CV, d;
+    float* packed; int phase;          // data parallel: 1 = class sums + counts of the local batch -> packed; 2 = the update from the all-reduced packed
 };
+// packed = [sums Q (CQ*d) | counts Q (CQ) | sums V (CV*d) | counts V (CV)]  (the layout of vlt5_proto_stats_pack)
+__device__ __forceinline__ float* packed_sums(const HeadArgs& a, bool isQ, int cls) {
+    return a.packed + (isQ ? (size_t)cls * a.d : (size_t)a.CQ * (a.d + 1) + (size_t)cls * a.d);
+}
+__device__ __forceinline__ float* packed_count(const HeadArgs& a, bool isQ, int cls) {
+    return a.packed + (isQ ? (size_t)a.CQ * a.d + cls : (size_t)a.CQ * (a.d + 1) + (size_t)a.CV * a.d + cls);
+}
 __global__ __launch_bounds__(256) void proto_row_kernel(HeadArgs a) {
     extern __shared__ float wgt[];                 // [B] one-hot column of this class
     __shared__ float sh[4];
@@ -207,10 +215,29 @@ __global__ __launch_bounds__(256) void proto_row_kernel(HeadArgs a) {
     float* P = (isQ ? a.Qp : a.Vp) + (size_t)cls * d;
     float* An = (isQ ? a.AnQ : a.AnV) + (size_t)cls * d;
     if (a.update) {
-        for (int b = threadIdx.x; b < a.B; b += blockDim.x) wgt[b] = onehot[(size_t)b * C + cls];
-        __syncthreads();
         float n = 0.f;
-        for (int b = 0; b < a.B; ++b) n += wgt[b];
+        if (a.phase != 2) {
+            for (int b = threadIdx.x; b < a.B; b += blockDim.x) wgt[b] = onehot[(size_t)b * C + cls];
+            __syncthreads();
+            for (int b = 0; b < a.B; ++b) n += wgt[b];
+        } else {
+            n = *packed_count(a, isQ, cls);            // the global batch's count of this class
+        }
+        if (a.phase == 1) {                            // local class sums + count, nothing else (the all-reduce comes next)
+            if (threadIdx.x == 0) *packed_count(a, isQ, cls) = n;
+            float* dst = packed_sums(a, isQ, cls);
+            for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+                for (int b = 0; b < a.B; ++b) {
+                    const float w = wgt[b];
+                    const float4 v = *reinterpret_cast<const float4*>(pool + (size_t)b * d + c);
+                    s.x += w * v.x; s.y += w * v.y; s.z += w * v.z; s.w += w * v.w;
+                }
+                dst[c] = s.x; dst[c + 1] = s.y; dst[c + 2] = s.z; dst[c + 3] = s.w;
+            }
+            return;
+        }
         const float div = n <= 0.f ? 1.f : n;
         if (threadIdx.x == 0) {
             float* num = isQ ? a.Qnum : a.Vnum;
@@ -218,11 +245,16 @@ __global__ __launch_bounds__(256) void proto_row_kernel(HeadArgs a) {
         }
         for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.phase == 2) {
+                const float* src = packed_sums(a, isQ, cls);
+                s = make_float4(src[c], src[c + 1], src[c + 2], src[c + 3]);
+            } else {
 #pragma unroll 8
-            for (int b = 0; b < a.B; ++b) {
-                const float w = wgt[b];
-                const float4 v = *reinterpret_cast<const float4*>(pool + (size_t)b * d + c);
-                s.x += w * v.x; s.y += w * v.y; s.z += w * v.z; s.w += w * v.w;
+                for (int b = 0; b < a.B; ++b) {
+                    const float w = wgt[b];
+                    const float4 v = *reinterpret_cast<const float4*>(pool + (size_t)b * d + c);
+                    s.x += w * v.x; s.y += w * v.y; s.z += w * v.z; s.w += w * v.w;
+                }
             }
             const float cur[4] = {s.x / div, s.y / div, s.z / div, s.w / div};
 #pragma unroll
@@ -409,13 +441,16 @@ extern "C" int vlt5_proto_head_fwd(const vlt5_proto_head_desc* h, void* stream) 
     if (!h || !h->hidden || !h->poolQ || !h->poolV || !h->Qproto || !h->Vproto || !h->scratch || !h->idxQ || !h->idxV) return VLT5_ERR_ARG;
     if (h->B <= 0 || h->S <= 0 || h->CQ <= 0 || h->CV <= 0 || h->split <= 0) return VLT5_ERR_ARG;
     if ((h->d & 3) || h->d > 2048 || (h->hidden_sb & 3)) return VLT5_ERR_ALIGN;
+    if (h->phase < 0 || h->phase > 2 || (h->phase != 0 && (!h->packed || !h->update))) return VLT5_ERR_ARG;
     if (h->update) {
-        if (!h->onehotQ || !h->onehotV || !h->Qnum || !h->Vnum || h->task < 0 || h->task >= h->CQ) return VLT5_ERR_ARG;
+        if ((h->phase != 2 && (!h->onehotQ || !h->onehotV)) || !h->Qnum || !h->Vnum || h->task < 0 || h->task >= h->CQ) return VLT5_ERR_ARG;
         if (!h->first && h->task != 0 && !h->qmem) return VLT5_ERR_ARG;
     }
-    int rc = vlt5_proto_pool(h->hidden, h->hidden_sb, h->B, h->S, h->d, h->split, h->poolQ, h->poolV, stream);
+    int rc = VLT5_OK;
+    if (h->phase != 2) rc = vlt5_proto_pool(h->hidden, h->hidden_sb, h->B, h->S, h->d, h->split, h->poolQ, h->poolV, stream);
     if (rc) return rc;
     HeadArgs a;
+    a.packed = h->packed; a.phase = h->phase;
     a.poolQ = h->poolQ; a.poolV = h->poolV; a.onehotQ = h->onehotQ; a.onehotV = h->onehotV;
     a.Qp = h->Qproto; a.Vp = h->Vproto; a.Qnum = h->Qnum; a.Vnum = h->Vnum; a.qmem = h->qmem;
     a.AnQ = h->scratch; a.AnV = h->scratch + (size_t)h->CQ * h->d;
@@ -423,6 +458,7 @@ extern "C" int vlt5_proto_head_fwd(const vlt5_proto_head_desc* h, void* stream) 
     a.B = h->B; a.CQ = h->CQ; a.CV = h->CV; a.d = h->d;
     hipLaunchKernelGGL(proto_row_kernel, dim3(h->CQ + h->CV), dim3(256), h->B * sizeof(float), ST, a);
     LAUNCH_CHECK();
+    if (h->phase == 1) return VLT5_OK;                  // (the caller all-reduces `packed`, then calls again with phase = 2)
     Retrieve2 r;
     r.protos[0] = h->Qproto; r.protos[1] = h->Vproto; r.An[0] = a.AnQ; r.An[1] = a.AnV; r.pool[0] = h->poolQ; r.pool[1] = h->poolV;
     r.idx[0] = h->idxQ; r.idx[1] = h->idxV; r.C[0] = h->CQ; r.C[1] = h->CV;

@@ -528,7 +528,14 @@ class VLT5(nn.Module):
             check(lib().vlt5_encoder_fwd(C.byref(c), C.byref(cs), stream), "vlt5_encoder_fwd")
             # SS/SI prototype head (modeling_t5_our.py:583-615)
             fused_head = not self.proto.dist_enabled and not (proto_update and memory) and os.environ.get("VQACL_FUSED_HEAD", "1") != "0"
-            if fused_head:          # pooling, state update and retrieval of both heads in three launches (vlt5_proto_head_fwd)
+            dist_head = (self.proto.dist_enabled and proto_update and not memory and enc_f32.is_cuda
+                         and os.environ.get("VQACL_FUSED_HEAD", "1") != "0")
+            if dist_head:           # data parallel: the same head in two halves around one all-reduce of the class statistics (four launches)
+                ql = to_device(ques_labels, dev, torch.float32)
+                cl = to_device(cate_labels, dev, torch.float32)
+                poolQ, poolV, idxQ, idxV = self.proto.forward_dist(enc_f32, enc_bf16, S, self.L, ql, cl, int(current_task_id),
+                                                                   float(proto_alpha), float(proto_beta))
+            elif fused_head:        # pooling, state update and retrieval of both heads in three launches (vlt5_proto_head_fwd)
                 ql = to_device(ques_labels, dev, torch.float32) if proto_update else None
                 cl = to_device(cate_labels, dev, torch.float32) if proto_update else None
                 poolQ, poolV, idxQ, idxV = self.proto.forward(enc_f32, enc_b16, S, self.L, ql, cl, int(current_task_id), float(proto_alpha),

@@ -133,6 +133,53 @@ class PrototypeHead:
         del keep
         return poolQ, poolV, idxQ, idxV
 
+    def forward_dist(self, enc_f32, enc_bf16, S: int, split: int, ques_labels, cate_labels, task: int, alpha: float, beta: float):
+        """The training head under data parallelism in two halves around ONE all-reduce (vlt5_proto_head_desc.phase, round 5): pooling +
+        the local batch's class sums and counts -> `packed`; all-reduce; class means of the GLOBAL batch, the state update, the normalised
+        copies and the retrieval of both heads -- four launches instead of ten, and every rank holds the prototypes a single process
+        would compute on the concatenated batch.  Returns (poolQ, poolV, idxQ, idxV)."""
+        import ctypes as C
+        import torch.distributed as dist
+        B, Sx, d = enc_f32.shape
+        dev = enc_f32.device
+        h = L.ProtoHeadDesc()
+        poolQ = torch.empty(B, d, device=dev, dtype=torch.float32)
+        poolV = torch.empty(B, d, device=dev, dtype=torch.float32)
+        idxQ = torch.empty(B, device=dev, dtype=torch.int64)
+        idxV = torch.empty(B, device=dev, dtype=torch.int64)
+        if getattr(self, "_scratch", None) is None:
+            self._scratch = torch.empty((self.CQ + self.CV) * d, device=dev, dtype=torch.float32)
+        n = (self.CQ + self.CV) * (d + 1)
+        if getattr(self, "_packed", None) is None or self._packed.numel() != n:
+            self._packed = torch.empty(n, device=dev, dtype=torch.float32)
+        ql, cl = ques_labels.contiguous(), cate_labels.contiguous()
+        first = task not in self.seen_tasks
+        qmem, qinit = None, 0
+        if not first and task != 0:
+            if task in self.Q_task_mem_proto:
+                qmem, qinit = self.Q_task_mem_proto[task], 1
+            else:
+                qmem = torch.empty_like(self.Q_prototype)
+                self.Q_task_mem_proto[task] = qmem
+        h.hidden, h.hidden_sb, h.B, h.S, h.d, h.split = ptr(enc_f32), enc_f32.stride(0), B, S, d, split
+        h.poolQ, h.poolV = ptr(poolQ), ptr(poolV)
+        h.Qproto, h.Vproto, h.Qnum, h.Vnum = ptr(self.Q_prototype), ptr(self.V_prototype), ptr(self.Q_prototype_num), ptr(self.V_prototype_num)
+        h.CQ, h.CV, h.alpha, h.beta = self.CQ, self.CV, float(alpha), float(beta)
+        h.idxQ, h.idxV = ptr(idxQ), ptr(idxV)
+        h.out_f32, h.out_sb = ptr(enc_f32[:, S]), Sx * d
+        h.out_bf16, h.out_sb_bf16 = ptr(enc_bf16[:, S]), Sx * d
+        h.scratch, h.packed = ptr(self._scratch), ptr(self._packed)
+        h.onehotQ, h.onehotV, h.qmem, h.qmem_initialised = ptr(ql), ptr(cl), ptr(qmem), qinit
+        h.first, h.task, h.update = int(first), int(task), 1
+        h.phase = 1
+        check(lib().vlt5_proto_head_fwd(C.byref(h), stream_ptr()), "vlt5_proto_head_fwd (phase 1)")
+        dist.all_reduce(self._packed, group=self.dist_group)
+        h.phase = 2
+        check(lib().vlt5_proto_head_fwd(C.byref(h), stream_ptr()), "vlt5_proto_head_fwd (phase 2)")
+        self.seen_tasks.add(task)
+        del ql, cl, qmem
+        return poolQ, poolV, idxQ, idxV
+
     def memory_loss(self, poolQ, poolV, ques_labels, cate_labels):
         return (ops.proto_memory_loss(poolQ, ques_labels, self.Q_prototype),
                 ops.proto_memory_loss(poolV, cate_labels, self.V_prototype))
