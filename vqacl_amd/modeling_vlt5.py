@@ -533,7 +533,7 @@ class VLT5(nn.Module):
             if dist_head:           # data parallel: the same head in two halves around one all-reduce of the class statistics (four launches)
                 ql = to_device(ques_labels, dev, torch.float32)
                 cl = to_device(cate_labels, dev, torch.float32)
-                poolQ, poolV, idxQ, idxV = self.proto.forward_dist(enc_f32, enc_bf16, S, self.L, ql, cl, int(current_task_id),
+                poolQ, poolV, idxQ, idxV = self.proto.forward_dist(enc_f32, enc_b16, S, self.L, ql, cl, int(current_task_id),
                                                                    float(proto_alpha), float(proto_beta))
             elif fused_head:        # pooling, state update and retrieval of both heads in three launches (vlt5_proto_head_fwd)
                 ql = to_device(ques_labels, dev, torch.float32) if proto_update else None
