@@ -277,3 +277,132 @@ def compare_seeds(curves_e, curves_o, window=10):
         zs.append((a, me, mo, (me - mo) / se if se > 0 else 0.0, se))
     within = sum(abs(z[3]) <= 2.0 for z in zs) / len(zs)
     return zs, within
+
+
+class _Moments:
+    """Running first / second moments over dropout seeds (f64 on the device), with the first moment also kept per half (even / odd
+    seeds) so the seed noise left in a mean can be read off the data: cos(mean_A, mean_B)."""
+
+    def __init__(self):
+        self.n, self.s, self.q, self.half = 0, {}, {}, ({}, {})
+
+    def add(self, **xs):
+        for k, x in xs.items():
+            x = x.detach().double().reshape(-1)
+            if k not in self.s:
+                self.s[k], self.q[k] = torch.zeros_like(x), torch.zeros_like(x)
+                self.half[0][k], self.half[1][k] = torch.zeros_like(x), torch.zeros_like(x)
+            self.s[k] += x
+            self.q[k] += x * x
+            self.half[self.n & 1][k] += x
+        self.n += 1
+
+    def mean(self, k):
+        return self.s[k] / self.n
+
+    def var_sum(self, k):
+        """Sum over the elements of the unbiased per-element variance over the seeds."""
+        m = self.mean(k)
+        return float(((self.q[k] - self.n * m * m) / (self.n - 1)).clamp(min=0).sum())
+
+
+def _cos(a, b):
+    return float(torch.dot(a, b) / (a.norm() * b.norm()).clamp(min=1e-300))
+
+
+def dropout_moments(dev, ocfg, B=80, K=32, p=0.1, warm_steps=0, init_seed=3, data_seed=1234, lr=1e-4, log=None):
+    """The benched configuration (dropout on) against the oracle WITHOUT a shared random stream: from the same weights and on the same
+    batch, K dropout seeds per side (the engine's counter-hash masks, torch's generator); what must agree is the DISTRIBUTION over the
+    seeds -- the mean and the per-element variance of the loss, the encoder output, the decoder output, the logits and the gradient.
+    A dropout site that is missing, doubled, applied with another probability or scale, or whose backward uses another mask than its
+    forward shows up as a variance ratio off 1 or as a mean gradient that points elsewhere (oracle alone, one of the 24 sites of the
+    tiny model removed: variance ratios 0.57-0.99, most sites 0.93-0.97).
+
+    warm_steps > 0: that many dropout-off optimizer steps of the ENGINE first, both sides then start from its weights (away from the
+    initialisation, where the loss barely reacts to the masks).  The prototype memory is initialised by one eval-mode train_step per
+    side and then left alone (proto_update=False), so the seeds are independent draws."""
+    from oracle import ref_cpu as R
+    import dataclasses
+    data = SyntheticVQA(dev, seed=data_seed, feat_dim=ocfg.feat_dim, n_ques=ocfg.n_ques, n_cate=ocfg.n_cate)
+    params = R.init_params(ocfg, seed=init_seed)
+    eng = EngineSide(dev, ocfg, params, 0.0, 0, lr)
+    if warm_steps:
+        eng.new_stage()
+        for i in range(warm_steps):
+            eng.step(data.batch(B, 0, 0, 20_000 + i), 0, warmup_scale(i, max(1, warm_steps // 20)))
+        sd = eng.model.state_dict()
+        params = {k: sd[k].detach().float().cpu().clone() for k in params}
+    batch = data.batch(B, 0, 0, 77_777)
+    names = [k for k in params if not k.startswith("prototype_fc")]
+    ocfg_p = dataclasses.replace(ocfg, dropout=p)
+    orc = R.OracleModel(ocfg_p, {k: v.to(dev) for k, v in params.items()})
+    model = eng.model
+    # prototype memory: one eval-mode step per side
+    model.eval()
+    with torch.no_grad():
+        model.train_step(batch, 0, 0.5, 0.3)
+        with torch.device(dev):
+            orc.train_step(batch, 0, 0.5, 0.3, training=False)
+    fwd_kw = dict(input_ids=batch["input_ids"], labels=batch["target_ids"], cate_labels=batch["cate_labels"], ques_labels=batch["ques_labels"],
+                  proto_update=False)
+
+    def engine_draw(seed, training=True):
+        model.train(training)
+        model.cfg.dropout_rate = p
+        model.base_seed, model._step_count = (0x5EED + 7919 * seed) & 0x7FFFFFFF, 0
+        for q in model.parameters():
+            q.grad = None
+        out = model(vis_inputs=(batch["vis_feats"], batch["boxes"]), scores=batch["scores"], **fwd_kw)
+        out["loss_reduced"].backward()
+        g = torch.cat([model._params_by_name[k].grad.reshape(-1) for k in names])
+        return dict(loss=out["loss_reduced"].reshape(1), enc=out["encoder_hidden_states"], dec=out["decoder_last_hidden_state"],
+                    logits=out["logits"], grad=g)
+
+    def oracle_draw(seed, training=True):
+        torch.manual_seed(1_000_003 * (seed + 1))
+        torch.cuda.manual_seed(1_000_003 * (seed + 1))
+        orc.zero_grad()
+        with torch.device(dev):
+            out = R.vlt5_forward(orc.P, orc.state, ocfg_p, vis_feats=batch["vis_feats"], boxes=batch["boxes"], training=training, **fwd_kw)
+            loss = R.train_step_loss(out["loss"], batch["target_ids"], batch["scores"])
+            loss.backward()
+        g = torch.cat([orc.P[k].grad.reshape(-1) for k in names])
+        return dict(loss=loss.reshape(1), enc=out["encoder_hidden_states"], dec=out["decoder_last_hidden_state"], logits=out["logits"], grad=g)
+
+    # the masks off: the scale of the bf16 difference the means can at best agree to
+    e0, o0 = engine_draw(0, training=False), oracle_draw(0, training=False)
+    e0, o0 = {k: v.detach().double().reshape(-1) for k, v in e0.items()}, {k: v.detach().double().reshape(-1) for k, v in o0.items()}
+    base = {k: float((e0[k] - o0[k]).norm() / o0[k].norm().clamp(min=1e-300)) for k in e0}
+    base["grad_cos"] = _cos(e0["grad"], o0["grad"])
+    me, mo = _Moments(), _Moments()
+    for s in range(K):
+        me.add(**engine_draw(s))
+        mo.add(**oracle_draw(s))
+        if log and (s + 1) % 8 == 0:
+            log(f"  {s + 1} seeds per side")
+    r = dict(K=K, B=B, p=p, warm_steps=warm_steps, masks_off=base, keys={})
+    le, lo = me.mean("loss").item(), mo.mean("loss").item()
+    se = math.sqrt((me.var_sum("loss") + mo.var_sum("loss")) / K)
+    r["loss"] = dict(engine=le, oracle=lo, se=se, z=(le - lo) / se if se > 0 else 0.0, sd_engine=math.sqrt(me.var_sum("loss")),
+                     sd_oracle=math.sqrt(mo.var_sum("loss")), masks_off=(float(e0["loss"]), float(o0["loss"])))
+    for k in ("enc", "dec", "logits", "grad"):
+        a, b = me.mean(k), mo.mean(k)
+        ve, vo = me.var_sum(k), mo.var_sum(k)
+        r["keys"][k] = dict(var_ratio=ve / vo if vo > 0 else float("nan"),
+                            mean_rel_diff=float((a - b).norm() / b.norm()), noise_floor=math.sqrt((ve + vo) / K) / float(b.norm()),
+                            cos_means=_cos(a, b), cos_halves_engine=_cos(me.half[0][k], me.half[1][k]),
+                            cos_halves_oracle=_cos(mo.half[0][k], mo.half[1][k]), norm_ratio=float(a.norm() / b.norm()),
+                            noise_to_mean=math.sqrt(vo) / float(b.norm()))
+    return r
+
+
+def format_moments(r):
+    out = [f"dropout {r['p']}: {r['K']} seeds per side, B = {r['B']}, same weights ({r['warm_steps']} dropout-off optimizer steps from the initialisation) and batch",
+           f"  loss            engine {r['loss']['engine']:.5f}  oracle {r['loss']['oracle']:.5f}  difference {r['loss']['engine'] - r['loss']['oracle']:+.5f} = {r['loss']['z']:+.2f} standard errors "
+           f"(sd over seeds engine {r['loss']['sd_engine']:.5f} oracle {r['loss']['sd_oracle']:.5f}; masks off {r['loss']['masks_off'][0]:.5f} / {r['loss']['masks_off'][1]:.5f})",
+           "  quantity   variance over seeds engine/oracle   |mean_e - mean_o| / |mean_o|  (seed noise left in it, masks-off difference)   cos(mean_e, mean_o)  (halves: engine, oracle)   |mean_e| / |mean_o|   sd / |mean|"]
+    for k, v in r["keys"].items():
+        out.append(f"  {k:8s}   {v['var_ratio']:.4f}                               {v['mean_rel_diff']:.5f}  ({v['noise_floor']:.5f}, {r['masks_off'][k]:.5f})"
+                   f"                                  {v['cos_means']:.5f}  ({v['cos_halves_engine']:.5f}, {v['cos_halves_oracle']:.5f})          {v['norm_ratio']:.4f}   {v['noise_to_mean']:.3f}")
+    out.append(f"  masks off: cos(grad_e, grad_o) {r['masks_off']['grad_cos']:.5f}")
+    return out

@@ -38,6 +38,9 @@ for N in 2 4 8; do
   python3 bench.py --gpus $N --rehearsal --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $OUT/${TAG}_rehearsal_n$N.json 2> $OUT/${TAG}_rehearsal_n$N.err
 done
 python3 tools/trajectory.py --steps-per-stage 100 --out gpurun_out/${TAG}_trajectory.txt > /dev/null 2>&1
+# dropout on against the oracle in distribution: moments over dropout seeds from the same weights on the same batch
+python3 tools/dropout_moments.py --seeds 48 --warm 0 20 --out gpurun_out/${TAG}_dropout_moments.txt > /dev/null 2>&1
+python3 tools/dropout_moments.py --seeds 192 --warm 60 --out gpurun_out/${TAG}_dropout_moments_late.txt > /dev/null 2>&1
 python3 tools/step_graph_probe.py 4 8 16 32 80 2>&1 | grep -v "amdgpu.ids\|UserWarning\|detach()\|print(f" > $OUT/${TAG}_step_graph_probe.txt
 cd /tmp
 rm -rf $OUT/${TAG}_dk $OUT/${TAG}_dd
