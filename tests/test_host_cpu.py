@@ -254,3 +254,20 @@ def test_gradient_release_plan_covers_every_bucket_once_and_follows_the_tuning(b
     one = VLT5VQA(VLT5Config(d_model=64, d_kv=16, num_heads=4, d_ff=128, num_layers=1, num_decoder_layers=2, vocab_size=400, feat_dim=64),
                   device=torch.device("cpu"))
     assert sorted(covered(one.grad_release_plan())) == list(range(one._nbuckets)) and one.grad_release_plan()[0] == (0, 0, 3)
+
+
+def test_moment_accumulator_of_the_dropout_comparison():
+    """tests/trajectory_lib.py::_Moments (the statistics behind test_dropout_on_matches_the_oracle_in_distribution): running mean,
+    summed unbiased variance and the two half sums against torch on stacked samples."""
+    import trajectory_lib as T
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(7, 9, generator=g) * (1 + i % 3) + 0.5 for i in range(11)]
+    m = T._Moments()
+    for x in xs:
+        m.add(a=x, loss=x.sum().reshape(1))
+    st = torch.stack(xs).double().reshape(11, -1)
+    assert torch.allclose(m.mean("a"), st.mean(0), atol=1e-12)
+    assert abs(m.var_sum("a") - float(st.var(0, unbiased=True).sum())) < 1e-9
+    assert torch.allclose(m.half[0]["a"], st[0::2].sum(0), atol=1e-12) and torch.allclose(m.half[1]["a"], st[1::2].sum(0), atol=1e-12)
+    assert abs(m.var_sum("loss") - float(torch.stack([x.sum() for x in xs]).double().var(unbiased=True))) < 1e-9
+    assert abs(T._cos(st[0], st[0] * 3.0) - 1.0) < 1e-12

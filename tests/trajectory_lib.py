@@ -406,3 +406,28 @@ def format_moments(r):
                    f"                                  {v['cos_means']:.5f}  ({v['cos_halves_engine']:.5f}, {v['cos_halves_oracle']:.5f})          {v['norm_ratio']:.4f}   {v['noise_to_mean']:.3f}")
     out.append(f"  masks off: cos(grad_e, grad_o) {r['masks_off']['grad_cos']:.5f}")
     return out
+
+
+def first_stage_seeds(dev, ocfg, seeds=32, steps=60, B=80, lr=1e-4, lo=10, log=None):
+    """Many dropout seeds per side over the FIRST stage only (same weights at step 0, same batches): the per-seed mean loss over steps
+    lo..steps as the sample; returns means, standard deviations and z of the difference.  (The sharper look at 'does one side learn
+    faster under dropout' than the windows of the full schedule, whose neighbouring windows are not independent.)"""
+    stat = ([], [])
+    curves = ([], [])
+    for seed in range(seeds):
+        for s, name in enumerate(("engine", "oracle")):
+            r = run_pair(dev, ocfg, dropout=0.1, seed=seed, B=B, steps_per_stage=steps, n_tasks=1, n_groups=1, lr=lr, n_eval=1, sides=(name,))
+            c = r["losses"][0]
+            curves[s].append(c)
+            stat[s].append(sum(c[lo:]) / len(c[lo:]))
+        if log and (seed + 1) % 4 == 0:
+            log(f"  {seed + 1} seeds per side")
+
+    def ms(v):
+        m = sum(v) / len(v)
+        return m, (sum((x - m) ** 2 for x in v) / (len(v) - 1)) ** 0.5
+    (me, sde), (mo, sdo) = ms(stat[0]), ms(stat[1])
+    se = math.sqrt(sde ** 2 / seeds + sdo ** 2 / seeds)
+    zs, within = compare_seeds(curves[0], curves[1], window=10)
+    return dict(seeds=seeds, steps=steps, lo=lo, mean_engine=me, mean_oracle=mo, sd_engine=sde, sd_oracle=sdo, z=(me - mo) / se, se=se,
+                windows=zs, per_seed=stat)

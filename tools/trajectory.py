@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--eval", type=int, default=512)
     ap.add_argument("--seeds", type=int, default=5, help="seeds per side of the dropout-0.1 comparison (0: skip it)")
+    ap.add_argument("--first-stage-seeds", type=int, default=0, help="only this: N dropout seeds per side over the first stage (steps-per-stage steps)")
     ap.add_argument("--tiny", action="store_true", help="the tiny configuration (a quick look, not the figure)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -43,6 +44,18 @@ def main():
         f"{args.steps_per_stage} optimizer steps = {args.tasks * args.groups * args.steps_per_stage} steps; new AdamW + 5 % warm-up per (task, group), "
         f"clip 5, lr {args.lr:g}; from task 1 on every second step is a rehearsal batch of earlier tasks")
     log(f"# source_sha16 {source_hash()}   {time.strftime('%Y-%m-%d %H:%M:%S')}   checker: oracle/ref_cpu.py as torch eager fp32 on the same GPU")
+    if args.first_stage_seeds:
+        log(f"\n## dropout 0.1, first stage only ({args.steps_per_stage} steps from the same weights on the same batches), {args.first_stage_seeds} seeds per side")
+        r = T.first_stage_seeds(dev, ocfg, seeds=args.first_stage_seeds, steps=args.steps_per_stage, B=args.batch, lr=args.lr, log=log)
+        log(f"per-seed mean loss over steps {r['lo']}..{r['steps']}: engine {r['mean_engine']:.5f} (sd {r['sd_engine']:.5f})  oracle {r['mean_oracle']:.5f} (sd {r['sd_oracle']:.5f})  "
+            f"difference {r['mean_engine'] - r['mean_oracle']:+.5f} = {r['z']:+.2f} standard errors ({r['se']:.5f})")
+        log("  window start, mean engine, mean oracle, z, sigma")
+        for a, me, mo, z, se in r["windows"]:
+            log(f"  {a:4d}  {me:.4f}  {mo:.4f}  {z:+.2f}  {se:.4f}")
+        if args.out:
+            with open(os.path.join(ROOT, args.out) if not os.path.isabs(args.out) else args.out, "w") as fh:
+                fh.write("\n".join(lines) + "\n")
+        return
     kw = dict(B=args.batch, steps_per_stage=args.steps_per_stage, n_tasks=args.tasks, n_groups=args.groups, lr=args.lr, n_eval=args.eval)
     log("\n## dropout off: engine and oracle on the same batches from the same weights")
     r = T.run_pair(dev, ocfg, dropout=0.0, log=log, **kw)
@@ -82,6 +95,9 @@ def main():
             return m, (sum((x - m) ** 2 for x in v) / max(1, len(v) - 1)) ** 0.5
         (me, se), (mo, so) = ms(acc_e), ms(acc_o)
         log(f"held-out accuracy over seeds: engine {100 * me:.2f} +- {100 * se:.2f} %, oracle {100 * mo:.2f} +- {100 * so:.2f} %")
+        n = len(acc_e)
+        sed = (se ** 2 / n + so ** 2 / n) ** 0.5
+        log(f"difference of the means engine - oracle: {100 * (me - mo):+.2f} points, standard error {100 * sed:.2f} ({n} seeds per side, {len(re_['truth'])} held-out questions each)")
     if args.out:
         with open(os.path.join(ROOT, args.out) if not os.path.isabs(args.out) else args.out, "w") as fh:
             fh.write("\n".join(lines) + "\n")
