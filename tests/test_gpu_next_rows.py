@@ -106,6 +106,29 @@ def test_h5_layout_source_fills_the_store(dev):
         assert float(gb[r].max()) <= 1.0
 
 
+def test_real_hdf5_file_fills_the_store(dev):
+    """A REAL HDF5 file in the reference's layout (tests/golden/g10_feature_file.h5: written by libhdf5, the library h5py wraps) read by
+    path -- h5py when installed, otherwise vqacl_amd.hdf5_io -- into the HBM store at the reference's feature width."""
+    import os
+    import numpy as np
+    from vqacl_amd import hdf5_io
+    from vqacl_amd.feed import FeatureStore, H5FeatureSource
+    if hdf5_io.find_library() is None:
+        pytest.skip("libhdf5 not on this machine")
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ref = np.load(os.path.join(gold, "g10_feature_items.npz"))
+    ids = ["9", "COCO_val2014_000000000042", "458752"]
+    store = FeatureStore(4, n_boxes=36, feat_dim=2048, device=dev)
+    src = H5FeatureSource(os.path.join(gold, "g10_feature_file.h5"))
+    src.fill(store, ids, chunk=2)
+    gf, gb = store.gather(store.slots(ids))
+    for r, i in enumerate(ids):
+        feats, _ = src.read(i)
+        assert torch.equal(gf[r].cpu(), feats.to(BF))                                   # the store's rounding = the engine's rounding of an f32 batch
+        assert torch.equal(gb[r].cpu(), torch.from_numpy(ref[f"{i}/boxes"]))            # = what the reference's item read returned
+        assert abs(float(gf[r].double().sum()) - float(ref[f"{i}/vis_feats_sum"])) < 2e-3 * float(ref[f"{i}/vis_feats_sum"])
+
+
 def test_train_and_test_step_from_store_equal_the_f32_batch(dev):
     """Feeding a step from the store changes nothing downstream: same encoder states bit for bit, same loss, same tokens."""
     from oracle import ref_cpu as R

@@ -1,0 +1,109 @@
+"""Real HDF5 ingestion without h5py: `vqacl_amd.hdf5_io` (ctypes over libhdf5, the C library h5py wraps) against a file
+in the reference's layout -- tests/golden/g10_feature_file.h5, written by that library from seeded arrays (oracle/make_golden_h5.py) --
+and against what the reference's own item-read statements (vqa_data_memory.py:166-187) returned for it (g10_feature_items.npz)."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from vqacl_amd import hdf5_io as H
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PATH = os.path.join(GOLD, "g10_feature_file.h5")
+pytestmark = pytest.mark.skipif(H.find_library() is None, reason="libhdf5 not on this machine")
+
+
+def seeded():
+    from oracle.make_golden_h5 import IMAGES, seeded_items
+    return IMAGES, seeded_items()
+
+
+def test_library_loads_and_reports_its_version():
+    assert H.library_version() >= (1, 8, 0)
+
+
+def test_golden_file_reads_back_the_seeded_arrays_through_the_h5py_style_interface():
+    images, items = seeded()
+    with H.H5File(PATH) as f:
+        assert sorted(f.keys()) == sorted(i for i, _, _ in images) and len(f) == 3
+        for img_id, w, h in images:
+            assert img_id in f and f"{img_id}/features" in f and f"{img_id}/nothing" not in f and f"x{img_id}/features" not in f
+            d = f[f"{img_id}/features"]
+            assert d.shape == (36, 2048) and d.dtype == np.float32 and len(d) == 36 and d.size == 36 * 2048
+            feats = np.zeros((36, 2048), dtype=np.float32)
+            d.read_direct(feats)                                          # the reference's call (vqa_data_memory.py:167)
+            assert np.array_equal(feats, items[img_id]["features"])
+            assert np.array_equal(d[()], feats) and np.array_equal(d[...], feats) and np.array_equal(d[3:5, :7], feats[3:5, :7])
+            wide = np.zeros((36, 2048), dtype=np.float64)
+            d.read_direct(wide)                                           # HDF5 converts to the destination's type
+            assert np.array_equal(wide, feats.astype(np.float64))
+            iw, ih = f[f"{img_id}/img_w"][()], f[f"{img_id}/img_h"][()]
+            assert isinstance(iw, np.int64) and (int(iw), int(ih)) == (w, h) and f[f"{img_id}/img_w"].shape == ()
+            grp = f[img_id]
+            assert sorted(grp.keys()) == ["boxes", "features", "img_h", "img_w", "obj_conf", "obj_id"]
+            assert np.array_equal(grp["obj_id"][()], items[img_id]["obj_id"]) and grp["obj_id"].dtype == np.int64
+            assert np.array_equal(grp["boxes"][()], items[img_id]["boxes"])
+        with pytest.raises(KeyError):
+            f["12345/features"]                                           # (the reference catches exactly this: :168)
+        with pytest.raises(TypeError):
+            f["9/features"].read_direct(np.zeros((36, 2047), dtype=np.float32))
+        with pytest.raises(TypeError):
+            f["9/features"].read_direct(np.zeros((2048, 36), dtype=np.float32).T)      # not C-contiguous
+    with pytest.raises(ValueError):
+        f["9"]
+    with pytest.raises(OSError):
+        H.H5File(os.path.join(GOLD, "g9_loop.json"))                     # not an HDF5 file
+    with pytest.raises(OSError):
+        H.H5File(os.path.join(GOLD, "does_not_exist.h5"))
+
+
+def test_feature_source_on_the_real_file_equals_the_reference_item_read():
+    """H5FeatureSource(path) (h5py absent -> the ctypes binding) against the tensors the reference's statements produced."""
+    from vqacl_amd.feed import H5FeatureSource
+    images, items = seeded()
+    gold = np.load(os.path.join(GOLD, "g10_feature_items.npz"))
+    src = H5FeatureSource(PATH)
+    for img_id, w, h in images:
+        feats, boxes = src.read(img_id)
+        assert feats.dtype == torch.float32 and tuple(feats.shape) == (36, 2048) and tuple(boxes.shape) == (36, 4)
+        assert torch.equal(feats, torch.from_numpy(items[img_id]["features"]))
+        assert float(feats.double().sum()) == float(gold[f"{img_id}/vis_feats_sum"])
+        assert np.array_equal(feats[:2, :8].numpy(), gold[f"{img_id}/vis_feats_head"])
+        assert np.array_equal(boxes.numpy(), gold[f"{img_id}/boxes"])        # bit-exact: same divisions, same clamp
+        assert float(boxes.max()) <= 1.0 and float(boxes.min()) >= 0.0 and boxes[0].tolist() == [0.0, 0.0, 1.0, 1.0]
+    with pytest.raises(KeyError):
+        src.read("777")
+
+
+def test_written_files_round_trip_and_agree_with_h5dump(tmp_path):
+    rng = np.random.default_rng(3)
+    items = {"a": dict(f32=rng.standard_normal((5, 7)).astype(np.float32), f64=rng.standard_normal(4), i32=rng.integers(-9, 9, (2, 3)).astype(np.int32),
+                       u8=rng.integers(0, 255, 6).astype(np.uint8), s=7, t=np.float32(0.25)),
+             12: dict(i64=np.arange(5), i16=np.arange(-3, 3, dtype=np.int16))}
+    p = str(tmp_path / "rt.h5")
+    H.write_feature_file(p, items)
+    with H.H5File(p) as f:
+        assert sorted(f.keys()) == ["12", "a"]
+        for g, entry in items.items():
+            for k, v in entry.items():
+                got = f[f"{g}/{k}"][()]
+                assert np.array_equal(got, np.asarray(v)) and got.dtype == np.asarray(v).dtype, (g, k)
+        assert f["a/s"][()] == 7 and f["a/s"].shape == () and f["a/t"][()] == np.float32(0.25)
+    with pytest.raises(TypeError):
+        H.write_feature_file(str(tmp_path / "bad.h5"), {"a": dict(x=np.array(["no strings"]))})
+    with pytest.raises(ValueError):
+        H.H5File(p, "w")
+    # the HDF Group's own reader on the same file
+    h5dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if os.path.exists("/opt/conda/bin/h5dump") else None)
+    if h5dump is None:
+        pytest.skip("h5dump not installed: round trip checked, independent reader not")
+    out = subprocess.run([h5dump, "-d", "/a/i32", p], capture_output=True, text=True, check=True).stdout
+    assert "H5T_STD_I32LE" in out and "SIMPLE { ( 2, 3 ) / ( 2, 3 ) }" in out
+    body = out[out.index("DATA {"):]
+    nums = [int(t) for t in body.replace("(0,0):", " ").replace("(1,0):", " ").replace(",", " ").split() if t.lstrip("-").isdigit()]
+    assert nums == items["a"]["i32"].reshape(-1).tolist()
+    hdr = subprocess.run([h5dump, "-H", PATH], capture_output=True, text=True, check=True).stdout
+    assert hdr.count('DATASET "features"') == 3 and "( 36, 2048 ) / ( 36, 2048 )" in hdr and "H5T_STD_I64LE" in hdr

@@ -151,15 +151,20 @@ class FeatureStore:
 
 class H5FeatureSource:
     """The reference's on-disk format (vqa_data_memory.py:124-134,166-187): `{img_id}/features [n_boxes,2048] f32`,
-    `{img_id}/boxes [n_boxes,4]` in pixels, `{img_id}/img_w`, `{img_id}/img_h`.  Needs h5py (not in this image: the class raises
-    ImportError when constructed without it; everything else in this module works without)."""
+    `{img_id}/boxes [n_boxes,4]` in pixels, `{img_id}/img_w`, `{img_id}/img_h`.  A path is opened with h5py when that is installed,
+    otherwise through `vqacl_amd.hdf5_io` (ctypes over the same HDF5 C library h5py wraps; this image has the library but not h5py);
+    an already opened file -- or any mapping with h5py's dataset interface -- is used as it is."""
 
     def __init__(self, path, n_boxes=36, feat_dim=2048):
         if isinstance(path, (str, bytes)) or hasattr(path, "__fspath__"):
-            import h5py
-            self.f = h5py.File(path, "r")
+            try:
+                import h5py
+                self.f = h5py.File(path, "r")
+            except ImportError:
+                from .hdf5_io import H5File
+                self.f = H5File(path)
         else:
-            self.f = path               # an already opened file (or any mapping with h5py's dataset interface)
+            self.f = path
         self.n_boxes, self.feat_dim = n_boxes, feat_dim
 
     def read(self, img_id):
