@@ -10,6 +10,39 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def run_bounded(cmd, env, timeout, attempts=2):
+    """subprocess.run with a bound per attempt and ONE retry on a timeout.  One full-suite run of round 5 (of about ten) stalled for more
+    than 17 minutes somewhere in the multi-process tests and could not be reproduced (the same tree passed in 7:53 on the next box); a
+    launch that stalls is cut after `timeout` seconds (the launcher itself gives up first: --launch-timeout) and started again, and the
+    retry is reported -- a second stall fails the test."""
+    import signal
+    for k in range(attempts):
+        # own session: on a stall the launcher AND the rank processes it started are ended (exactly that process group)
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+        try:
+            out, err = proc.communicate(timeout=timeout)
+            return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGTERM)
+                out, err = proc.communicate(timeout=30)
+            except Exception:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                out, err = proc.communicate()
+            msg = f"bench launch stalled for {timeout} s (attempt {k + 1} of {attempts}): {' '.join(cmd[1:8])} ...; stderr tail: {(err or '')[-600:]!r}"
+            print(msg, file=sys.stderr, flush=True)
+            try:
+                from test_gpu_model import parity_log
+                parity_log("WARNING " + msg)
+            except Exception:
+                pass
+            if k + 1 == attempts:
+                raise
+
+
 def test_bench_line_contract_short_run():
     import torch
     if not torch.cuda.is_available():
@@ -17,8 +50,7 @@ def test_bench_line_contract_short_run():
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-parity"],
-                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    p = run_bounded([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-parity"], env, timeout=500)
     assert p.returncode == 0, p.stderr[-2000:]
     line = p.stdout.strip().splitlines()[-1]
     d = json.loads(line)                                          # the LAST stdout line is the JSON line
@@ -63,8 +95,8 @@ def test_bench_rehearsal_n_ranks_on_one_gpu(n, algo):
     # (gloo moves ~2 GB per rank and step through the host: a step of 8 ranks takes about a minute -- the wide runs are kept short)
     steps = 2 if n <= 2 else 1
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--rehearsal", "--steps", str(steps), "--warmup", "1", "--batch", "16",
-           "--store-images", "256", "--dp-algo", algo, "--no-cpu-baseline", "--no-parity", "--launch-timeout", "1200"] + (["--no-roofline"] if n > 4 else [])
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1400, env=env, cwd=ROOT)
+           "--store-images", "256", "--dp-algo", algo, "--no-cpu-baseline", "--no-parity", "--launch-timeout", "540"] + (["--no-roofline"] if n > 4 else [])
+    p = run_bounded(cmd, env, timeout=600)                     # (N = 8 takes about 150 s)
     assert p.returncode == 0, (p.stderr[-3000:], p.stdout[-500:])
     d = json.loads(p.stdout.strip().splitlines()[-1])
     assert d["rehearsal"] is True and d["value"] is None and d["ms_per_step"] is None and d["backend"] == "gloo"
@@ -96,7 +128,7 @@ def test_bench_rehearsal_under_torch_distributed_run():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearsal", "--steps", "2", "--warmup", "1", "--batch", "16", "--store-images", "256",
            "--no-cpu-baseline", "--no-parity", "--no-roofline"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    p = run_bounded(cmd, env, timeout=400)
     assert p.returncode == 0, (p.stderr[-3000:], p.stdout[-500:])
     lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{") and '"metric"' in ln]
     assert len(lines) == 1, p.stdout[-2000:]                       # rank 0 only
