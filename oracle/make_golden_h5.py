@@ -9,6 +9,8 @@ from `feats = np.zeros(...)` to `boxes.clamp_(...)` are taken out of the referen
 interface that class restates.  Nothing of the reference's text is written out: the fixture holds the file and the tensors those
 statements produced; the test regenerates the seeded arrays itself, so the file's content is pinned twice.
 
+The file carries no object timestamps (`write_feature_file(track_times=False)`): running this script again reproduces it byte for byte.
+
 Usage:  python oracle/make_golden_h5.py
 """
 import ast

@@ -68,6 +68,7 @@ def lib():
         "H5Dread": (herr_t, [hid_t, hid_t, hid_t, hid_t, hid_t, C.c_void_p]), "H5Dwrite": (herr_t, [hid_t, hid_t, hid_t, hid_t, hid_t, C.c_void_p]),
         "H5Screate": (hid_t, [C.c_int]), "H5Screate_simple": (hid_t, [C.c_int, C.POINTER(hsize_t), C.POINTER(hsize_t)]), "H5Sclose": (herr_t, [hid_t]),
         "H5Sget_simple_extent_ndims": (C.c_int, [hid_t]), "H5Sget_simple_extent_dims": (C.c_int, [hid_t, C.POINTER(hsize_t), C.POINTER(hsize_t)]),
+        "H5Pcreate": (hid_t, [hid_t]), "H5Pclose": (herr_t, [hid_t]), "H5Pset_obj_track_times": (herr_t, [hid_t, C.c_int]),
         "H5Tget_class": (C.c_int, [hid_t]), "H5Tget_size": (C.c_size_t, [hid_t]), "H5Tget_sign": (C.c_int, [hid_t]), "H5Tclose": (herr_t, [hid_t]),
     }
     for name, (res, args) in sig.items():
@@ -269,18 +270,30 @@ class H5File(Group):
             pass
 
 
-def write_feature_file(path, items):
+def write_feature_file(path, items, track_times=False):
     """Create `path` in the reference's layout: for every (img_id, dict) of `items` a group `{img_id}` holding one dataset per dict
     entry -- arrays as simple dataspaces of their dtype, Python / numpy scalars as scalar datasets (how h5py stores `grp['img_w'] = w`).
     The reference's files carry `features [n,2048] f32`, `boxes [n,4] f32`, `img_w`, `img_h` (+ `obj_id`, `obj_conf`, `attr_id`,
-    `attr_conf` that its dataset class never reads)."""
+    `attr_conf` that its dataset class never reads).  track_times=False (h5py's default for datasets too): no modification times in
+    the object headers, so the same items give the same bytes."""
     L = lib()
-    fid = L.H5Fcreate(os.fspath(path).encode(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT)
+    plists = []
+
+    def plist(cls_symbol):
+        if track_times:
+            return H5P_DEFAULT
+        pid = L.H5Pcreate(hid_t.in_dll(L, cls_symbol).value)
+        if pid < 0 or L.H5Pset_obj_track_times(pid, 0) < 0:
+            raise Hdf5Error("could not build the creation property list")
+        plists.append(pid)
+        return pid
+    fcpl, gcpl, dcpl = plist("H5P_CLS_FILE_CREATE_ID_g"), plist("H5P_CLS_GROUP_CREATE_ID_g"), plist("H5P_CLS_DATASET_CREATE_ID_g")
+    fid = L.H5Fcreate(os.fspath(path).encode(), H5F_ACC_TRUNC, fcpl, H5P_DEFAULT)
     if fid < 0:
         raise Hdf5Error(f"unable to create {path!r}")
     try:
         for img_id, entry in (items.items() if hasattr(items, "items") else items):
-            gid = L.H5Gcreate2(fid, str(img_id).encode(), H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT)
+            gid = L.H5Gcreate2(fid, str(img_id).encode(), H5P_DEFAULT, gcpl, H5P_DEFAULT)
             if gid < 0:
                 raise Hdf5Error(f"H5Gcreate2 failed for {img_id!r}")
             try:
@@ -295,7 +308,7 @@ def write_feature_file(path, items):
                     else:
                         sp = L.H5Screate_simple(a.ndim, (hsize_t * a.ndim)(*a.shape), None)
                     tp = _native(a.dtype)
-                    did = L.H5Dcreate2(gid, key.encode(), tp, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT)
+                    did = L.H5Dcreate2(gid, key.encode(), tp, sp, H5P_DEFAULT, dcpl, H5P_DEFAULT)
                     ok = did >= 0 and L.H5Dwrite(did, tp, H5S_ALL, H5S_ALL, H5P_DEFAULT, a.ctypes.data_as(C.c_void_p)) >= 0
                     if did >= 0:
                         L.H5Dclose(did)
@@ -306,3 +319,5 @@ def write_feature_file(path, items):
                 L.H5Gclose(gid)
     finally:
         L.H5Fclose(fid)
+        for pid in plists:
+            L.H5Pclose(pid)
