@@ -4,7 +4,6 @@ Checker: the CPU oracle (oracle/ref_cpu.py) and plain fp32 torch math on the sam
 rounded BEFORE the reference computation, so the only differences left are accumulation order and the bf16 rounding
 of outputs; tolerances are written next to each check.
 """
-import math
 
 import pytest
 import torch

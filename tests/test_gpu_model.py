@@ -12,7 +12,6 @@ On top of the fixed tolerances every headline figure is PINNED: profiles/r04_par
 round's kernels were committed, and a run whose figure exceeds twice its pin (or the noise floor below, whichever is larger) fails --
 a regression that triples an error no longer hides under a loose bound.  Measured worst cases of a run: profiles/rNN_parity.txt.
 """
-import copy
 
 import pytest
 import torch

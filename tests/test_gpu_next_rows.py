@@ -1,7 +1,6 @@
 """GPU tests of the "next" rows through the C ABI: the HBM-resident feature store (bit-exact against the
 engine's own rounding of the f32 batch), train/test steps fed from the store, and the dual-level loop driver over the engine
 with checkpoint / prototype files round-tripped."""
-import copy
 import os
 import random
 

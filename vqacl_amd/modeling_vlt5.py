@@ -14,7 +14,6 @@ Memory layout (sized for 288 GB HBM, one process per GPU):
 """
 import ctypes as C
 import os
-import math
 from collections import OrderedDict
 
 import numpy as np
