@@ -27,6 +27,24 @@ import time
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # this pool's driver only supports dmabuf IPC (RCCL across processes)
 
 
+def arm_stall_dump(role):
+    """SIGUSR1 -> the Python stacks of every thread of THIS process, written to $VQACL_STALL_DUMP_DIR/<role>_pid<pid>.txt (stderr when the
+    variable is unset).  The launcher sends it to its ranks before it gives up on them, tests/test_gpu_bench_line.py sends it to a launch
+    that ran into its bound: a stalled multi-rank launch leaves the call every rank sits in instead of a bare timeout."""
+    import faulthandler
+    import signal
+    target = sys.stderr
+    d = os.environ.get("VQACL_STALL_DUMP_DIR")
+    if d:
+        try:
+            os.makedirs(d, exist_ok=True)
+            target = open(os.path.join(d, f"{role}_pid{os.getpid()}.txt"), "w")
+        except OSError:
+            target = sys.stderr
+    faulthandler.register(signal.SIGUSR1, file=target, all_threads=True, chain=False)
+    return target
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +142,7 @@ def run_launcher(args, argv):
               "`python3 bench.py ...` after `--`", file=sys.stderr, flush=True)
         return 2
     procs, lines = [], []
+    arm_stall_dump("launcher")
 
     def pump(rank, stream):            # every rank's stdout: rank 0's last JSON object is the bench line, the rest goes to stderr
         for raw in stream:
@@ -152,7 +171,11 @@ def run_launcher(args, argv):
         if (rc != 0 or time.time() > deadline) and alive:
             if rc == 0:
                 rc = 124
-                print("bench.py launcher: timed out waiting for the ranks", file=sys.stderr, flush=True)
+                print("bench.py launcher: timed out waiting for the ranks; asking them for their stacks (SIGUSR1)", file=sys.stderr, flush=True)
+                import signal
+                for r in alive:                            # (every rank armed arm_stall_dump() before it imported torch)
+                    procs[r].send_signal(signal.SIGUSR1)
+                time.sleep(3.0)
             for r in alive:                                # exactly the processes started above
                 procs[r].terminate()
             for r in alive:
@@ -177,6 +200,9 @@ if __name__ == "__main__":
     _rc = run_launcher(parse_args(), sys.argv[1:])
     if _rc is not None:
         sys.exit(_rc)
+
+if __name__ == "__main__":
+    arm_stall_dump("rank%s" % os.environ.get("RANK", "0"))
 
 import torch  # noqa: E402
 

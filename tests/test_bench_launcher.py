@@ -121,3 +121,38 @@ def test_launcher_needs_a_json_line(monkeypatch, capfd):
     sys.path.insert(0, ROOT)
     bench = _stub_plan(monkeypatch, ["print('no line here')"])
     assert bench.run_launcher(bench.parse_args(["--gpus", "1", "--force-dist"]), ["--gpus", "1", "--force-dist"]) == 1
+
+
+STALLED_RANK = ("import sys, time; sys.path.insert(0, %r); import bench; bench.arm_stall_dump('rank' + __import__('os').environ.get('RANK', '0'));\n"
+                "def stuck_in_a_collective():\n    time.sleep(120)\nstuck_in_a_collective()   # stands in for bench.py") % ROOT
+
+
+def test_launcher_asks_stalled_ranks_for_their_stacks_before_it_gives_up(monkeypatch, capfd, tmp_path):
+    """A launch that runs into --launch-timeout leaves, per rank, the Python stack the rank sits in (SIGUSR1 -> faulthandler), then ends
+    the ranks and returns 124 -- a stall is a failure with an artifact, never a silent retry."""
+    sys.path.insert(0, ROOT)
+    monkeypatch.setenv("VQACL_STALL_DUMP_DIR", str(tmp_path))
+    bench = _stub_plan(monkeypatch, [STALLED_RANK, STALLED_RANK])
+    t0 = time.time()
+    rc = bench.run_launcher(bench.parse_args(["--gpus", "2", "--launch-timeout", "4"]), ["--gpus", "2"])
+    assert rc == 124 and time.time() - t0 < 60
+    dumps = sorted(f for f in os.listdir(tmp_path) if f.startswith("rank"))
+    assert len(dumps) == 2 and dumps[0].startswith("rank0_pid") and dumps[1].startswith("rank1_pid"), dumps
+    for f in dumps:
+        assert "stuck_in_a_collective" in open(tmp_path / f).read()
+    assert "asking them for their stacks" in capfd.readouterr().err
+
+
+def test_bounded_launch_of_the_gpu_tests_fails_with_the_stacks_attached(monkeypatch, tmp_path):
+    """tests/test_gpu_bench_line.py::run_bounded: no retry; a launch over its bound fails the test and the failure carries the stacks."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_bench_line as T
+    monkeypatch.setattr(T, "STALL_DIR", str(tmp_path))
+    with pytest.raises(pytest.fail.Exception) as ei:
+        T.run_bounded([sys.executable, "-c", STALLED_RANK], _clean_env(), timeout=4)
+    assert "still running after 4 s" in str(ei.value) and "stuck_in_a_collective" in str(ei.value)
+    sub = [d for d in os.listdir(tmp_path)]
+    assert len(sub) == 1 and "launch.txt" in os.listdir(tmp_path / sub[0])
+    # a launch inside its bound is returned as subprocess.run would return it
+    res = T.run_bounded([sys.executable, "-c", "print('fine')"], _clean_env(), timeout=30)
+    assert res.returncode == 0 and res.stdout.strip() == "fine"
