@@ -706,6 +706,8 @@ def test_data_parallel_overlap_path_on_one_gpu_and_rank_equivalence(dev):
         model = make_model(ocfg, params, dev)
         model.train()
         dp = DataParallelVLT5(model, bucket_mb=0.05, grad_dtype=torch.float32)   # tiny buckets: several collectives interleaved with backward
+        # f32 buckets: the 1/world scaling runs on the communication stream -> HIGH priority (round 6: chosen per configuration)
+        assert dp.comm_carries_kernels() and dp.comm_priority() == -1 and dp.comm_stream.priority == -1
         dp.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
         torch.cuda.synchronize()
         # equal up to the summation order of the embedding scatter-add (float atomics)
@@ -716,6 +718,8 @@ def test_data_parallel_overlap_path_on_one_gpu_and_rank_equivalence(dev):
         model2.train()
         dp2 = DataParallelVLT5(model2, bucket_mb=0.05)
         assert dp2.grad_dtype is torch.bfloat16
+        # bf16 buckets mirrored by the engine, but no FusedAdamW reads the staging buffer: the cast back is a kernel on the stream
+        assert dp2.mirror_enabled() and dp2.comm_carries_kernels() and dp2.comm_stream.priority == -1
         dp2.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
         torch.cuda.synchronize()
         g2 = model2.flat_grads()
@@ -741,7 +745,10 @@ def test_data_parallel_overlap_path_on_one_gpu_and_rank_equivalence(dev):
             dp3 = DataParallelVLT5(m3, bucket_mb=0.05)
             opt3 = FusedAdamW(reference_param_groups(m3, 0.01), m3, lr=1e-3, eps=1e-6, max_grad_norm=0.05)   # the clip is active
             assert dp3.defer_cast_back
+            # the default configuration: event waits and collectives only -> NORMAL priority (profiles/r05_w_comm_stream_priority.txt)
+            assert not dp3.comm_carries_kernels() and dp3.comm_stream.priority == 0
             dp3.defer_cast_back = defer
+            assert dp3.comm_stream.priority == (0 if defer else -1)      # re-created behind the old one when the configuration changes
             for it in range(2):
                 dp3.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
                 assert dp3.g16_valid == defer

@@ -637,7 +637,7 @@ class VLT5(nn.Module):
             cs.events, cs.n_events = arr, len(events)
             keep = keep + (arr,)
         mirrored = False
-        if events is not None and self.dp.grad_dtype is torch.bfloat16 and os.environ.get("VQACL_DP_MIRROR", "1") != "0":
+        if events is not None and self.dp.mirror_enabled():
             # bf16 buckets: the weight-gradient GEMMs write the staging copy of every layer bucket themselves (no cast pass)
             cs.grads_bf16 = ptr(self.dp.staging(target))
             mirrored = True

@@ -112,16 +112,10 @@ class DataParallelVLT5:
                 ends[bucket] = max(ends.get(bucket, 0), (off + n + 63) // 64 * 64)
         self.bucket_end = [ends[b] for b in sorted(ends)]
         self.bucket_start = [0] + self.bucket_end[:-1]
-        # The stream the waits for bucket events and the collectives are issued on.  NORMAL priority since round 5: with bf16 buckets
-        # mirrored by the GEMM epilogues it carries no kernels of its own (event waits only; the collectives themselves run on the
-        # process group's internal stream, which bench.py / the launcher create at high priority), and a HIGH-priority stream that sits
-        # on a pending event wait costs the compute queue dearly on this runtime: +0.23 ms per step at world size 1 in same-box A/B runs
-        # (9.20 -> 8.97 ms), and a persistent 3x slowdown of the whole step (26 ms) when the GPU was touched before
-        # init_process_group() -- profiles/r05_w_comm_stream_priority.txt.  VQACL_COMM_PRIORITY=-1 restores the round-1 choice (made when
-        # every bucket was cast on this stream: at normal priority those casts only ran once backward had finished).
-        import os
-        prio = int(os.environ.get("VQACL_COMM_PRIORITY", "0"))
-        self.comm_stream = torch.cuda.Stream(priority=prio) if model._flat.is_cuda else None
+        # The stream the waits for bucket events and the collectives are issued on: created on first use, its priority chosen per
+        # configuration (the `comm_stream` property below)
+        self._comm = None
+        self._comm_prio = None
         self._events = None
         self.defer_cast_back = False        # set by FusedAdamW: the optimizer reads the reduced bf16 buckets itself
         self.g16_valid = False              # the staging buffer holds this backward's reduced gradients, not yet cast back
@@ -136,6 +130,44 @@ class DataParallelVLT5:
 
     def __getattr__(self, name):            # .train_step, .train(), .eval(), .state_dict() ... go to the model
         return getattr(self.__dict__["module"], name)
+
+    # ---- the communication stream ----------------------------------------------------------------------
+    def mirror_enabled(self):
+        """bf16 buckets written by the engine itself (weight-gradient GEMM epilogues + vlt5_mirror_rows_bf16: vlt5_step.grads_bf16), so
+        that no cast pass runs on the communication stream.  VQACL_DP_MIRROR=0 turns it off (the cast-per-slice path of round 1)."""
+        import os
+        return self.grad_dtype is torch.bfloat16 and self.module._flat.is_cuda and os.environ.get("VQACL_DP_MIRROR", "1") != "0"
+
+    def comm_carries_kernels(self):
+        """Does this configuration enqueue KERNELS on the communication stream (besides event waits and collectives)?  f32 buckets:
+        the 1/world scaling (`div_`); bf16 buckets without the engine's mirror: `vlt5_cast_bf16` per slice; bf16 buckets without
+        FusedAdamW reading the staging buffer (`defer_cast_back`): `vlt5_cast_f32` behind every all-reduce / all-gather."""
+        return not (self.mirror_enabled() and self.defer_cast_back)
+
+    def comm_priority(self):
+        """0 (normal) when the stream carries event waits only: a HIGH-priority stream sitting on a pending event wait costs the compute
+        queue +0.23 ms per step at world size 1 on this runtime, and a persistent 3x slowdown when the GPU was touched before
+        init_process_group() (profiles/r05_w_comm_stream_priority.txt).  -1 (high) when it carries kernels: at normal priority the casts
+        of a bucket released mid-backward only ran once backward had finished (round 1, tools/dp_overlap_probe.py) -- the overlap the
+        buckets exist for.  VQACL_COMM_PRIORITY overrides.  (The collectives themselves run on the process group's internal stream:
+        create the group with `ProcessGroupNCCL.Options(is_high_priority_stream=True)`, as bench.py does -- INTEGRATION.md.)"""
+        import os
+        forced = os.environ.get("VQACL_COMM_PRIORITY")
+        if forced is not None:
+            return int(forced)
+        return -1 if self.comm_carries_kernels() else 0
+
+    @property
+    def comm_stream(self):
+        if not self.module._flat.is_cuda:
+            return None
+        want = self.comm_priority()
+        if self._comm is None or self._comm_prio != want:
+            new = torch.cuda.Stream(priority=want)
+            if self._comm is not None:      # the configuration changed (an optimizer was attached, a switch flipped): keep the order
+                new.wait_stream(self._comm)
+            self._comm, self._comm_prio = new, want
+        return self._comm
 
     def describe(self):
         return {"algo": self.algo, "grad_dtype": str(self.grad_dtype).replace("torch.", ""), "world": self.world,
