@@ -27,9 +27,17 @@ extern "C" {
 #define VLT5_OK 0
 #define VLT5_ERR_ARG 1001
 #define VLT5_ERR_ALIGN 1002
-#define VLT5_ABI_VERSION 7
+#define VLT5_ERR_PLAN 1003   /* vlt5_step.release_plan_id does not name the order THIS call completes gradient buckets in */
+#define VLT5_ABI_VERSION 8
 
 int vlt5_abi_version(void);
+/* 0 for the product build.  Non-zero: the library was compiled with experiment switches whose RESULTS ARE WRONG on purpose (upper-bound
+ * measurements: tools/r05_attn_bwd_fusion_bound.sh) or that stamp timelines into user buffers -- a loader must refuse such a build
+ * unless it was asked for one (vqacl_amd/_lib.py: VLT5_ALLOW_EXPERIMENT=1). */
+#define VLT5_BUILD_ENC_DGRAD_HOT_A   1
+#define VLT5_BUILD_ATTN_BWD_NO_STORE 2
+#define VLT5_BUILD_TIMELINE          4
+int vlt5_build_flags(void);
 
 /* ---- experiment switches (A/B runs, tests of the alternative paths) -------------------------------------------------------
  * Every field: 0 = the library's default; the product path passes NULL or an all-zero record.  Read by the call that receives it,
@@ -536,6 +544,11 @@ typedef struct {
      * are then complete only after vlt5_encoder_bwd; ignored with a side stream / gradient-bucket events (data parallelism). */
     int defer_decoder_wgrads;
     const vlt5_tuning* tuning;     /* optional experiment switches (NULL = defaults) */
+    /* optional, with `events`: the id vlt5_grad_release_plan() returned when the caller cut its event waits / collectives.  The backward
+     * phases recompute it from what THEY are about to do (configuration, tuning, side stream, defer_decoder_wgrads) and return
+     * VLT5_ERR_PLAN before launching anything when it differs -- a caller that waits for a bucket's event after the wrong call would
+     * otherwise read the PREVIOUS backward's record without an error.  0: not checked. */
+    int release_plan_id;
 } vlt5_step;
 /* number of slots of vlt5_step.gnorm_partials for this configuration, or 0 when it is not supported (a matrix dimension that is
  * no multiple of 64: the slot ranges of neighbouring tensors would overlap) */
@@ -561,6 +574,11 @@ int vlt5_encoder_late_layers_tuned(int num_layers, const vlt5_tuning* tuning);  
  * (their weight gradients ride in that phase's launches); the caller enqueues its waits for them after that call.  0: signalled at the
  * end of vlt5_decoder_bwd.  The stacked cross-K/V bucket (index num_decoder_layers) is always signalled by vlt5_decoder_bwd. */
 int vlt5_decoder_buckets_late(const vlt5_config* c, const vlt5_tuning* tuning, int side_stream);
+/* The order a backward WITH gradient-bucket events and defer_decoder_wgrads = 1 completes the buckets in, as the engine itself decides
+ * it: up to `cap` triples (phase, lo, hi) into `triples` -- phase 0: buckets [lo, hi) are signalled by vlt5_decoder_bwd, phase 1: by
+ * vlt5_encoder_bwd, in this order (a wait for a bucket's event must be enqueued AFTER the call that records it).  Returns the plan's id
+ * (> 0, for vlt5_step.release_plan_id; a function of the triples), or a negative value for bad arguments / cap < 5.  *n = triples written. */
+int vlt5_grad_release_plan(const vlt5_config* c, const vlt5_tuning* tuning, int side_stream, int* triples, int cap, int* n);
 /* a lowest-priority stream for vlt5_step.side_stream (hipStreamCreateWithPriority); the caller destroys it */
 int vlt5_side_stream_create(void** stream);
 int vlt5_side_stream_destroy(void* stream);

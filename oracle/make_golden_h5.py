@@ -73,6 +73,23 @@ def main():
         out[f"{img_id}/boxes"] = env["boxes"].numpy()
     f.close()
     np.savez(os.path.join(OUT, "g10_feature_items.npz"), **out)
+    # round 6: the same first image re-packed the way `create_dataset(..., compression="gzip", shuffle=True, chunks=(9, 512))` stores it
+    # (chunked + shuffle + deflate), with an IEEE-half and a float64 copy of a feature slice beside it -- storage forms the reference's own
+    # extraction scripts do not produce (they write `grp[name] = array`: contiguous, uncompressed) but re-packed feature files do; the
+    # read path must return the same item for them.  (No h5py in this image: written through libhdf5's own filter pipeline; h5dump is
+    # the independent reader in tests/test_hdf5_cpu.py.)
+    first = IMAGES[0][0]
+    packed = dict(items[first])
+    packed["features_f16"] = items[first]["features"][:, :64].astype(np.float16)
+    packed["features_f64"] = items[first]["features"][:4, :16].astype(np.float64)
+    gz = os.path.join(OUT, "g11_feature_file_gzip.h5")
+    H.write_feature_file(gz, {first: packed}, compression="gzip", compression_opts=4, shuffle=True, chunks=(9, 512))
+    with H.H5File(gz) as g:
+        env = {"f": g, "img_id": first, "np": np, "torch": torch, "self": types.SimpleNamespace(n_boxes=36), "datum": None, "out_dict": {}}
+        exec(code, env)
+        assert torch.equal(env["out_dict"]["vis_feats"], torch.from_numpy(items[first]["features"]))
+        assert np.array_equal(env["boxes"].numpy(), out[f"{first}/boxes"]), "the reference's item read returns the same item from the re-packed file"
+    print("g11_feature_file_gzip.h5:", os.path.getsize(gz), "bytes")
     print("g10_feature_file.h5:", os.path.getsize(path), "bytes;", len(IMAGES), "images; HDF5", ".".join(map(str, H.library_version())))
 
 

@@ -66,6 +66,18 @@ def _worker(rank, world, port, q):
         assert sorted(plan) == sorted((a, b) for lo, hi in dflt.release_ranges for a, b, _, _ in dflt.slices_of(lo, hi))
         assert sum(b - a for a, b in plan) == dflt.bucket_end[-1] and len(set(plan)) == len(plan)
         assert all((dflt.chunk(a, b)[1] - dflt.chunk(a, b)[0]) % 8 == 0 for a, b in plan), "chunks stay 16-byte aligned in bf16"
+        # the release plan is FROZEN at construction (round 6): a later edit of the tuning record moves what the engine reports, not the
+        # wrapper's slice plan / chunk ownership -- and the next backward's check refuses to run with the moved plan
+        from vqacl_amd import _lib as LL
+        frozen, ranges = dflt.slice_plan(), dflt.release_ranges
+        old_tuning = model.tuning
+        model.tuning = LL.make_tuning(wgrad_shadow=1)
+        assert tuple(model.grad_release_plan()) != dflt._frozen_plan, "the engine's plan follows the tuning record"
+        assert dflt.slice_plan() == frozen and dflt.release_ranges == ranges
+        with pytest.raises(LL.Vlt5Error, match="release plan changed"):
+            dflt.check_release_plan(model.grad_release_plan())
+        model.tuning = old_tuning
+        dflt.check_release_plan(model.grad_release_plan())
         # reading parameters is local in the default mode and refuses (instead of starting a collective) with a sharded master
         dflt.params_sharded = True
         from vqacl_amd._lib import Vlt5Error

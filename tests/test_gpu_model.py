@@ -678,6 +678,43 @@ def test_incremental_decoder_step_matches_full_decoder_logits(dev, fast, variant
     assert lib().vlt5_decoder_step(C.byref(c), C.byref(cs), ptr(tok), T, ptr(cache), ptr(logits), ptr(nxt), stream_ptr()) == 1001
 
 
+def test_backward_phases_refuse_a_release_plan_that_is_not_theirs(dev):
+    """vlt5_step.release_plan_id (round 6): with gradient-bucket events the backward phases recompute the order they are about to complete the
+    buckets in and return VLT5_ERR_PLAN -- before launching anything -- when the caller cut its waits by another one."""
+    import ctypes as C
+    from vqacl_amd import _lib as L
+    from vqacl_amd._lib import check, lib, stream_ptr
+    from oracle import ref_cpu as R
+    ocfg = R.tiny_cfg()
+    model = make_model(ocfg, R.init_params(ocfg, seed=3), dev)
+    dims = (4, 12, 36, 4)
+    model._workspace(*dims)
+    B, Lt, V, T = dims
+    st = dict(dims=dims, training=True, seed=1, feats=torch.zeros(B, V, ocfg.feat_dim, device=dev), boxes=torch.zeros(B, V, 4, device=dev),
+              input_ids=torch.zeros(B, Lt, dtype=torch.long, device=dev), labels=torch.zeros(B, T, dtype=torch.long, device=dev),
+              enc_lut=model._lut(Lt, Lt, True), dec_lut=model._lut(T, T, False))
+    c = model.cfg.c_struct()
+    events = [torch.cuda.Event() for _ in range(model._nbuckets)]
+    for e in events:
+        e.record()
+    arr = (L.vp * len(events))(*[L.vp(e.cuda_event) for e in events])
+    plan, pid = model._release_plan()
+    model.tuning = L.make_tuning(wgrad_shadow=1)
+    other = model._release_plan()[1]
+    model.tuning = L.make_tuning()
+    assert other != pid
+    for fn in (lib().vlt5_decoder_bwd, lib().vlt5_encoder_bwd):
+        cs = model._make_step(st, model._flat_grad)
+        cs.events, cs.n_events, cs.defer_decoder_wgrads = arr, len(events), 1
+        cs.release_plan_id = other
+        assert fn(C.byref(c), C.byref(cs), stream_ptr()) == 1003
+        cs.release_plan_id, cs.defer_decoder_wgrads = pid, 0          # the plan describes the deferred order
+        assert fn(C.byref(c), C.byref(cs), stream_ptr()) == 1003
+    with pytest.raises(L.Vlt5Error, match="release plan"):
+        check(1003, "vlt5_encoder_bwd")
+    torch.cuda.synchronize()
+
+
 def test_data_parallel_overlap_path_on_one_gpu_and_rank_equivalence(dev):
     """(1) The RCCL path (events recorded by the engine, comm stream, bucketed all-reduce over flat-gradient slices) with a
     single-rank NCCL group on the real GPU: gradients must equal the non-DP run.
@@ -686,6 +723,7 @@ def test_data_parallel_overlap_path_on_one_gpu_and_rank_equivalence(dev):
     import socket
     import torch.distributed as dist
     from oracle import ref_cpu as R
+    from vqacl_amd import _lib as L
     from vqacl_amd.parallel import DataParallelVLT5
     ocfg = R.tiny_cfg()
     params = R.init_params(ocfg, seed=77)
@@ -782,6 +820,16 @@ def test_data_parallel_overlap_path_on_one_gpu_and_rank_equivalence(dev):
         # (the squared norm is summed chunk by chunk instead of over the whole buffer: the clip factor may differ in its last bit)
         assert torch.allclose(m4.flat_params(), outs[0][0], rtol=0.0, atol=2e-6), "zero1 over one RCCL rank == all-reduce + whole-buffer update"
         assert abs(float(opt4.grad_norm()) - outs[0][1]) <= 1e-5 * max(outs[0][1], 1e-6)
+        # round 6: the release plan is frozen when the wrapper is built -- a tuning record edited afterwards (it would move chunk ownership
+        # under the sharded Adam moments, and the call that records the decoder buckets' events) makes the next backward refuse
+        m4.tuning = L.make_tuning(wgrad_shadow=1)
+        res4 = dp4.train_step(batch, 0, 0.5, 0.3)
+        with pytest.raises(L.Vlt5Error, match="release plan changed"):
+            res4["loss"].backward()
+        m4.tuning = L.make_tuning()
+        dp4.train_step(batch, 0, 0.5, 0.3)["loss"].backward()
+        opt4.step()
+        torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
 

@@ -22,7 +22,57 @@ def seeded():
 
 
 def test_library_loads_and_reports_its_version():
-    assert H.library_version() >= (1, 8, 0)
+    assert H.library_version() >= (1, 10, 0)       # (lib() refuses older ones: 32-bit hid_t)
+
+
+def test_an_old_library_is_refused_with_a_clear_message(tmp_path, monkeypatch):
+    """hid_t is a 32-bit int before HDF5 1.10: the binding would pass every handle with the wrong width.  A stand-in library that reports
+    1.8.21 must be refused by lib() with the reason, before any other entry point is touched."""
+    src = tmp_path / "old.c"
+    src.write_text("int H5get_libversion(unsigned*a,unsigned*b,unsigned*c){*a=1;*b=8;*c=21;return 0;}\n")
+    so = tmp_path / "libold.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)])
+    monkeypatch.setenv("VQACL_HDF5_LIB", str(so))
+    monkeypatch.setattr(H, "_lib", None)
+    with pytest.raises(H.Hdf5Error, match="1.8.21.*needs libhdf5 >= 1.10"):
+        H.lib()
+    monkeypatch.undo()
+    assert H.lib() is not None
+
+
+def test_repacked_file_chunked_gzip_half_and_double_reads_back_the_same_item():
+    """tests/golden/g11_feature_file_gzip.h5: the first image of g10 stored chunked (9 x 512) through the shuffle + deflate filters, with an
+    IEEE-half and a float64 dataset beside it -- the storage forms a re-packed feature file can have (round-5 advisor).  Same item through
+    H5FeatureSource, half read exactly, and the HDF Group's h5dump confirms the file really is chunked / deflated / 16-bit."""
+    from vqacl_amd.feed import H5FeatureSource
+    images, items = seeded()
+    first = images[0][0]
+    gz = os.path.join(GOLD, "g11_feature_file_gzip.h5")
+    gold = np.load(os.path.join(GOLD, "g10_feature_items.npz"))
+    feats, boxes = H5FeatureSource(gz).read(first)
+    assert torch.equal(feats, torch.from_numpy(items[first]["features"])) and np.array_equal(boxes.numpy(), gold[f"{first}/boxes"])
+    with H.H5File(gz) as f:
+        assert sorted(f[first].keys()) == ["boxes", "features", "features_f16", "features_f64", "img_h", "img_w", "obj_conf", "obj_id"]
+        h = f[f"{first}/features_f16"]
+        want = items[first]["features"][:, :64].astype(np.float16)
+        assert h.dtype == np.float16 and h.shape == (36, 64)
+        assert h[()].dtype == np.float16 and np.array_equal(h[()], want)
+        wide = np.zeros((36, 64), dtype=np.float32)
+        h.read_direct(wide)                                              # the reference's read_direct into an f32 buffer: exact widening
+        assert np.array_equal(wide, want.astype(np.float32))
+        d = f[f"{first}/features_f64"]
+        assert d.dtype == np.float64 and np.array_equal(d[()], items[first]["features"][:4, :16].astype(np.float64))
+        narrow = np.zeros((4, 16), dtype=np.float32)
+        d.read_direct(narrow)
+        assert np.array_equal(narrow, items[first]["features"][:4, :16])
+        with pytest.raises(TypeError):
+            f._children(f"/{first}/features")                             # not a group
+    h5dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if os.path.exists("/opt/conda/bin/h5dump") else None)
+    if h5dump is None:
+        pytest.skip("h5dump not installed")
+    hdr = subprocess.run([h5dump, "-pH", gz], capture_output=True, text=True, check=True).stdout
+    assert "CHUNKED ( 9, 512 )" in hdr and "COMPRESSION DEFLATE { LEVEL 4 }" in hdr and "PREPROCESSING SHUFFLE" in hdr
+    assert "16-bit little-endian floating-point" in hdr and "H5T_IEEE_F64LE" in hdr
 
 
 def test_golden_file_reads_back_the_seeded_arrays_through_the_h5py_style_interface():

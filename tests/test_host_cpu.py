@@ -3,6 +3,7 @@ mirrors the reference's state_dict, the bucket tables are bit-exact, the module 
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -26,7 +27,27 @@ def test_library_exports_every_symbol_of_the_header(built):
     for name in sorted(declared):
         assert hasattr(raw, name), f"libvlt5_hip.so does not export {name}"
     assert set(built.PROTOTYPES) == declared, (set(built.PROTOTYPES) ^ declared)
-    assert built.lib().vlt5_abi_version() == 7
+    assert built.lib().vlt5_abi_version() == 8 and built.lib().vlt5_build_flags() == 0
+
+
+def test_experiment_builds_are_refused_by_the_loader(built, tmp_path, monkeypatch):
+    """Round-5 advisor: libraries compiled with -DENC_DGRAD_HOT_A / -DATTN_BWD_NO_STORE (upper-bound measurements, results wrong on purpose)
+    carried the product's ABI number and loaded through VLT5_LIB without complaint.  They now report vlt5_build_flags() != 0 and the loader
+    refuses them unless VLT5_ALLOW_EXPERIMENT=1.  (A stand-in library with the two entry points is enough to exercise the loader.)"""
+    import subprocess
+    src = tmp_path / "fake.c"
+    src.write_text("int vlt5_abi_version(void){return %d;}\nint vlt5_build_flags(void){return 3;}\n" % built.ABI_VERSION)
+    so = tmp_path / "libfake.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)])
+    code = ("import sys; sys.path.insert(0, %r)\nfrom vqacl_amd import _lib as L\nL.PROTOTYPES = {k: v for k, v in L.PROTOTYPES.items() "
+            "if k in ('vlt5_abi_version', 'vlt5_build_flags')}\n"
+            "try:\n    L.lib(); print('LOADED')\nexcept L.Vlt5Error as e:\n    print('REFUSED', e)\n" % ROOT)
+    env = dict(os.environ, VLT5_LIB=str(so))
+    env.pop("VLT5_ALLOW_EXPERIMENT", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout
+    assert "REFUSED" in out and "EXPERIMENT build" in out and "ENC_DGRAD_HOT_A" in out and "ATTN_BWD_NO_STORE" in out, out
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, VLT5_ALLOW_EXPERIMENT="1"), capture_output=True, text=True, timeout=120).stdout
+    assert "LOADED" in out, out
 
 
 def test_struct_sizes_match_the_c_side(built, tmp_path):
@@ -251,6 +272,19 @@ def test_gradient_release_plan_covers_every_bucket_once_and_follows_the_tuning(b
     m.tuning = L.make_tuning()
     m.side_stream_enabled = True                                              # a side stream for the weight gradients: no shadowing either
     assert m.grad_release_plan()[0] == (0, 0, Ld + 1)
+    # the plan's id (vlt5_step.release_plan_id: the backward phases refuse a plan that is not theirs) is a function of the triples
+    m.side_stream_enabled = False
+    ids = {}
+    for setting in (0, 1):
+        m.tuning = L.make_tuning(wgrad_shadow=setting)
+        plan_, pid = m._release_plan()
+        assert pid > 0 and plan_ == m.grad_release_plan()
+        ids[setting] = pid
+    assert ids[0] != ids[1]
+    m.tuning = L.make_tuning(enc_cut=1)
+    assert m._release_plan()[1] not in ids.values() and m._release_plan()[0] != plan
+    m.tuning = L.make_tuning()
+    assert m._release_plan() == (plan, ids[0])
     one = VLT5VQA(VLT5Config(d_model=64, d_kv=16, num_heads=4, d_ff=128, num_layers=1, num_decoder_layers=2, vocab_size=400, feat_dim=64),
                   device=torch.device("cpu"))
     assert sorted(covered(one.grad_release_plan())) == list(range(one._nbuckets)) and one.grad_release_plan()[0] == (0, 0, 3)

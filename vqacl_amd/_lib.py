@@ -133,7 +133,7 @@ class Step(C.Structure):
                 ("wait_events", C.POINTER(vp)), ("n_wait_events", c_i),
                 ("feat_store", vp), ("box_store", vp), ("feat_slots", vp), ("n_slots", c_ll),
                 ("side_stream", vp), ("side_events", C.POINTER(vp)), ("n_side_events", c_i), ("grads_bf16", vp),
-                ("gnorm_partials", vp), ("defer_decoder_wgrads", c_i), ("tuning", C.POINTER(Tuning))]
+                ("gnorm_partials", vp), ("defer_decoder_wgrads", c_i), ("tuning", C.POINTER(Tuning)), ("release_plan_id", c_i)]
 
 
 class DecAttnGrads(C.Structure):
@@ -176,6 +176,8 @@ class DecodeLinearDesc(C.Structure):
 # name -> (restype, argtypes); every symbol declared in include/vlt5_hip.h
 PROTOTYPES = {
     "vlt5_abi_version": (c_i, []),
+    "vlt5_build_flags": (c_i, []),
+    "vlt5_grad_release_plan": (c_i, [C.POINTER(Config), C.POINTER(Tuning), c_i, C.POINTER(c_i), c_i, C.POINTER(c_i)]),
     "vlt5_gemm_bf16": (c_i, [C.POINTER(GemmDesc), vp]),
     "vlt5_gemm_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
     "vlt5_gemm_auto_split": (c_i, [c_i, c_i, c_i, c_ll]),
@@ -275,6 +277,9 @@ PROTOTYPES = {
 WS_ENC_OUT, WS_ENC_EXT, WS_LOGITS, WS_LOSS_TOK, WS_LOSS, WS_ENC_MASK_EXT, WS_DEC_OUT = range(7)
 
 _lib = None
+ABI_VERSION = 8
+BUILD_FLAG_NAMES = {1: "ENC_DGRAD_HOT_A (input-gradient GEMM reads one row: wrong gradients)", 2: "ATTN_BWD_NO_STORE (attention backward "
+                    "stores nothing: wrong gradients)", 4: "TIMELINE (phase stamps written into user buffers)"}
 
 
 class Vlt5Error(RuntimeError):
@@ -293,15 +298,24 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.vlt5_abi_version() != 7:
-            raise Vlt5Error("libvlt5_hip.so ABI version mismatch")
+        if L.vlt5_abi_version() != ABI_VERSION:
+            raise Vlt5Error(f"{LIB_PATH}: ABI version {L.vlt5_abi_version()}, this package needs {ABI_VERSION} -- rebuild it "
+                            "(python -c 'import __graft_entry__ as g; g.build()')")
+        flags = L.vlt5_build_flags()
+        if flags and os.environ.get("VLT5_ALLOW_EXPERIMENT") != "1":
+            # (tools/build_variant.sh builds: upper-bound measurements whose RESULTS ARE WRONG, timeline stamps into user buffers)
+            raise Vlt5Error(f"{LIB_PATH} is an EXPERIMENT build (vlt5_build_flags() = {flags}: "
+                            + ", ".join(n for b, n in BUILD_FLAG_NAMES.items() if flags & b)
+                            + "): its results are not the product's.  Set VLT5_ALLOW_EXPERIMENT=1 to load it for a measurement.")
         _lib = L
     return _lib
 
 
 def check(rc, what=""):
     if rc != 0:
-        kind = {1001: "bad argument", 1002: "alignment (contiguous dims must be multiples of 8)"}.get(rc, f"hipError {rc}")
+        kind = {1001: "bad argument", 1002: "alignment (contiguous dims must be multiples of 8)",
+                1003: "the caller's gradient release plan (vlt5_step.release_plan_id) is not the order this call completes the buckets in "
+                      "-- tuning / side stream changed after the data-parallel wrapper was built?"}.get(rc, f"hipError {rc}")
         raise Vlt5Error(f"{what} failed: {kind}")
 
 

@@ -300,3 +300,14 @@ extern "C" int vlt5_attn_bwd(const vlt5_attn_desc* d, void* stream) {
     LAUNCH_CHECK();
     return VLT5_OK;
 }
+
+int vlt5_build_flags_attn() {
+    int f = 0;
+#ifdef ATTN_BWD_NO_STORE
+    f |= VLT5_BUILD_ATTN_BWD_NO_STORE;
+#endif
+#ifdef ATTN_TIMELINE
+    f |= VLT5_BUILD_TIMELINE;
+#endif
+    return f;
+}

@@ -1238,6 +1238,31 @@ extern "C" int vlt5_decoder_buckets_late(const vlt5_config* c, const vlt5_tuning
     return shadow_rule(*c, t, true, side_stream != 0) ? 1 : 0;
 }
 
+// The release order of the gradient buckets with events (the host cuts its waits and collectives by this) and its id.
+namespace {
+int release_plan(const vlt5_config& c, const vlt5_tuning* t, bool side, int* tri, int cap, int* n) {
+    Layout L;
+    build_layout(c, L, false);
+    const int Ld = c.num_decoder_layers, Le = c.num_layers, nb = L.nbuckets;
+    const int late_layers = Le > 1 ? enc_cut(Le, t ? t->enc_cut : 0) : Le;
+    const int cut = Le > 1 ? Ld + 1 + (Le - late_layers) : Ld + 1;
+    const bool late = shadow_rule(c, t, true, side);
+    int out[15], m = 0;
+    auto add = [&](int ph, int lo, int hi) { out[m * 3] = ph; out[m * 3 + 1] = lo; out[m * 3 + 2] = hi; ++m; };
+    if (late) { add(0, Ld, Ld + 1); add(1, 0, Ld); } else add(0, 0, Ld + 1);
+    add(1, Ld + 1, cut); add(1, nb - 1, nb); add(1, cut, nb - 1);
+    if (tri) { if (cap < m) return -VLT5_ERR_ARG; for (int i = 0; i < m * 3; ++i) tri[i] = out[i]; }
+    if (n) *n = m;
+    unsigned h = 2166136261u;                                 // FNV-1a over the triples, folded to a positive int
+    for (int i = 0; i < m * 3; ++i) { h ^= (unsigned)out[i]; h *= 16777619u; }
+    return (int)(h & 0x3fffffffu) + 1;
+}
+}  // namespace
+extern "C" int vlt5_grad_release_plan(const vlt5_config* c, const vlt5_tuning* t, int side_stream, int* triples, int cap, int* n) {
+    if (!c || (triples && cap < 5)) return -VLT5_ERR_ARG;
+    return release_plan(*c, t, side_stream != 0, triples, cap, n);
+}
+
 // A stream of the LOWEST priority for vlt5_step.side_stream: the weight-gradient GEMMs then only take the workgroup slots the
 // input-gradient chain on the caller's (normal-priority) stream leaves free, instead of starving it.
 extern "C" int vlt5_side_stream_create(void** stream) {
@@ -1319,12 +1344,26 @@ extern "C" long long vlt5_workspace_offset(const vlt5_config* c, int B, int L, i
     }
 }
 
+int vlt5_build_flags_engine() {
+#ifdef ENC_DGRAD_HOT_A
+    return VLT5_BUILD_ENC_DGRAD_HOT_A;
+#else
+    return 0;
+#endif
+}
+// the caller's release plan against what this backward call is about to do (vlt5_step.release_plan_id)
+static int check_release_plan(const Ctx& k) {
+    if (!k.s.release_plan_id || !bucket_events(k)) return VLT5_OK;
+    if (!k.s.defer_decoder_wgrads) return VLT5_ERR_PLAN;          // (the plan describes the deferred order)
+    return release_plan(k.c, &k.tun, k.side != nullptr, nullptr, 0, nullptr) == k.s.release_plan_id ? VLT5_OK : VLT5_ERR_PLAN;
+}
 #define ENGINE_ENTRY(fn, bwd)                                                   \
     extern "C" int vlt5_##fn(const vlt5_config* c, const vlt5_step* s, void* stream) { \
         if (!c || !s) return VLT5_ERR_ARG;                                      \
         Ctx k(*c, *s, stream);                                                  \
         int rc = k.check(bwd);                                                  \
         if (rc) return rc;                                                      \
+        if (bwd) { rc = check_release_plan(k); if (rc) return rc; }             \
         return fn(k);                                                           \
     }
 extern "C" int vlt5_decoder_step(const vlt5_config* c, const vlt5_step* s, const long long* tokens, int t, void* kv_cache,

@@ -301,3 +301,19 @@ extern "C" int vlt5_drop_cast(const float* src, void* dst_bf16, long long rows, 
     return VLT5_OK;
 }
 extern "C" int vlt5_abi_version(void) { return VLT5_ABI_VERSION; }
+// per translation unit (an experiment flag may be given to one file only): the units that hold wrong-result switches report their own
+int vlt5_build_flags_engine();
+int vlt5_build_flags_attn();
+extern "C" int vlt5_build_flags(void) {
+    int f = vlt5_build_flags_engine() | vlt5_build_flags_attn();
+#if defined(GEMM_TIMELINE) || defined(ATTN_TIMELINE) || defined(DECLIN_TIMELINE)
+    f |= VLT5_BUILD_TIMELINE;
+#endif
+#if defined(ENC_DGRAD_HOT_A)
+    f |= VLT5_BUILD_ENC_DGRAD_HOT_A;
+#endif
+#if defined(ATTN_BWD_NO_STORE)
+    f |= VLT5_BUILD_ATTN_BWD_NO_STORE;
+#endif
+    return f;
+}

@@ -32,6 +32,10 @@ class Hdf5Error(OSError):
     pass
 
 
+class H5G_info_t(C.Structure):              # H5Gpublic.h (unchanged 1.8 ... 1.14)
+    _fields_ = [("storage_type", C.c_int), ("nlinks", hsize_t), ("max_corder", C.c_int64), ("mounted", C.c_uint)]
+
+
 def find_library():
     """Path of libhdf5: $VQACL_HDF5_LIB, the loader's search path, then the places this image and Debian put it."""
     cand = [os.environ.get("VQACL_HDF5_LIB"), ctypes.util.find_library("hdf5"), ctypes.util.find_library("hdf5_serial")]
@@ -60,7 +64,7 @@ def lib():
         "H5Oopen": (hid_t, [hid_t, C.c_char_p, hid_t]), "H5Oclose": (herr_t, [hid_t]), "H5Iget_type": (C.c_int, [hid_t]),
         "H5Lexists": (C.c_int, [hid_t, C.c_char_p, hid_t]),
         "H5Gcreate2": (hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t]), "H5Gclose": (herr_t, [hid_t]),
-        "H5Gget_num_objs": (herr_t, [hid_t, C.POINTER(hsize_t)]),
+        "H5Gget_info": (herr_t, [hid_t, C.POINTER(H5G_info_t)]),
         "H5Lget_name_by_idx": (C.c_ssize_t, [hid_t, C.c_char_p, C.c_int, C.c_int, hsize_t, C.c_char_p, C.c_size_t, hid_t]),
         "H5Dopen2": (hid_t, [hid_t, C.c_char_p, hid_t]), "H5Dclose": (herr_t, [hid_t]),
         "H5Dcreate2": (hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t, hid_t, hid_t]),
@@ -69,8 +73,19 @@ def lib():
         "H5Screate": (hid_t, [C.c_int]), "H5Screate_simple": (hid_t, [C.c_int, C.POINTER(hsize_t), C.POINTER(hsize_t)]), "H5Sclose": (herr_t, [hid_t]),
         "H5Sget_simple_extent_ndims": (C.c_int, [hid_t]), "H5Sget_simple_extent_dims": (C.c_int, [hid_t, C.POINTER(hsize_t), C.POINTER(hsize_t)]),
         "H5Pcreate": (hid_t, [hid_t]), "H5Pclose": (herr_t, [hid_t]), "H5Pset_obj_track_times": (herr_t, [hid_t, C.c_int]),
+        "H5Pset_chunk": (herr_t, [hid_t, C.c_int, C.POINTER(hsize_t)]), "H5Pset_deflate": (herr_t, [hid_t, C.c_uint]), "H5Pset_shuffle": (herr_t, [hid_t]),
+        "H5Zfilter_avail": (C.c_int, [C.c_int]),
         "H5Tget_class": (C.c_int, [hid_t]), "H5Tget_size": (C.c_size_t, [hid_t]), "H5Tget_sign": (C.c_int, [hid_t]), "H5Tclose": (herr_t, [hid_t]),
+        "H5Tcopy": (hid_t, [hid_t]), "H5Tset_fields": (herr_t, [hid_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
+        "H5Tset_size": (herr_t, [hid_t, C.c_size_t]), "H5Tset_ebias": (herr_t, [hid_t, C.c_size_t]),
     }
+    # the version first, through the one entry point whose signature never changed: hid_t is a 32-bit int before 1.10 (every handle
+    # below would be passed and returned with the wrong width), and H5Gget_info / H5Oopen are 1.8+
+    ver = (C.c_uint(), C.c_uint(), C.c_uint())
+    L.H5get_libversion.restype, L.H5get_libversion.argtypes = herr_t, [C.POINTER(C.c_uint)] * 3
+    if L.H5get_libversion(*[C.byref(v) for v in ver]) < 0 or (ver[0].value, ver[1].value) < (1, 10):
+        raise Hdf5Error(f"{path}: HDF5 {ver[0].value}.{ver[1].value}.{ver[2].value} -- vqacl_amd.hdf5_io needs libhdf5 >= 1.10 (64-bit hid_t); "
+                        "set VQACL_HDF5_LIB to a newer library or install h5py (H5FeatureSource uses it when present)")
     for name, (res, args) in sig.items():
         f = getattr(L, name)
         f.restype, f.argtypes = res, args
@@ -114,7 +129,9 @@ class Dataset:
         tp = L.H5Dget_type(did)
         cls, size, sign = L.H5Tget_class(tp), L.H5Tget_size(tp), L.H5Tget_sign(tp)
         L.H5Tclose(tp)
-        if cls == H5T_FLOAT and size in (4, 8):
+        if cls == H5T_FLOAT and size in (2, 4, 8):
+            # (IEEE half: what h5py writes for a float16 array.  libhdf5 < 1.14.4 has no native half type; the library converts between
+            #  any two IEEE-style float layouts, so half datasets are read as float32 -- exact -- and narrowed back for `[()]`)
             self.dtype = np.dtype(f"float{8 * size}")
         elif cls == H5T_INTEGER and size in (1, 2, 4, 8):
             self.dtype = np.dtype(f"{'u' if sign == 0 else ''}int{8 * size}")
@@ -135,6 +152,11 @@ class Dataset:
             raise TypeError(f"can't broadcast {self.shape} -> {tuple(dest.shape)}")
         if self.dtype is None:
             raise TypeError(f"{self.name}: unsupported HDF5 type class")
+        if dest.dtype == np.float16:
+            wide = np.empty(self.shape, dtype=np.float32)
+            self.read_direct(wide)
+            dest[...] = wide                    # (exact for a half dataset; round to nearest otherwise, as h5py's conversion)
+            return
         if lib().H5Dread(self._id, _native(dest.dtype), H5S_ALL, H5S_ALL, H5P_DEFAULT, dest.ctypes.data_as(C.c_void_p)) < 0:
             raise Hdf5Error(f"H5Dread failed on {self.name}")
 
@@ -241,11 +263,13 @@ class H5File(Group):
         oid = L.H5Oopen(self._id, (path or "/").encode(), H5P_DEFAULT)
         if oid < 0:
             raise KeyError(path)
-        n = hsize_t()
-        L.H5Gget_num_objs(oid, C.byref(n))
+        info = H5G_info_t()                   # (H5Gget_num_objs is a deprecated symbol: absent from builds without the 1.6 API)
+        if L.H5Gget_info(oid, C.byref(info)) < 0:
+            L.H5Oclose(oid)
+            raise TypeError(f"{path!r} is not a group")
         out = []
         buf = C.create_string_buffer(1024)
-        for i in range(n.value):
+        for i in range(info.nlinks):
             ln = L.H5Lget_name_by_idx(oid, b".", 0, 0, i, buf, 1024, H5P_DEFAULT)      # H5_INDEX_NAME, H5_ITER_INC
             if ln >= 0:
                 out.append(buf.value.decode())
@@ -270,12 +294,28 @@ class H5File(Group):
             pass
 
 
-def write_feature_file(path, items, track_times=False):
+def _half_type():
+    """IEEE binary16 as an HDF5 type, built the way h5py builds it (a copy of the 32-bit IEEE type with 5 exponent / 10 mantissa bits)."""
+    L = lib()
+    tid = L.H5Tcopy(hid_t.in_dll(L, "H5T_IEEE_F32LE_g").value)
+    if tid < 0 or L.H5Tset_fields(tid, 15, 10, 5, 0, 10) < 0 or L.H5Tset_size(tid, 2) < 0 or L.H5Tset_ebias(tid, 15) < 0:
+        raise Hdf5Error("could not build the IEEE half type")
+    return tid
+
+
+def write_feature_file(path, items, track_times=False, compression=None, compression_opts=4, shuffle=False, chunks=None):
     """Create `path` in the reference's layout: for every (img_id, dict) of `items` a group `{img_id}` holding one dataset per dict
     entry -- arrays as simple dataspaces of their dtype, Python / numpy scalars as scalar datasets (how h5py stores `grp['img_w'] = w`).
     The reference's files carry `features [n,2048] f32`, `boxes [n,4] f32`, `img_w`, `img_h` (+ `obj_id`, `obj_conf`, `attr_id`,
     `attr_conf` that its dataset class never reads).  track_times=False (h5py's default for datasets too): no modification times in
-    the object headers, so the same items give the same bytes."""
+    the object headers, so the same items give the same bytes.  The reference's extraction scripts write `grp['features'] = array`
+    (contiguous, uncompressed: the default here); `compression="gzip"` (+ `compression_opts` level, `shuffle`, `chunks` = a shape or None
+    for one chunk per dataset) stores the non-scalar datasets chunked through the deflate filter, as `create_dataset(..., compression=
+    "gzip")` would -- files re-packed that way read back through the same calls.  float16 arrays are stored as IEEE half."""
+    if compression not in (None, "gzip"):
+        raise ValueError("compression must be None or 'gzip'")
+    if compression and lib().H5Zfilter_avail(1) <= 0:
+        raise Hdf5Error("this libhdf5 was built without the deflate filter")
     L = lib()
     plists = []
 
@@ -307,11 +347,29 @@ def write_feature_file(path, items, track_times=False):
                         sp = L.H5Screate(H5S_SCALAR)
                     else:
                         sp = L.H5Screate_simple(a.ndim, (hsize_t * a.ndim)(*a.shape), None)
-                    tp = _native(a.dtype)
-                    did = L.H5Dcreate2(gid, key.encode(), tp, sp, H5P_DEFAULT, dcpl, H5P_DEFAULT)
-                    ok = did >= 0 and L.H5Dwrite(did, tp, H5S_ALL, H5S_ALL, H5P_DEFAULT, a.ctypes.data_as(C.c_void_p)) >= 0
+                    half = a.dtype == np.float16
+                    if half:                        # stored as IEEE half, handed over as float32 (the library narrows: exact)
+                        a = a.astype(np.float32)
+                    ftp = _half_type() if half else _native(a.dtype)
+                    mtp = _native(a.dtype)
+                    this_dcpl = dcpl
+                    if compression and a.ndim:
+                        this_dcpl = L.H5Pcreate(hid_t.in_dll(L, "H5P_CLS_DATASET_CREATE_ID_g").value)
+                        ch = tuple(chunks) if chunks is not None and len(chunks) == a.ndim else a.shape
+                        ch = tuple(max(1, min(int(c), int(n))) for c, n in zip(ch, a.shape))
+                        bad = this_dcpl < 0 or (not track_times and L.H5Pset_obj_track_times(this_dcpl, 0) < 0) \
+                            or L.H5Pset_chunk(this_dcpl, a.ndim, (hsize_t * a.ndim)(*ch)) < 0 \
+                            or (shuffle and L.H5Pset_shuffle(this_dcpl) < 0) or L.H5Pset_deflate(this_dcpl, int(compression_opts)) < 0
+                        if bad:
+                            raise Hdf5Error("could not build the chunked / deflate creation property list")
+                    did = L.H5Dcreate2(gid, key.encode(), ftp, sp, H5P_DEFAULT, this_dcpl, H5P_DEFAULT)
+                    ok = did >= 0 and L.H5Dwrite(did, mtp, H5S_ALL, H5S_ALL, H5P_DEFAULT, a.ctypes.data_as(C.c_void_p)) >= 0
                     if did >= 0:
                         L.H5Dclose(did)
+                    if this_dcpl != dcpl and this_dcpl >= 0:
+                        L.H5Pclose(this_dcpl)
+                    if half:
+                        L.H5Tclose(ftp)
                     L.H5Sclose(sp)
                     if not ok:
                         raise Hdf5Error(f"writing {img_id}/{key} failed")

@@ -584,12 +584,18 @@ class VLT5(nn.Module):
         BEFORE the last weight-gradient GEMMs, then the lower half).  The decoder layers' buckets belong to phase 1 when their weight
         gradients ride in the encoder phase's launches (vlt5_decoder_buckets_late).  A wait for a bucket's event must be enqueued
         AFTER the call that records it; the data-parallel wrapper cuts its collectives -- and, sharded, its chunk ownership -- by this."""
+        return self._release_plan()[0]
+
+    def _release_plan(self):
+        """(plan, id) as the ENGINE decides them (vlt5_grad_release_plan: the same predicates its backward phases evaluate): the host never
+        re-derives the order.  The id travels back in vlt5_step.release_plan_id, so a backward whose order differs refuses to run."""
         c = self.cfg.c_struct()
-        Ld, Le, nb = self.cfg.num_decoder_layers, self.cfg.num_layers, self._nbuckets
-        cut = Ld + 1 + (Le - lib().vlt5_encoder_late_layers_tuned(Le, C.byref(self.tuning))) if Le > 1 else Ld + 1
-        late = lib().vlt5_decoder_buckets_late(C.byref(c), C.byref(self.tuning), int(self.side_stream_enabled)) == 1
-        head = [(0, Ld, Ld + 1), (1, 0, Ld)] if late else [(0, 0, Ld + 1)]
-        return head + [(1, Ld + 1, cut), (1, nb - 1, nb), (1, cut, nb - 1)]
+        tri = (C.c_int * 15)()
+        n = C.c_int(0)
+        pid = lib().vlt5_grad_release_plan(C.byref(c), C.byref(self.tuning), int(self.side_stream_enabled), tri, 5, C.byref(n))
+        if pid <= 0:
+            raise L.Vlt5Error("vlt5_grad_release_plan failed")
+        return [(tri[3 * i], tri[3 * i + 1], tri[3 * i + 2]) for i in range(n.value)], pid
 
     def _engine_backward(self, st, g, fused):
         c = self.cfg.c_struct()
@@ -629,7 +635,9 @@ class VLT5(nn.Module):
             events = self.dp.make_events(self._nbuckets)
             # only the events the wrapper waits for (the last bucket of every merged slice) are recorded: a marker in the chain's
             # queue is not free, and 26 of them per backward bought nothing
-            plan = self.grad_release_plan()
+            plan, plan_id = self._release_plan()
+            self.dp.check_release_plan(plan)           # frozen at wrapper construction (chunk ownership and Adam moments follow from it)
+            cs.release_plan_id = plan_id               # ... and checked again by the engine calls against what THEY will do
             need = set()
             for _, lo_, hi_ in plan:
                 need.update(last for _, _, _, last in self.dp.slices_of(lo_, hi_))

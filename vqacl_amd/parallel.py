@@ -124,6 +124,14 @@ class DataParallelVLT5:
         self.params_sharded = False         # the f32 master of the layer buckets is only current on the owning rank (zero1)
         self._slices_done = []              # slices reduce-scattered by the current backward, in issue order
         self._param_slices = []
+        # the order the engine completes gradient buckets in (and the call that signals each): frozen here, equal on every rank
+        self._frozen_plan = tuple(tuple(t) for t in model.grad_release_plan())
+        if self.world > 1:
+            seen = [None] * self.world
+            dist.all_gather_object(seen, self._frozen_plan, group=process_group)
+            if any(tuple(map(tuple, p)) != self._frozen_plan for p in seen):
+                from ._lib import Vlt5Error
+                raise Vlt5Error(f"ranks disagree on the gradient release plan (VLT5_* tuning variables differ between ranks?): {seen}")
         # identical initial weights on every rank (what DDP's constructor would do)
         dist.broadcast(model._flat, src=0, group=process_group)
         model._bf16_version = -1
@@ -178,9 +186,18 @@ class DataParallelVLT5:
     def release_ranges(self):
         """The bucket ranges the engine releases gradients in, in order (VLT5.grad_release_plan): stacked cross k/v, decoder layers,
         upper half of the encoder, the last bucket (embeddings / norms), lower half of the encoder -- the slice plan, and with it the
-        chunk every rank owns under zero1, only depends on these (a function of the configuration and the tuning record, the same
-        on every rank)."""
-        return tuple((lo, hi) for _, lo, hi in self.module.grad_release_plan())
+        chunk every rank owns under zero1, only depends on these.  FROZEN when the wrapper is built (`_frozen_plan`): the owned chunks
+        and the sharded Adam moments follow from it, so it must not move with a later edit of `model.tuning` / the side-stream switch."""
+        return tuple((lo, hi) for _, lo, hi in self._frozen_plan)
+
+    def check_release_plan(self, plan):
+        """Called by every backward with the plan the engine reports NOW: a plan that moved since the wrapper was built would silently
+        change chunk ownership (stale Adam moments) and the call a bucket's event is recorded by (a stale event) -- refuse."""
+        if tuple(tuple(t) for t in plan) != self._frozen_plan:
+            from ._lib import Vlt5Error
+            raise Vlt5Error(f"the gradient release plan changed after DataParallelVLT5 was built ({self._frozen_plan} -> {tuple(map(tuple, plan))}): "
+                            "model.tuning (wgrad_shadow, enc_cut) and the side-stream switch must be set BEFORE the wrapper is created; "
+                            "build a new wrapper (and optimizer) for a different plan")
 
     def slice_plan(self):
         """Every merged slice a backward reduce-scatters, [(a, b)] in flat elements, in issue order."""
