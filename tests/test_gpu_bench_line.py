@@ -45,6 +45,8 @@ def run_bounded(cmd, env, timeout):
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
     try:
         out, err = proc.communicate(timeout=timeout)
+        import shutil
+        shutil.rmtree(dump_dir, ignore_errors=True)        # (the ranks open their dump files when they arm the handler: empty unless asked)
         return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
     except subprocess.TimeoutExpired:
         members = group_members(proc.pid)
