@@ -127,11 +127,16 @@ class DataParallelVLT5:
         # the order the engine completes gradient buckets in (and the call that signals each): frozen here, equal on every rank
         self._frozen_plan = tuple(tuple(t) for t in model.grad_release_plan())
         if self.world > 1:
-            seen = [None] * self.world
-            dist.all_gather_object(seen, self._frozen_plan, group=process_group)
-            if any(tuple(map(tuple, p)) != self._frozen_plan for p in seen):
+            # (a tensor collective on the model's device, like the weight broadcast below -- nothing the RCCL path does not do anyway)
+            mine = torch.full((16,), -1, dtype=torch.int64, device=model._flat.device)
+            flat_plan = [v for t in self._frozen_plan for v in t]
+            mine[:len(flat_plan)] = torch.tensor(flat_plan, dtype=torch.int64)
+            seen = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(seen, mine, group=process_group)
+            if any(not torch.equal(t, mine) for t in seen):
                 from ._lib import Vlt5Error
-                raise Vlt5Error(f"ranks disagree on the gradient release plan (VLT5_* tuning variables differ between ranks?): {seen}")
+                raise Vlt5Error("ranks disagree on the gradient release plan (VLT5_* tuning variables differ between ranks?): "
+                                + str([t.tolist() for t in seen]))
         # identical initial weights on every rank (what DDP's constructor would do)
         dist.broadcast(model._flat, src=0, group=process_group)
         model._bf16_version = -1
