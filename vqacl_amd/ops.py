@@ -23,8 +23,9 @@ def _need(t, dtype=None):
 
 def gemm(A, B, M, N, K, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, alpha=1.0, bias=None, relu=False,
          resid=None, gate=None, gate_scale=1.0, drop_p=0.0, drop_seed=0, accum=False, split_k=1, tile=(0, 0),
-         lda=None, ldb=None, ldc=None, batch=1, batch_strides=(0, 0, 0), emit=None, norm=None):
+         lda=None, ldb=None, ldc=None, batch=1, batch_strides=(0, 0, 0), emit=None, norm=None, tuning=None):
     """C[M,N] = epi(alpha * sum_k A[m,k] B[n,k]); A,B bf16 2-D tensors, k-major flags as in vlt5_gemm_desc.
+    tuning: a vlt5_tuning record (_lib.make_tuning) for the launch's policy switches.
     emit = (w_norm f32 [N], xw bf16 [M,N], partials f32 [M,32]): producer side of a folded T5 RMS norm -- returns (out, nparts);
     norm = (partials, nparts, d, eps, rstd_out or None): consumer side."""
     g, out, _keep = gemm_desc(A, B, M, N, K, a_kmajor=a_kmajor, b_kmajor=b_kmajor, out=out, out_f32=out_f32, alpha=alpha, bias=bias,
@@ -35,6 +36,8 @@ def gemm(A, B, M, N, K, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=Fal
         g.emit_norm_w, g.emit_xw_bf16, g.emit_partials = ptr(emit[0]), ptr(emit[1]), ptr(emit[2])
     if norm is not None:
         g.norm_partials, g.norm_nparts, g.norm_d, g.norm_eps, g.norm_rstd_out = ptr(norm[0]), norm[1], norm[2], norm[3], ptr(norm[4])
+    if tuning is not None:
+        g.tuning = C.pointer(tuning)
     check(lib().vlt5_gemm_bf16(C.byref(g), stream_ptr()), "vlt5_gemm_bf16")
     if emit is not None:
         return out, g.emit_nparts
