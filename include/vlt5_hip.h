@@ -72,9 +72,7 @@ typedef struct {
     int gemm_split_cap;     /* > 0: largest automatic split-K factor of the small-output policy (default 4; 8 until round 5) */
     int decode_nfrag;       /* decode kernels: 1, 2 or 4 forces the column-tile width of the projections to 16 x this many columns; 16: the
                                round-4 geometry rule (widest tile that fills the chip) at every row count; 0: the launch geometry's own choice */
-    int gemm_ksplit;        /* 2: few-row GEMMs with row-major operands and K = 768 / 1024 (the decoder's forward projections) through the
-                               K-split kernel (csrc/ksplit.hip: the reduction split over the waves of a workgroup, operands straight
-                               into registers, one memory latency instead of twelve serial k-steps); 1 / 0: the tiled kernel */
+    int reserved[1];
 } vlt5_tuning;
 
 /* ---- GEMM: C[M,N] = epi(alpha * sum_k A[m,k] B[n,k]) -------------------------------------------

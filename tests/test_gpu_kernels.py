@@ -179,49 +179,6 @@ def test_gemm_epilogues(dev, tile, M, N, K):
     close(out, base + 2.0, 2e-3, 2e-2, "accumulate")
 
 
-@pytest.mark.parametrize("M,N,K", [(400, 2304, 768), (400, 768, 768), (400, 3072, 768), (20, 768, 768), (33, 64, 768), (512, 1024, 1024),
-                                   (100, 4096, 1024), (80, 192, 768)])
-def test_ksplit_kernel_for_few_row_projections(dev, M, N, K):
-    """csrc/ksplit.hip (vlt5_tuning.gemm_ksplit = 2): the reduction split over the four waves of a workgroup, operands straight into
-    registers -- the decoder's forward projections (HF T5Attention q/k/v/o, T5DenseReluDense wi at M = B*T rows).  Against the f32
-    product of the same bf16 operands, every epilogue it takes (plain bf16, ReLU + dropout bf16, dropout + f32 residual, alpha), the
-    dropout mask bit-equal to the tiled kernel's (the backward regenerates it from the same counters), ragged row counts, repeated
-    launches bit-identical; and a description it does not take (k-major operand, bias, K = 200) falls through to the tiled kernel."""
-    from vqacl_amd import ops
-    from vqacl_amd import _lib as L
-    on, off = L.make_tuning(gemm_ksplit=True), L.make_tuning(gemm_ksplit=False)
-    g = torch.Generator().manual_seed(M + N + K)
-    A = rnd((M, K), g).to(BF)
-    B = (rnd((N, K), g) * K ** -0.5 + torch.arange(N)[:, None] * 1e-4).to(BF)      # asymmetric: a transposed C-write cannot pass
-    resid = rnd((M, N), g)
-    base = A.float() @ B.float().t()
-    Ad, Bd, Rd = A.to(dev), B.to(dev), resid.to(dev)
-    close(ops.gemm(Ad, Bd, M, N, K, tuning=on), base, 1e-2, 2e-2, "plain bf16")
-    close(ops.gemm(Ad, Bd, M, N, K, out_f32=True, alpha=0.25, tuning=on), 0.25 * base, 1e-3, 2e-3, "alpha, f32")
-    close(ops.gemm(Ad, Bd, M, N, K, out_f32=True, resid=Rd, tuning=on), base + resid, 1e-3, 4e-3, "f32 + residual")
-    close(ops.gemm(Ad, Bd, M, N, K, relu=True, tuning=on), torch.relu(base), 1e-2, 2e-2, "relu bf16")
-    # dropout: the same keep pattern as the tiled kernel (element index m*N+n, same hash), the kept values scaled alike
-    for kw in (dict(relu=True), dict(out_f32=True, resid=Rd)):
-        a = ops.gemm(Ad, Bd, M, N, K, drop_p=0.1, drop_seed=99, tuning=on, **kw).float()
-        b = ops.gemm(Ad, Bd, M, N, K, drop_p=0.1, drop_seed=99, tuning=off, **kw).float()
-        close(a, b, 1e-2, 2e-2, f"dropout {list(kw)}: ksplit vs tiled")
-        if "resid" in kw:
-            dropped_a, dropped_b = (a - Rd) == 0, (b - Rd) == 0
-            assert torch.equal(dropped_a, dropped_b), "dropout mask differs from the tiled kernel's"
-            frac = float(dropped_a.float().mean())
-            assert abs(frac - 0.1) < 0.02 + 3.0 / (M * N) ** 0.5, frac
-    x1 = ops.gemm(Ad, Bd, M, N, K, out_f32=True, resid=Rd, drop_p=0.1, drop_seed=5, tuning=on)
-    x2 = ops.gemm(Ad, Bd, M, N, K, out_f32=True, resid=Rd, drop_p=0.1, drop_seed=5, tuning=on)
-    assert torch.equal(x1, x2), "fixed summation order: repeated launches are bit-identical"
-    # not this kernel's: the dispatcher falls through to the tiles, results as ever
-    bias = rnd((N,), g).to(dev)
-    close(ops.gemm(Ad, Bd, M, N, K, out_f32=True, bias=bias, tuning=on), base + bias.cpu(), 1e-3, 4e-3, "bias -> tiled kernel")
-    Bk = B.t().contiguous().to(dev)                                              # [K, N]: the k-major view of the same B
-    close(ops.gemm(Ad, Bk, M, N, K, b_kmajor=True, out_f32=True, tuning=on), base, 1e-3, 4e-3, "k-major B -> tiled kernel")
-    close(ops.gemm(Ad[:, :200].contiguous(), Bd[:, :200].contiguous(), M, N, 200, out_f32=True, tuning=on),
-          A[:, :200].float() @ B[:, :200].float().t(), 1e-3, 4e-3, "K = 200 -> tiled kernel")
-
-
 def test_gemm_randomised_shapes_layouts_and_epilogues(dev):
     """80 seeded random problems: ragged M (any), N and K multiples of 8 (K tails below 64), every operand layout, every tile,
     padded leading dimensions, split-K, layer batches, and the epilogue combinations the engine issues -- against torch f32."""

@@ -1376,9 +1376,8 @@ def test_degenerate_rows_vs_oracle(dev):
                                     dict(dec_fused=True),                              # fused decoder attention sublayers (csrc/dec_attn.hip)
                                     dict(fused_attn=False),                            # encoder q|k|v GEMM + attention core as two launches
                                     dict(fused_heads=1),                               # one head per workgroup in the fused encoder kernel
-                                    dict(wgrad_shadow=False, wgrad_grouped=False, enc_cut=3),
-                                    dict(gemm_ksplit=True), dict(gemm_ksplit=False)],   # few-row projections through csrc/ksplit.hip / the tiles
-                         ids=["unfolded", "fold-dec", "dec-fused", "unfused-attn", "one-head", "plain-wgrads", "ksplit", "no-ksplit"])
+                                    dict(wgrad_shadow=False, wgrad_grouped=False, enc_cut=3)],
+                         ids=["unfolded", "fold-dec", "dec-fused", "unfused-attn", "one-head", "plain-wgrads"])
 def test_alternative_engine_paths_still_match_the_oracle(dev, tuning):
     """The engine folds the encoder's T5 RMS norms around their GEMMs, fuses the encoder's projection + attention core and groups
     weight-gradient launches by default; the other paths stay in the library as options of a vlt5_tuning record (vlt5_step.tuning) --

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""The K-split kernel (csrc/ksplit.hip, vlt5_tuning.gemm_ksplit = 2) against the tiled kernel on the decoder's forward projections:
+"""EXPERIMENT, not product (needs tools/experiments/ksplit_kernel.patch applied and the library rebuilt): measured in round 6 and not kept
+-- profiles/r06_d_ksplit_probe.txt, r06_d_ab_ksplit.txt.
+The K-split kernel (csrc/ksplit.hip, vlt5_tuning.gemm_ksplit = 2) against the tiled kernel on the decoder's forward projections:
 correctness against an f32 torch product of the same bf16 operands (and bit-equality of the dropout mask with the tiled kernel's),
 graph-replayed timing warm (one weight matrix) and cold-ish (rotating through 48 weight matrices, > Infinity Cache).
 

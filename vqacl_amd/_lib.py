@@ -23,7 +23,7 @@ class Tuning(C.Structure):
     _fields_ = [("fold_norm", c_i), ("fold_norm_dec", c_i), ("fused_attn", c_i), ("fused_heads", c_i), ("dec_fused", c_i),
                 ("enc_cut", c_i), ("wgrad_shadow", c_i), ("wgrad_grouped", c_i), ("gemm_t128_kmkm", c_i), ("gemm_t256_km", c_i),
                 ("gemm_t256_min", c_i), ("gemm_dec_tall", c_i), ("gemm_split_kmin", c_i), ("decode_fast", c_i), ("decode_split_norm", c_i),
-                ("gemm_rmkm_tile", c_i), ("gemm_rmrm_f32_tile", c_i), ("gemm_split_cap", c_i), ("decode_nfrag", c_i), ("gemm_ksplit", c_i)]
+                ("gemm_rmkm_tile", c_i), ("gemm_rmrm_f32_tile", c_i), ("gemm_split_cap", c_i), ("decode_nfrag", c_i), ("reserved", c_i * 1)]
 
 
 # environment variable -> (field, how its value maps): the library itself reads no environment; the host reads these ONCE per model
@@ -35,8 +35,7 @@ _TUNING_ENV = {"VLT5_FOLD_NORM": ("fold_norm", "onoff"), "VLT5_FOLD_NORM_DEC": (
                "VLT5_GEMM_T256_MIN": ("gemm_t256_min", "int"), "VLT5_GEMM_DEC_TALL": ("gemm_dec_tall", "onoff"),
                "VLT5_GEMM_SPLIT_KMIN": ("gemm_split_kmin", "int"), "VLT5_DECODE_FAST": ("decode_fast", "onoff"),
                "VLT5_DECODE_SPLIT_NORM": ("decode_split_norm", "onoff"), "VLT5_GEMM_RMKM_TILE": ("gemm_rmkm_tile", "int"),
-               "VLT5_GEMM_RMRM_F32_TILE": ("gemm_rmrm_f32_tile", "int"), "VLT5_GEMM_SPLIT_CAP": ("gemm_split_cap", "int"), "VLT5_DECODE_NFRAG": ("decode_nfrag", "int"),
-               "VLT5_GEMM_KSPLIT": ("gemm_ksplit", "onoff")}
+               "VLT5_GEMM_RMRM_F32_TILE": ("gemm_rmrm_f32_tile", "int"), "VLT5_GEMM_SPLIT_CAP": ("gemm_split_cap", "int"), "VLT5_DECODE_NFRAG": ("decode_nfrag", "int")}
 
 
 def make_tuning(**fields):

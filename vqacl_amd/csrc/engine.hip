@@ -13,8 +13,6 @@
 #include <string>
 #include <vector>
 
-bool vlt5_gemm_ksplit_shape_ok(int M, int N, int K);                     // ksplit.hip
-
 namespace {
 
 constexpr int MAXL = 48;
@@ -328,7 +326,6 @@ struct Ctx {
     // +0.13 ms per step against -0.17 ms of norm launches saved ... and +0.13 ms of slower 84-tile GEMMs: a net loss, off by default)
     bool fold_dec() const { return tun.fold_norm_dec == 2 && fold_on(); }
     bool fold_enc_first(int l) const { return fold_on() && l > 0 && pick_split(p.M, d, ff) <= 1; }     // the norm in front of layer l's attention
-    bool ksplit_on(int M, int N, int Kred) const { return tun.gemm_ksplit == 2 && vlt5_gemm_ksplit_shape_ok(M, N, Kred); }
     int pick_split(int M, int N, int Kred) const { return vlt5_gemm_auto_split_tuned(M, N, Kred, (long long)p.slab_bytes, &tun); }
     int ffw() const { return c.gated_act ? 2 * ff : ff; }
     // hidden activation of an FFN: h = dropout(act(xn Wi^T)).  ReLU: one GEMM with the activation in its epilogue.  Gated GELU (HF
@@ -346,7 +343,7 @@ struct Ctx {
     int lin_fwd_for_norm(const bf16_t* X, const bf16_t* W, float* Y, int M, int N, int K, float dp, uint32_t dseed,
                          const float* resid, int* pending) const {
         *pending = 0;
-        const int sk = ksplit_on(M, N, K) ? 1 : pick_split(M, N, K);      // (the K-split kernel finishes the row itself: no slabs)
+        const int sk = pick_split(M, N, K);
         if (sk <= 1) return lin_fwd(X, W, Y, M, N, K, 1, 1.f, nullptr, 0, dp, dseed, resid);
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);

@@ -17,8 +17,6 @@ int launch_64x64(const GemmArgs& a, int akm, int bkm, int splits, int batch, hip
 }  // namespace vlt5gemm
 using namespace vlt5gemm;
 
-int vlt5_gemm_ksplit_try(const vlt5_gemm_desc* g, hipStream_t st);       // ksplit.hip
-
 extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->B || !d->C) return VLT5_ERR_ARG;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return VLT5_ERR_ARG;
@@ -34,11 +32,6 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         return VLT5_ERR_ARG;
     if (d->defer_reduce && d->accum) return VLT5_ERR_ARG;            // the consumer of the slabs adds nothing else
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (d->tuning && d->tuning->gemm_ksplit == 2) {
-        // few rows, row-major operands, K = 768 / 1024: the reduction split over the waves of a workgroup (ksplit.hip)
-        const int rc = vlt5_gemm_ksplit_try(d, st);
-        if (rc != -1) { d->split_used = 1; return rc; }
-    }
     GemmArgs a;
     a.A = (const bf16_t*)d->A; a.B = (const bf16_t*)d->B; a.C = d->C;
     a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
