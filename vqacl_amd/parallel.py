@@ -176,7 +176,7 @@ class DataParallelVLT5:
             return None
         want = self.comm_priority()
         if self._comm is None or self._comm_prio != want:
-            new = torch.cuda.Stream(priority=want)
+            new = torch.cuda.Stream(device=self.module._flat.device, priority=want)     # (first use may be on an autograd thread)
             if self._comm is not None:      # the configuration changed (an optimizer was attached, a switch flipped): keep the order
                 new.wait_stream(self._comm)
             self._comm, self._comm_prio = new, want
