@@ -8,7 +8,7 @@ allocation sets in ONE process on ONE box give 1.19 ... 1.43 ms (each stable to 
 from 1.46 to 1.27 ms with the byte offset between the streams (`tools/adamw_placement_probe.py`, `tools/adamw_pad_probe.py`,
 `profiles/r06_h_*`).  There is no closed form for the good offsets (they differ between boxes), so the placement is MEASURED: the model
 allocates one arena for master, gradient, moments and shadow, times the real AdamW kernel over a handful of strides between the
-streams (a few ms each, once per model construction) and carves the five buffers at the fastest one.
+streams (twelve candidates, ~6 ms each, once per model construction) and carves the five buffers at the fastest one.
 
 Numerics are not involved: the buffers hold what they always held, only their addresses are chosen.  Host logic without a GPU (CPU
 models of the tests) and small models get plain separate allocations.
@@ -19,7 +19,7 @@ import torch
 
 MIB = 1 << 20
 # byte offsets added to the streams' natural stride (4 * n bytes); the arena carries 4 * max(PADS) of slack (288 GB of HBM)
-PADS = (0, 48 * MIB, 96 * MIB, 144 * MIB, 192 * MIB, 240 * MIB)
+PADS = tuple(k * 24 * MIB for k in range(12))      # 0 ... 264 MiB: no structure was found in the good offsets, so a dozen are simply tried
 MIN_ELEMS = 32 * 1000 * 1000          # below this the pass is microseconds: not worth a measurement
 
 
