@@ -689,19 +689,27 @@ def test_optimizer_streams_are_placed_in_one_arena_and_nothing_else_changes(dev,
     torch.manual_seed(5)
     placed = VLT5VQA(VLT5Config(**cfg), device=dev)
     info = placed.placement_info
-    assert info["placement"] == "one arena" and len(info["adamw_us_by_pad_mib"]) >= 4, info
-    best = min(info["adamw_us_by_pad_mib"].values())
-    assert info["adamw_us_by_pad_mib"][info["stride_pad_mib"]] == best and 300.0 < best < 5000.0, info
-    n = placed.flat_params().numel()
-    stride = 4 * n + info["stride_pad_mib"] * (1 << 20)
-    assert placed._flat_grad.data_ptr() - placed._flat.data_ptr() == stride and placed._adam_m.data_ptr() - placed._flat_grad.data_ptr() == stride
-    assert all(t.data_ptr() % 16 == 0 for t in (placed._flat, placed._flat_grad, placed._adam_m, placed._adam_v, placed._flat_bf16))
+    t = info["adamw_us_by_candidate"]
+    assert len(t) == 16 and info["placement"] in t and t[info["placement"]] == min(t.values()) and 300.0 < min(t.values()) < 5000.0, info
+    assert sum(k.startswith("arena+") for k in t) == 12 and sum(k.startswith("separate#") for k in t) == 4
+    assert all(x.data_ptr() % 16 == 0 for x in (placed._flat, placed._flat_grad, placed._adam_m, placed._adam_v, placed._flat_bf16))
+    assert len({x.data_ptr() for x in (placed._flat, placed._flat_grad, placed._adam_m, placed._adam_v, placed._flat_bf16)}) == 5
     assert float(placed._flat_grad.abs().sum()) == 0.0 and float(placed._adam_m.abs().sum()) == 0.0 and float(placed._adam_v.abs().sum()) == 0.0
+    assert float(placed._flat_bf16.float().abs().sum()) > 0.0, "the shadow follows the initialised master"
+    # the arena at a forced stride (A/B switch): the streams lie where the stride says
+    monkeypatch.setenv("VQACL_PLACEMENT", "96")
+    forced = VLT5VQA(VLT5Config(**cfg), device=dev)
+    monkeypatch.delenv("VQACL_PLACEMENT")
+    n = forced.flat_params().numel()
+    stride = 4 * n + 96 * (1 << 20)
+    assert forced.placement_info["placement"] == "arena+96MiB" and forced.placement_info["adamw_us_by_candidate"] == {}
+    assert forced._flat_grad.data_ptr() - forced._flat.data_ptr() == stride and forced._adam_m.data_ptr() - forced._flat_grad.data_ptr() == stride
+    del forced
     monkeypatch.setenv("VQACL_PLACEMENT", "0")
     torch.manual_seed(5)
     plain = VLT5VQA(VLT5Config(**cfg), device=dev)
     monkeypatch.delenv("VQACL_PLACEMENT")
-    assert plain.placement_info["placement"] == "separate allocations" and plain._adam_m is None
+    assert plain.placement_info["placement"].startswith("separate allocations") and plain._adam_m is None
     assert torch.equal(plain.flat_params(), placed.flat_params()), "same seed, same initial weights"
     batch = {k: v.to(dev) for k, v in synthetic_batch(8, seed=3).items()}
     outs = []

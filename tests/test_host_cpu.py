@@ -325,9 +325,9 @@ def test_stream_placement_helpers_on_the_host(built):
     assert (master._version - v0[0], grad._version - v0[1], m._version - v0[2]) == (1, 2, 0), "no shared version counter between the streams"
     assert float(arena[:4].view(torch.float32)[0]) == 1.0 and float(m.abs().sum()) == 0.0
     out = P.place_streams(n, "cpu")
-    assert out[3] is None and out[4] is None and out[5]["placement"] == "separate allocations"
+    assert out[3] is None and out[4] is None and out[5]["placement"].startswith("separate allocations")
     model = VLT5VQA(VLT5Config(d_model=64, d_kv=16, num_heads=4, d_ff=128, num_layers=1, num_decoder_layers=1, vocab_size=400, feat_dim=64),
                     device=torch.device("cpu"))
-    assert model.placement_info["placement"] == "separate allocations" and model.lease_adam_state(object()) is None
+    assert model.placement_info["placement"].startswith("separate allocations") and model.lease_adam_state(object()) is None
     opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-3)
     assert opt._m.numel() == model.flat_params().numel() and opt._m.data_ptr() != opt._v.data_ptr()

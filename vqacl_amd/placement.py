@@ -7,8 +7,9 @@ other: with unchanged code the same nine launches take 1.13-1.46 ms per step ove
 allocation sets in ONE process on ONE box give 1.19 ... 1.43 ms (each stable to 0.5 %), and carved out of one allocation the pass moves
 from 1.46 to 1.27 ms with the byte offset between the streams (`tools/adamw_placement_probe.py`, `tools/adamw_pad_probe.py`,
 `profiles/r06_h_*`).  There is no closed form for the good offsets (they differ between boxes), so the placement is MEASURED: the model
-allocates one arena for master, gradient, moments and shadow, times the real AdamW kernel over a handful of strides between the
-streams (twelve candidates, ~6 ms each, once per model construction) and carves the five buffers at the fastest one.
+times the real AdamW kernel on sixteen candidate placements of master, gradient, moments and shadow -- one arena at twelve strides
+between the streams, four sets of plain separate allocations (on some boxes one of those beats every stride) -- ~6 ms each, once per
+model construction, and keeps the fastest.
 
 Numerics are not involved: the buffers hold what they always held, only their addresses are chosen.  Host logic without a GPU (CPU
 models of the tests) and small models get plain separate allocations.
@@ -64,33 +65,52 @@ def _time_pass(bufs, n, reps=3):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+N_SEPARATE = 4                         # independent allocation sets tried beside the arena strides
+
+
 def place_streams(n, device, pads=None, log=None):
     """The five flat buffers of a model with n parameters (n a multiple of 64 elements): (master, grad, shadow, m, v, info).  m / v are
-    None when the buffers are separate allocations (the optimizer then allocates its own moments).  info: what was measured."""
+    None when nothing was measured (CPU, small model, VQACL_PLACEMENT=0): the optimizer then allocates its own moments.  Otherwise
+    the candidates -- the arena at each stride of PADS and N_SEPARATE sets of five plain allocations (what the model did until round
+    6; on some boxes one of those beats every arena stride) -- are all allocated, the real AdamW kernel is timed on each, the fastest
+    is kept and the rest freed.  info: what was measured."""
     dev = torch.device(device)
     mode = os.environ.get("VQACL_PLACEMENT", "1")
     if dev.type != "cuda" or n < MIN_ELEMS or mode == "0":
         return (torch.zeros(n, device=dev, dtype=torch.float32), torch.zeros(n, device=dev, dtype=torch.float32),
-                torch.zeros(n, device=dev, dtype=torch.bfloat16), None, None, {"placement": "separate allocations"})
+                torch.zeros(n, device=dev, dtype=torch.bfloat16), None, None, {"placement": "separate allocations, not measured"})
     pads = tuple(PADS if pads is None else pads)
-    if mode not in ("0", "1"):                     # VQACL_PLACEMENT=<MiB>: that stride, no measurement (A/B runs)
-        pads = (int(mode) * MIB,)
+    n_sep = N_SEPARATE
+    if mode not in ("0", "1"):                     # VQACL_PLACEMENT=<MiB>: the arena at that stride, no measurement (A/B runs)
+        pads, n_sep = (int(mode) * MIB,), 0
     nbytes = 4 * (4 * n + max(pads)) + 2 * n + 4096
     with torch.cuda.device(dev):
         arena = torch.zeros(nbytes, device=dev, dtype=torch.uint8)
-        timings = {}
-        best = pads[0]
-        if len(pads) > 1:
-            for pad in pads:
-                bufs = carve(arena, n, pad)
+        sets = [[torch.zeros(n, device=dev, dtype=torch.float32) for _ in range(4)] + [torch.zeros(n, device=dev, dtype=torch.bfloat16)]
+                for _ in range(n_sep)]
+        timings, cands = {}, []
+        for pad in pads:
+            cands.append((f"arena+{pad // MIB}MiB", lambda pad=pad: carve(arena, n, pad)))
+        for i, bufs in enumerate(sets):
+            cands.append((f"separate#{i}", lambda bufs=bufs: tuple(bufs)))
+        best = cands[0][0]
+        if len(cands) > 1:
+            for name, make in cands:
+                bufs = make()
                 bufs[1].fill_(1e-3)                # (a gradient that moves the moments: the pass does its real arithmetic)
-                timings[pad // MIB] = round(_time_pass(bufs, n), 1)
+                timings[name] = round(_time_pass(bufs, n), 1)
                 torch.cuda.synchronize(dev)
-            best = min(pads, key=lambda q: timings[q // MIB])
-            arena.zero_()                          # the trial passes wrote moments and masters
-    master, grad, m, v, shadow = carve(arena, n, best)
-    info = {"placement": "one arena", "stride_pad_mib": best // MIB, "adamw_us_by_pad_mib": timings, "arena_bytes": nbytes}
+            best = min(timings, key=timings.get)
+        master, grad, m, v, shadow = dict(cands)[best]()
+        if best.startswith("arena"):
+            arena.zero_()                          # the trial passes wrote masters and moments
+            master._vlt5_arena = arena
+        else:
+            for t in (master, grad, m, v, shadow):
+                t.zero_()
+        del sets, cands, arena
+        torch.cuda.empty_cache()                   # the losing candidates go back to the driver, not into the caching allocator's pool
+    info = {"placement": best, "adamw_us_by_candidate": timings}
     if log:
         log(info)
-    master._vlt5_arena = arena                     # (keeps the allocation alive with the views)
     return master, grad, shadow, m, v, info
