@@ -807,7 +807,6 @@ def main():
            "samples_per_sec_per_gpu": round(value / world, 2), "final_loss": round(final_loss, 4),
            "step_tflops_per_gpu": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms, 2),
            "step_frac_of_mfma_peak": round(FWD_BWD_GFLOP_PER_SAMPLE * B / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
-    out["optimizer_placement"] = getattr(model, "placement_info", None)      # (vqacl_amd/placement.py: where the AdamW pass's streams lie)
     if distributed:
         out["rccl_ranks_seen" if not rehearsal else "ranks_seen"] = dist.get_world_size()
         out["grad_exchange"] = dp_info

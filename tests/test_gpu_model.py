@@ -678,65 +678,6 @@ def test_incremental_decoder_step_matches_full_decoder_logits(dev, fast, variant
     assert lib().vlt5_decoder_step(C.byref(c), C.byref(cs), ptr(tok), T, ptr(cache), ptr(logits), ptr(nxt), stream_ptr()) == 1001
 
 
-def test_optimizer_streams_are_placed_in_one_arena_and_nothing_else_changes(dev, monkeypatch):
-    """vqacl_amd/placement.py (round 6): master, gradient, both Adam moments and the bf16 shadow of a base-sized model are carved out of one
-    arena at the stride between the streams that the clip + AdamW pass measured fastest on this device.  Only ADDRESSES are chosen: one
-    train step + optimizer step gives bit-identical weights with the placement off (separate allocations); the optimizer takes the
-    model's moment buffers (zeroed), a second live optimizer gets its own, and a new optimizer after the first is dropped takes them over."""
-    from vqacl_amd import VLT5VQA, VLT5Config, FusedAdamW, reference_param_groups
-    from bench import synthetic_batch
-    cfg = dict(dropout_rate=0.1)
-    torch.manual_seed(5)
-    placed = VLT5VQA(VLT5Config(**cfg), device=dev)
-    info = placed.placement_info
-    t = info["adamw_us_by_candidate"]
-    assert len(t) == 16 and info["placement"] in t and t[info["placement"]] == min(t.values()) and 300.0 < min(t.values()) < 5000.0, info
-    assert sum(k.startswith("arena+") for k in t) == 12 and sum(k.startswith("separate#") for k in t) == 4
-    assert all(x.data_ptr() % 16 == 0 for x in (placed._flat, placed._flat_grad, placed._adam_m, placed._adam_v, placed._flat_bf16))
-    assert len({x.data_ptr() for x in (placed._flat, placed._flat_grad, placed._adam_m, placed._adam_v, placed._flat_bf16)}) == 5
-    assert float(placed._flat_grad.abs().sum()) == 0.0 and float(placed._adam_m.abs().sum()) == 0.0 and float(placed._adam_v.abs().sum()) == 0.0
-    assert float(placed._flat_bf16.float().abs().sum()) > 0.0, "the shadow follows the initialised master"
-    # the arena at a forced stride (A/B switch): the streams lie where the stride says
-    monkeypatch.setenv("VQACL_PLACEMENT", "96")
-    forced = VLT5VQA(VLT5Config(**cfg), device=dev)
-    monkeypatch.delenv("VQACL_PLACEMENT")
-    n = forced.flat_params().numel()
-    stride = 4 * n + 96 * (1 << 20)
-    assert forced.placement_info["placement"] == "arena+96MiB" and forced.placement_info["adamw_us_by_candidate"] == {}
-    assert forced._flat_grad.data_ptr() - forced._flat.data_ptr() == stride and forced._adam_m.data_ptr() - forced._flat_grad.data_ptr() == stride
-    del forced
-    monkeypatch.setenv("VQACL_PLACEMENT", "0")
-    torch.manual_seed(5)
-    plain = VLT5VQA(VLT5Config(**cfg), device=dev)
-    monkeypatch.delenv("VQACL_PLACEMENT")
-    assert plain.placement_info["placement"].startswith("separate allocations") and plain._adam_m is None
-    assert torch.equal(plain.flat_params(), placed.flat_params()), "same seed, same initial weights"
-    batch = {k: v.to(dev) for k, v in synthetic_batch(8, seed=3).items()}
-    outs = []
-    for model in (placed, plain):
-        model.train()
-        opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-3, eps=1e-6, max_grad_norm=5.0)
-        assert (opt._m.data_ptr() == model._adam_m.data_ptr()) if model is placed else (model._adam_m is None)
-        for _ in range(2):
-            res = model.train_step(batch, 0, 0.5, 0.3)
-            res["loss"].backward()
-            opt.step()
-            for p in model.parameters():
-                p.grad = None
-        torch.cuda.synchronize()
-        outs.append((model.flat_params().clone(), opt._m.clone(), opt._v.clone(), float(res["loss"].detach())))
-        if model is placed:
-            second = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-3)
-            assert second._m.data_ptr() != model._adam_m.data_ptr(), "a second LIVE optimizer must not share the moments"
-            del second, opt
-            import gc
-            gc.collect()
-            third = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-3)
-            assert third._m.data_ptr() == model._adam_m.data_ptr() and float(third._m.abs().sum()) == 0.0 and float(third._v.abs().sum()) == 0.0
-    for a, b in zip(outs[0], outs[1]):
-        assert (torch.equal(a, b) if torch.is_tensor(a) else a == b), "placement must not change a single bit"
-
-
 def test_backward_phases_refuse_a_release_plan_that_is_not_theirs(dev):
     """vlt5_step.release_plan_id (round 6): with gradient-bucket events the backward phases recompute the order they are about to complete the
     buckets in and return VLT5_ERR_PLAN -- before launching anything -- when the caller cut its waits by another one."""

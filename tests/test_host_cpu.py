@@ -305,29 +305,3 @@ def test_moment_accumulator_of_the_dropout_comparison():
     assert torch.allclose(m.half[0]["a"], st[0::2].sum(0), atol=1e-12) and torch.allclose(m.half[1]["a"], st[1::2].sum(0), atol=1e-12)
     assert abs(m.var_sum("loss") - float(torch.stack([x.sum() for x in xs]).double().var(unbiased=True))) < 1e-9
     assert abs(T._cos(st[0], st[0] * 3.0) - 1.0) < 1e-12
-
-
-def test_stream_placement_helpers_on_the_host(built):
-    """vqacl_amd/placement.py without a GPU: the five buffers carved out of one arena are independent tensors (own version counters --
-    the model tells a torch-side write of the master from `_flat._version`), lie where the stride says, and a CPU / small model gets
-    plain separate allocations and no moment buffers of its own (the optimizer allocates them)."""
-    from vqacl_amd import placement as P
-    from vqacl_amd import VLT5VQA, VLT5Config, FusedAdamW, reference_param_groups
-    n, pad = 128, 512
-    arena = torch.zeros(4 * (4 * n + pad) + 2 * n + 4096, dtype=torch.uint8)
-    master, grad, m, v, shadow = P.carve(arena, n, pad)
-    assert [t.dtype for t in (master, grad, m, v, shadow)] == [torch.float32] * 4 + [torch.bfloat16]
-    assert grad.data_ptr() - master.data_ptr() == 4 * n + pad and shadow.data_ptr() - v.data_ptr() == 4 * n + pad
-    v0 = (master._version, grad._version, m._version)
-    master.fill_(1.0)
-    grad.add_(2.0)
-    grad.add_(2.0)
-    assert (master._version - v0[0], grad._version - v0[1], m._version - v0[2]) == (1, 2, 0), "no shared version counter between the streams"
-    assert float(arena[:4].view(torch.float32)[0]) == 1.0 and float(m.abs().sum()) == 0.0
-    out = P.place_streams(n, "cpu")
-    assert out[3] is None and out[4] is None and out[5]["placement"].startswith("separate allocations")
-    model = VLT5VQA(VLT5Config(d_model=64, d_kv=16, num_heads=4, d_ff=128, num_layers=1, num_decoder_layers=1, vocab_size=400, feat_dim=64),
-                    device=torch.device("cpu"))
-    assert model.placement_info["placement"].startswith("separate allocations") and model.lease_adam_state(object()) is None
-    opt = FusedAdamW(reference_param_groups(model, 0.01), model, lr=1e-3)
-    assert opt._m.numel() == model.flat_params().numel() and opt._m.data_ptr() != opt._v.data_ptr()

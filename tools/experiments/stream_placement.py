@@ -1,4 +1,6 @@
-"""Where the optimizer pass's five streams lie in HBM (round 6).
+"""EXPERIMENT, not product (vqacl_amd/placement.py of tools/experiments/stream_placement.patch; measured in round 6, no reliable gain: profiles/r06_i_*).
+
+Where the optimizer pass's five streams lie in HBM (round 6).
 
 The clip + AdamW pass (`csrc/optim.hip`; reference: transformers AdamW + clip_grad_norm_, trainer_base.py:130-198, vqacl.py:466-487) reads
 the f32 master, the gradient and both moments and writes the master, both moments and the bf16 shadow -- 30 B per parameter, eight

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""clip + AdamW of the real optimizer (nine launches over the model's runs) with the streams placed (vqacl_amd/placement.py) and as
+"""EXPERIMENT (needs tools/experiments/stream_placement.patch applied; measured in round 6 and not kept: profiles/r06_i_*).
+clip + AdamW of the real optimizer (nine launches over the model's runs) with the streams placed (vqacl_amd/placement.py) and as
 separate allocations, in one process on one box: the optimizer step alone (events around opt.step() after a real backward) and the
 whole train step.      python tools/placement_ab.py"""
 import os

@@ -202,8 +202,7 @@ class ContinualTrainer:
                 train_l, val_l, mem_l = train_loaders[group], val_loaders[group], memory_loaders[group]
                 n_mem = len(mem_l.dataset)
                 total = 2 * len(train_l.dataset) if n_mem > 0 else len(train_l.dataset)
-                self.optim = self.lr_scheduler = None      # (drop the previous group's optimizer first: the new one takes over the
-                self.optim = self.make_optimizer(self.model, self.lr)   # moment buffers the model placed beside its master, zeroed)
+                self.optim = self.make_optimizer(self.model, self.lr)
                 n_warm = warmup_iters(total, self.batch_size, self.epochs, self.warmup_ratio)
                 self.lr_scheduler = constant_schedule_with_warmup(self.optim, n_warm)
                 self.on_event("group", task=task, group=group, total_train_num=total, warmup_iters=n_warm)

@@ -181,21 +181,6 @@ class VLT5(nn.Module):
         self.proto = PrototypeHead(self.cfg.n_ques, self.cfg.n_cate, self.cfg.d_model, self._device)
         self.init_weights()
 
-    def lease_adam_state(self, optimizer):
-        """The two moment buffers that were placed together with master / gradient / shadow (zeroed), for ONE optimizer at a time -- the
-        reference builds a new optimizer per (task, category group) (vqacl.py:314-373) and drops the old one; a second LIVE optimizer on
-        the same model gets None and allocates its own moments."""
-        import weakref
-        if self._adam_m is None:
-            return None
-        holder = self._adam_lease() if self._adam_lease is not None else None
-        if holder is not None and holder is not optimizer:
-            return None
-        self._adam_lease = weakref.ref(optimizer)
-        self._adam_m.zero_()
-        self._adam_v.zero_()
-        return self._adam_m, self._adam_v
-
     # ------------------------------------------------------------------ construction ----------------
     @classmethod
     def from_pretrained(cls, name=None, config=None, **kw):
@@ -207,12 +192,9 @@ class VLT5(nn.Module):
         layout, total, nbuckets = param_layout(cfg)
         dev = self._device
         self._layout, self._total, self._nbuckets = layout, total, nbuckets
-        # master, gradient, bf16 shadow and -- on the GPU -- the optimizer's two moments in ONE arena, at the stride between the streams
-        # that the clip + AdamW pass measured fastest on this device (vqacl_amd/placement.py: the pass moves by 15-20 % with where its
-        # eight lock-stepped streams lie); separate allocations on the CPU, for small models and with VQACL_PLACEMENT=0
-        from .placement import place_streams
-        self._flat, self._flat_grad, self._flat_bf16, self._adam_m, self._adam_v, self.placement_info = place_streams(total, dev)
-        self._adam_lease = None              # weak reference to the FusedAdamW that uses _adam_m / _adam_v (one at a time)
+        self._flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self._flat_bf16 = torch.zeros(total, device=dev, dtype=torch.bfloat16)
+        self._flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
         self._flat_grad_tmp = None
         self._views, self._gviews, self._pinfo = {}, {}, {}
         for name, off, shape, bucket, decay, used in layout:

@@ -38,14 +38,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self.max_grad_norm = max_grad_norm
         self.hf_mode = int(hf_mode)
         flat = model.flat_params()
-        # the moments the model placed together with its master / gradient / shadow (vqacl_amd/placement.py), or -- CPU, small model, a
-        # second live optimizer on the same model -- allocations of their own
-        leased = model.lease_adam_state(self) if hasattr(model, "lease_adam_state") else None
-        if leased is not None and leased[0].numel() == flat.numel():
-            self._m, self._v = leased
-        else:
-            self._m = torch.zeros_like(flat)
-            self._v = torch.zeros_like(flat)
+        self._m = torch.zeros_like(flat)
+        self._v = torch.zeros_like(flat)
         self._t = 0
         dev = flat.device
         self._total_sq = torch.zeros(1, device=dev, dtype=torch.float32)
