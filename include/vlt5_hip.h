@@ -72,7 +72,8 @@ typedef struct {
     int gemm_split_cap;     /* > 0: largest automatic split-K factor of the small-output policy (default 4; 8 until round 5) */
     int decode_nfrag;       /* decode kernels: 1, 2 or 4 forces the column-tile width of the projections to 16 x this many columns; 16: the
                                round-4 geometry rule (widest tile that fills the chip) at every row count; 0: the launch geometry's own choice */
-    int reserved[1];
+    int ffn_gate_bits;      /* 1: the encoder's FFN hidden gradient gates by the saved bf16 activation (27.5 MB per layer at B = 80, read cold);
+                               2 / 0 (default): by the ReLU sign bits the forward projection leaves (vlt5_gemm_desc.relu_bits_out / gate_bits) */
 } vlt5_tuning;
 
 /* ---- GEMM: C[M,N] = epi(alpha * sum_k A[m,k] B[n,k]) -------------------------------------------
@@ -117,6 +118,11 @@ typedef struct vlt5_gemm_desc_s {
                                                 ceil(M/64)*ceil(N/64)); fixed reduction order -- the optimizer's gradient norm
                                                 without a second pass over the gradients (vlt5_gnorm_finish) */
     const vlt5_tuning* tuning;               /* optional experiment switches of the tile policy (NULL = defaults) */
+    /* ReLU sign bits instead of the saved activation (round 6): the backward of y = dropout(relu(x W^T)) gates dL/dh by h > 0 -- one BIT
+     * per element.  relu_bits_out (with relu, bf16 output, N % 8 == 0, no batch / split): the epilogue ALSO writes bit (n & 7) of byte
+     * relu_bits_out[m * ld_bits + n / 8] = (the stored bf16 value != 0).  gate_bits (instead of `gate`, same rules): v = bit ? v *
+     * gate_scale : 0 -- the hidden-gradient GEMM of an encoder FFN reads 1.7 MB of bits instead of 27.5 MB of cold activations. */
+    void* relu_bits_out; const void* gate_bits; int ld_bits;   /* ld_bits: bytes per row of the bit matrix, >= N / 8 */
 } vlt5_gemm_desc;
 int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream);     /* writes d->split_used */
 long long vlt5_gemm_workspace_bytes(int M, int ldc, int split_k);

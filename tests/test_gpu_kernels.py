@@ -179,6 +179,47 @@ def test_gemm_epilogues(dev, tile, M, N, K):
     close(out, base + 2.0, 2e-3, 2e-2, "accumulate")
 
 
+@pytest.mark.parametrize("tile,M,N,K", [((0, 0), 200, 192, 128), ((224, 256), 500, 520, 192), ((256, 256), 448, 512, 128), ((128, 64), 300, 264, 64),
+                                        ((64, 64), 37, 64, 256), ((0, 0), 4480, 3072, 768)])
+def test_gemm_relu_sign_bits(dev, tile, M, N, K):
+    """vlt5_gemm_desc.relu_bits_out / gate_bits (round 6): the forward FFN projection's ReLU (+ dropout) epilogue also leaves ONE BIT per
+    stored element (value != 0), and the hidden-gradient GEMM gates by those bits instead of the saved bf16 activation (HF
+    T5DenseReluDense backward: dh = (dy Wo) * 1[h > 0] * dropout scale) -- 1/16 of the bytes, the same predicate: outputs identical to
+    the activation-gated launch, bit for bit, for every tile shape."""
+    import numpy as np
+    from vqacl_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    A, B = rnd((M, K), g).to(BF).to(dev), rnd((N, K), g).to(BF).to(dev)
+    ldb = N // 8 + (8 if tile == (128, 64) else 0)                        # (a padded bit matrix too)
+    for dp in (0.0, 0.25):
+        bits = torch.full((M, ldb), 0xAA, device=dev, dtype=torch.uint8)
+        h = ops.gemm(A, B, M, N, K, relu=True, drop_p=dp, drop_seed=11, tile=tile, relu_bits_out=bits)
+        h_plain = ops.gemm(A, B, M, N, K, relu=True, drop_p=dp, drop_seed=11, tile=tile)
+        assert torch.equal(h.view(torch.int16), h_plain.view(torch.int16)), "the stored activation does not change"
+        want = np.packbits((h.float() != 0).cpu().numpy(), axis=1, bitorder="little")
+        got = bits.cpu().numpy()
+        assert np.array_equal(got[:, :N // 8], want), "bit (n & 7) of byte n / 8 = (h[m, n] != 0)"
+        assert (got[:, N // 8:] == 0xAA).all(), "bytes beyond N / 8 are not touched"
+        frac = float((h != 0).float().mean())
+        assert 0.2 < frac < 0.6
+        # the backward launch: dh = (dy W) gated -- by the activation, and by the bits
+        dy = rnd((M, 64), g).to(BF).to(dev)
+        W2 = rnd((64, N), g).to(BF).to(dev)                                # [K2 = 64, N]: k-major B, as the engine's input gradients read it
+        by_h = ops.gemm(dy, W2, M, N, 64, b_kmajor=True, gate=h, gate_scale=1.0 / 0.75, tile=tile)
+        by_bits = ops.gemm(dy, W2, M, N, 64, b_kmajor=True, gate_bits=bits, gate_scale=1.0 / 0.75, tile=tile)
+        assert torch.equal(by_h.view(torch.int16), by_bits.view(torch.int16)), "gating by the bits == gating by the activation"
+        assert float((by_bits != 0).float().mean()) < frac + 0.01
+    from vqacl_amd._lib import Vlt5Error
+    with pytest.raises(Vlt5Error):                                        # bits only beside the bf16 ReLU epilogue
+        ops.gemm(A, B, M, N, K, relu=True, out_f32=True, relu_bits_out=bits)
+    with pytest.raises(Vlt5Error):
+        ops.gemm(A, B, M, N, K, relu_bits_out=bits)
+    with pytest.raises(Vlt5Error):                                        # one gate at a time
+        ops.gemm(dy, W2, M, N, 64, b_kmajor=True, gate=h, gate_bits=bits)
+    with pytest.raises(Vlt5Error):
+        ops.gemm(dy, W2, M, N, 64, b_kmajor=True, gate_bits=bits[:, :N // 8 - 1].contiguous())
+
+
 def test_gemm_randomised_shapes_layouts_and_epilogues(dev):
     """80 seeded random problems: ragged M (any), N and K multiples of 8 (K tails below 64), every operand layout, every tile,
     padded leading dimensions, split-K, layer batches, and the epilogue combinations the engine issues -- against torch f32."""

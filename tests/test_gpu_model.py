@@ -678,6 +678,23 @@ def test_incremental_decoder_step_matches_full_decoder_logits(dev, fast, variant
     assert lib().vlt5_decoder_step(C.byref(c), C.byref(cs), ptr(tok), T, ptr(cache), ptr(logits), ptr(nxt), stream_ptr()) == 1001
 
 
+def test_relu_sign_bits_leave_every_gradient_bit_identical(dev):
+    """The encoder's FFN hidden gradient gates by ReLU sign bits (default, vlt5_tuning.ffn_gate_bits) or by the saved activation: the same
+    predicate, so loss and EVERY gradient of a base-model step with dropout on are bit-identical between the two."""
+    from oracle import ref_cpu as R
+    ocfg, params, batch = _base_case(dev, B=8, seed=99)
+    outs = []
+    for bits in (True, False):
+        model = set_tuning(make_model(ocfg, params, dev, dropout=0.1), dict(ffn_gate_bits=bits))
+        model.train()
+        res = model.train_step(batch, 0, 0.5, 0.3)
+        res["loss"].backward()
+        torch.cuda.synchronize()
+        outs.append((float(res["loss"].detach()), model.flat_grads().clone()))
+    assert outs[0][0] == outs[1][0] and float(outs[0][1].abs().sum()) > 0
+    assert torch.equal(outs[0][1], outs[1][1]), "gating by the sign bits must not move a single gradient bit"
+
+
 def test_backward_phases_refuse_a_release_plan_that_is_not_theirs(dev):
     """vlt5_step.release_plan_id (round 6): with gradient-bucket events the backward phases recompute the order they are about to complete the
     buckets in and return VLT5_ERR_PLAN -- before launching anything -- when the caller cut its waits by another one."""
@@ -1376,8 +1393,9 @@ def test_degenerate_rows_vs_oracle(dev):
                                     dict(dec_fused=True),                              # fused decoder attention sublayers (csrc/dec_attn.hip)
                                     dict(fused_attn=False),                            # encoder q|k|v GEMM + attention core as two launches
                                     dict(fused_heads=1),                               # one head per workgroup in the fused encoder kernel
-                                    dict(wgrad_shadow=False, wgrad_grouped=False, enc_cut=3)],
-                         ids=["unfolded", "fold-dec", "dec-fused", "unfused-attn", "one-head", "plain-wgrads"])
+                                    dict(wgrad_shadow=False, wgrad_grouped=False, enc_cut=3),
+                                    dict(ffn_gate_bits=False)],                        # the FFN hidden gradient gated by the saved activation
+                         ids=["unfolded", "fold-dec", "dec-fused", "unfused-attn", "one-head", "plain-wgrads", "gate-by-activation"])
 def test_alternative_engine_paths_still_match_the_oracle(dev, tuning):
     """The engine folds the encoder's T5 RMS norms around their GEMMs, fuses the encoder's projection + attention core and groups
     weight-gradient launches by default; the other paths stay in the library as options of a vlt5_tuning record (vlt5_step.tuning) --

@@ -23,7 +23,7 @@ class Tuning(C.Structure):
     _fields_ = [("fold_norm", c_i), ("fold_norm_dec", c_i), ("fused_attn", c_i), ("fused_heads", c_i), ("dec_fused", c_i),
                 ("enc_cut", c_i), ("wgrad_shadow", c_i), ("wgrad_grouped", c_i), ("gemm_t128_kmkm", c_i), ("gemm_t256_km", c_i),
                 ("gemm_t256_min", c_i), ("gemm_dec_tall", c_i), ("gemm_split_kmin", c_i), ("decode_fast", c_i), ("decode_split_norm", c_i),
-                ("gemm_rmkm_tile", c_i), ("gemm_rmrm_f32_tile", c_i), ("gemm_split_cap", c_i), ("decode_nfrag", c_i), ("reserved", c_i * 1)]
+                ("gemm_rmkm_tile", c_i), ("gemm_rmrm_f32_tile", c_i), ("gemm_split_cap", c_i), ("decode_nfrag", c_i), ("ffn_gate_bits", c_i)]
 
 
 # environment variable -> (field, how its value maps): the library itself reads no environment; the host reads these ONCE per model
@@ -35,7 +35,8 @@ _TUNING_ENV = {"VLT5_FOLD_NORM": ("fold_norm", "onoff"), "VLT5_FOLD_NORM_DEC": (
                "VLT5_GEMM_T256_MIN": ("gemm_t256_min", "int"), "VLT5_GEMM_DEC_TALL": ("gemm_dec_tall", "onoff"),
                "VLT5_GEMM_SPLIT_KMIN": ("gemm_split_kmin", "int"), "VLT5_DECODE_FAST": ("decode_fast", "onoff"),
                "VLT5_DECODE_SPLIT_NORM": ("decode_split_norm", "onoff"), "VLT5_GEMM_RMKM_TILE": ("gemm_rmkm_tile", "int"),
-               "VLT5_GEMM_RMRM_F32_TILE": ("gemm_rmrm_f32_tile", "int"), "VLT5_GEMM_SPLIT_CAP": ("gemm_split_cap", "int"), "VLT5_DECODE_NFRAG": ("decode_nfrag", "int")}
+               "VLT5_GEMM_RMRM_F32_TILE": ("gemm_rmrm_f32_tile", "int"), "VLT5_GEMM_SPLIT_CAP": ("gemm_split_cap", "int"), "VLT5_DECODE_NFRAG": ("decode_nfrag", "int"),
+               "VLT5_FFN_GATE_BITS": ("ffn_gate_bits", "onoff")}
 
 
 def make_tuning(**fields):
@@ -69,7 +70,8 @@ class GemmDesc(C.Structure):
                 ("batch_stride_c", c_ll), ("defer_reduce", c_i), ("split_used", c_i), ("c_bf16_copy", vp),
                 ("grouped_with", vp), ("emit_norm_w", vp), ("emit_xw_bf16", vp), ("emit_partials", vp), ("emit_nparts", c_i),
                 ("norm_partials", vp), ("norm_nparts", c_i), ("norm_d", c_i), ("norm_eps", c_f), ("norm_rstd_out", vp),
-                ("sumsq", vp), ("sumsq_batch_stride", c_ll), ("tuning", C.POINTER(Tuning))]
+                ("sumsq", vp), ("sumsq_batch_stride", c_ll), ("tuning", C.POINTER(Tuning)),
+                ("relu_bits_out", vp), ("gate_bits", vp), ("ld_bits", c_i)]
 
 
 class AttnDesc(C.Structure):

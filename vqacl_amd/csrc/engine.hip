@@ -133,6 +133,7 @@ struct Plan {
     size_t enc_out, enc_ext, mask_ext;
     size_t dec_ids, dec_bias, kv_all;
     size_t y[3 * MAXL + 1], yr[3 * MAXL + 1];
+    size_t hbits[MAXL];                    // ReLU sign bits of the encoder's FFN activations ([M][ff/8] bytes; vlt5_gemm_desc.relu_bits_out)
     size_t yn_a[MAXL], dqkv_s[MAXL], lse_s[MAXL], ctx_s[MAXL], yn_c[MAXL], qc[MAXL], lse_c[MAXL], ctx_c[MAXL], yn_f[MAXL], hd[MAXL], ud[MAXL];
     size_t dec_out, logits, lse_ce, loss_tok, row_w, loss;
     size_t ssq_e[2 * MAXL + 1], ssq_d[3 * MAXL + 1];      // per-norm partial sums of squares of the residual stream (norm folded around its GEMMs)
@@ -165,6 +166,7 @@ void make_plan(const vlt5_config& c, int B, int L, int V, int T, Plan& p) {
     for (int l = 0; l < Le; ++l) {
         p.xn_a[l] = take(M * d * 2); p.qkv[l] = take(M * 3 * inner * 2); p.lse[l] = take((size_t)B * H * p.S * 4);
         p.ctx[l] = take(M * inner * 2); p.xn_f[l] = take(M * d * 2); p.h[l] = take(M * ff * 2);
+        p.hbits[l] = (!c.gated_act && (ff & 7) == 0) ? take(M * (ff / 8)) : 0;
         p.u[l] = c.gated_act ? take(M * ffw * 2) : 0;
     }
     for (int i = 0; i <= 2 * Le; ++i) p.ssq_e[i] = take(M * 32 * 4);
@@ -290,7 +292,7 @@ struct Ctx {
     // y[M,N] = epi(alpha * x[M,K] W[N,K]^T)
     int lin_fwd(const bf16_t* X, const bf16_t* W, void* C, int M, int N, int K, int out_f32, float alpha = 1.f,
                 const float* bias = nullptr, int relu = 0, float dp = 0.f, uint32_t dseed = 0, const float* resid = nullptr,
-                NormIn nin = NormIn()) const {
+                NormIn nin = NormIn(), void* bits_out = nullptr) const {
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);
         g.tuning = &tun;
@@ -298,6 +300,7 @@ struct Ctx {
         g.alpha = alpha; g.bias = bias; g.relu = relu; g.drop_p = dp; g.drop_seed = dseed; g.resid = resid; g.ldr = N;
         g.out_f32 = out_f32;
         if (nin.part) { g.norm_partials = nin.part; g.norm_nparts = nin.n; g.norm_d = K; g.norm_eps = c.eps; g.norm_rstd_out = nin.rstd_out; }
+        if (bits_out) { g.relu_bits_out = bits_out; g.ld_bits = N / 8; }
         return vlt5_gemm_bf16(&g, st);
     }
     // y = resid + dropout(x W^T), and for the norm that consumes y next: bf16(y * w_norm) -> xw, partial sums of squares -> ssq;
@@ -326,12 +329,17 @@ struct Ctx {
     // +0.13 ms per step against -0.17 ms of norm launches saved ... and +0.13 ms of slower 84-tile GEMMs: a net loss, off by default)
     bool fold_dec() const { return tun.fold_norm_dec == 2 && fold_on(); }
     bool fold_enc_first(int l) const { return fold_on() && l > 0 && pick_split(p.M, d, ff) <= 1; }     // the norm in front of layer l's attention
+    // the encoder's FFN hidden gradient gates by ReLU sign bits (1.7 MB per layer at B = 80) instead of the saved bf16 activation (27.5 MB,
+    // read cold): same predicate, bit-identical gradients; vlt5_tuning.ffn_gate_bits = 1 keeps the activation as the gate
+    bool bits_on() const { return tun.ffn_gate_bits != 1 && !c.gated_act && (ff & 7) == 0; }
     int pick_split(int M, int N, int Kred) const { return vlt5_gemm_auto_split_tuned(M, N, Kred, (long long)p.slab_bytes, &tun); }
     int ffw() const { return c.gated_act ? 2 * ff : ff; }
     // hidden activation of an FFN: h = dropout(act(xn Wi^T)).  ReLU: one GEMM with the activation in its epilogue.  Gated GELU (HF
     // T5DenseGatedActDense): u = xn [wi_0; wi_1]^T kept for the backward, then h = dropout(gelu_new(u0) * u1)
-    int ffn_hidden(const bf16_t* xn, long long wi, bf16_t* u, bf16_t* h, int M, float dp, uint32_t dseed, NormIn nin = NormIn()) const {
-        if (!c.gated_act) return lin_fwd(xn, Pb + wi, h, M, ff, d, 0, 1.f, nullptr, 1, dp, dseed, nullptr, nin);
+    // bits (optional): the ReLU sign bits of h for the backward's gate (see bits_on())
+    int ffn_hidden(const bf16_t* xn, long long wi, bf16_t* u, bf16_t* h, int M, float dp, uint32_t dseed, NormIn nin = NormIn(),
+                   void* bits = nullptr) const {
+        if (!c.gated_act) return lin_fwd(xn, Pb + wi, h, M, ff, d, 0, 1.f, nullptr, 1, dp, dseed, nullptr, nin, bits);
         int rc = lin_fwd(xn, Pb + wi, u, M, 2 * ff, d, 0, 1.f, nullptr, 0, 0.f, 0, nullptr, nin);
         if (rc) return rc;
         return vlt5_glu_fwd(u, h, M, ff, dp, dseed, st);
@@ -366,13 +374,14 @@ struct Ctx {
     // `slabs` (optional): the consumer is a LayerNorm backward that can sum split-K slabs itself -- on return *slabs = number of
     // slabs left in the slab scratch (1: dX was written as usual)
     int lin_dgrad(const bf16_t* dY, const bf16_t* W, void* dX, int M, int N, int K, int out_f32, float alpha = 1.f,
-                  const bf16_t* gate = nullptr, float gate_scale = 1.f, int* slabs = nullptr) const {
+                  const bf16_t* gate = nullptr, float gate_scale = 1.f, int* slabs = nullptr, const void* gate_bits = nullptr) const {
         vlt5_gemm_desc g;
         memset(&g, 0, sizeof g);
         g.tuning = &tun;
         g.A = dY; g.B = W; g.C = dX; g.M = M; g.N = K; g.K = N; g.lda = N; g.ldb = K; g.ldc = K; g.b_kmajor = 1;
         g.alpha = alpha; g.gate = gate; g.ldg = K; g.gate_scale = gate_scale; g.out_f32 = out_f32;
-        if (out_f32 && !gate) {
+        if (gate_bits) { g.gate = nullptr; g.gate_bits = gate_bits; g.ld_bits = K / 8; }
+        if (out_f32 && !gate && !gate_bits) {
             int sk = pick_split(M, K, N);
             if (sk > 1) { g.split_k = sk; g.workspace = w<void>(p.slab); g.defer_reduce = slabs ? 1 : 0; }
         }
@@ -606,7 +615,8 @@ int encoder_fwd(const Ctx& k) {
             RC(k.lin_fwd(k.w<bf16_t>(p.ctx[l]), k.Pb + E.so, xf, M, d, inner, 1, 1.f, nullptr, 0, k.pdrop, k.seed(sb + E_ATTN_OUT), xa));
             RC(vlt5_layernorm_fwd(xf, k.P + E.ln_f, k.w<void>(p.xn_f[l]), nullptr, k.w<float>(p.xr[2 * l + 1]), M, d, c.eps, 0.f, 0, 0, 0, k.st));
         }
-        RC(k.ffn_hidden(k.w<bf16_t>(p.xn_f[l]), E.wi, k.w<bf16_t>(p.u[l]), k.w<bf16_t>(p.h[l]), M, k.pdrop, k.seed(sb + E_FFN_H), nin_f));
+        RC(k.ffn_hidden(k.w<bf16_t>(p.xn_f[l]), E.wi, k.w<bf16_t>(p.u[l]), k.w<bf16_t>(p.h[l]), M, k.pdrop, k.seed(sb + E_FFN_H), nin_f,
+                        k.bits_on() ? k.w<void>(p.hbits[l]) : nullptr));
         np_a = 0;
         if (l + 1 < c.num_layers && k.fold_enc_first(l + 1)) {
             pending = 0;
@@ -946,7 +956,7 @@ int decoder_step_fast(const Ctx& k, const vlt5_greedy_desc& g, bool chained) {
 // kept for the batched weight-gradient GEMMs at the end of the phase.  `next_dst` receives the operand of the next sublayer.
 int ffn_bwd(const Ctx& k, int M, float* dx, const float* x_in, const float* rstd, const bf16_t* h, const bf16_t* u, uint32_t h_seed,
             const bf16_t* dyd, bf16_t* dh, long long wi, long long wo, long long ln, bf16_t* next_dst, uint32_t next_seed,
-            bf16_t* xn_out = nullptr) {
+            bf16_t* xn_out = nullptr, const void* hbits = nullptr) {
     const Plan& p = k.p;
     const int d = k.d, ff = k.ff;
     float* tmp = k.w<float>(p.tmp);
@@ -957,7 +967,7 @@ int ffn_bwd(const Ctx& k, int M, float* dx, const float* x_in, const float* rstd
         RC(vlt5_glu_bwd(dhid, u, dh, M, ff, k.pdrop, h_seed, k.st));
     } else {
         const float gs = k.pdrop > 0.f ? drop_scale(drop_thr16(k.pdrop)) : 1.f;
-        RC(k.lin_dgrad(dyd, k.Pb + wo, dh, M, d, ff, 0, 1.f, h, gs));
+        RC(k.lin_dgrad(dyd, k.Pb + wo, dh, M, d, ff, 0, 1.f, h, gs, nullptr, hbits));
     }
     int ns = 1;
     RC(k.lin_dgrad(dh, k.Pb + wi, tmp, M, k.ffw(), d, 1, 1.f, nullptr, 1.f, &ns));
@@ -1140,7 +1150,7 @@ int encoder_bwd(const Ctx& k) {
         bf16_t* dqkv = k.w<bf16_t>(p.e_dqkv[l]);
         RC(ffn_bwd(k, M, dx, k.w<float>(p.x[2 * l + 1]), k.w<float>(p.xr[2 * l + 1]), k.w<bf16_t>(p.h[l]), k.w<bf16_t>(p.u[l]),
                    k.seed(sb + E_FFN_H), k.w<bf16_t>(p.e_dyd_f[l]), k.w<bf16_t>(p.e_dh[l]), E.wi, E.wo, E.ln_f, dyd_a, k.seed(sb + E_ATTN_OUT),
-                   k.fold_on() ? k.w<bf16_t>(p.xn_f[l]) : nullptr));
+                   k.fold_on() ? k.w<bf16_t>(p.xn_f[l]) : nullptr, k.bits_on() ? k.w<void>(p.hbits[l]) : nullptr));
         RC(k.lin_dgrad(dyd_a, k.Pb + E.so, dctx, M, d, inner, 0));
         RC(attn_call(k, true, qkv, (long long)S * 3 * inner, 3 * inner, qkv + inner, qkv + 2 * inner, (long long)S * 3 * inner,
                      3 * inner, nullptr, k.w<float>(p.lse[l]), k.w<float>(p.enc_bias), s.L, s.L, k.w<float>(p.mask), -10000.f, 0, S, S,

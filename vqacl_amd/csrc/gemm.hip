@@ -37,6 +37,11 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
     a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
     a.alpha = d->alpha; a.bias = d->bias; a.resid = d->resid; a.ldr = d->ldr;
     a.gate = (const bf16_t*)d->gate; a.ldg = d->ldg; a.gate_scale = d->gate_scale;
+    if (d->gate_bits || d->relu_bits_out) {        // ReLU sign bits: whole bytes per row, single un-split launches with the dedicated epilogues
+        if ((d->N & 7) || d->ld_bits < d->N / 8 || d->batch > 1 || d->split_k > 1 || d->grouped_with) return VLT5_ERR_ARG;
+        if (d->gate_bits && (d->gate || d->resid || d->accum || d->bias || d->relu || d->drop_p > 0.f || d->out_f32)) return VLT5_ERR_ARG;
+        if (d->relu_bits_out && (!d->relu || d->out_f32 || d->bias || d->gate || d->gate_bits || d->resid || d->accum)) return VLT5_ERR_ARG;
+    }
     a.drop_thr = d->drop_p > 0.f ? drop_thr16(d->drop_p) : 0u; a.drop_seed = d->drop_seed;
     a.relu = d->relu; a.out_f32 = d->out_f32; a.accum = d->accum;
     a.ktiles_per_split = 0; a.c_split_stride = 0;
@@ -71,6 +76,10 @@ extern "C" int vlt5_gemm_bf16(vlt5_gemm_desc* d, void* stream) {
         if ((((uintptr_t)d->emit_xw_bf16) & 15) || (((uintptr_t)d->emit_norm_w) & 15) || (d->ldc & 7)) return VLT5_ERR_ALIGN;
         a.emit_w = d->emit_norm_w; a.emit_xw = (bf16_t*)d->emit_xw_bf16; a.emit_ssq = d->emit_partials;
     }
+    // ReLU sign bits ride in fields their epilogues do not use otherwise (GemmArgs): the gate as a bit matrix = gate pointer with a
+    // NEGATIVE leading dimension; the bit matrix a ReLU bf16 epilogue writes = emit_xw with its bytes per row in ldr
+    if (d->gate_bits) { a.gate = (const bf16_t*)d->gate_bits; a.ldg = -d->ld_bits; }
+    if (d->relu_bits_out) { a.emit_xw = (bf16_t*)d->relu_bits_out; a.ldr = d->ld_bits; }
     a.grp_tiles = 0; a.gA = nullptr;
     const vlt5_gemm_desc* g2 = d->grouped_with;
     if (g2) {

@@ -56,6 +56,9 @@ struct GemmArgs {
     const float* bias;
     const float* resid; int ldr;
     const bf16_t* gate; int ldg; float gate_scale;
+    // (ReLU sign bits, vlt5_gemm_desc.gate_bits / relu_bits_out, travel in existing fields so that the argument block -- and with it the
+    //  8-wave instantiations' register budget -- does not grow: ldg < 0: `gate` points at the bit matrix, -ldg bytes per row; a ReLU bf16
+    //  epilogue with emit_xw != null: emit_xw is the bit matrix to write, ldr bytes per row)
     uint32_t drop_thr, drop_seed;
     int relu, out_f32, accum;
     int ktiles_per_split; long long c_split_stride;
@@ -598,7 +601,13 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
             asm volatile("global_load_dword %0, %1, off" : "=v"(touch_sink) : "v"(a));
         }
 #if GEMM_TOUCH_B >= 2
-        if (p.gate) {                              // the saved activation the epilogue gates by: as cold as the weights, 6x their size
+        if (p.gate && p.ldg < 0) {                 // ReLU sign bits: 1/16 of the bytes, one line per lane covers them
+            const long long ng = ((long long)p.M * (-p.ldg) + 127) >> 7;
+            if (i < ng) {
+                const char* a = reinterpret_cast<const char*>(p.gate) + (size_t)i * 128;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(touch_sink2) : "v"(a));
+            }
+        } else if (p.gate) {                       // the saved activation the epilogue gates by: as cold as the weights, 6x their size
             const int lprg = p.N >> 6;
             const long long ng = (long long)p.M * lprg;
             if (i < ng) {
@@ -860,6 +869,21 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
     auto store_pair_bf16 = [&](int m, int j, const float (&v)[4], const float (&w)[4]) __attribute__((always_inline)) {
         store_pair_bf16_to(reinterpret_cast<bf16_t*>(Cbase), m, j, v, w);
     };
+    // ... and the sign bits of the eight values the lane stores (GemmArgs.bits_out): after the swap a lane owns 8 consecutive columns
+    // starting at a multiple of 8 = exactly one byte of the [M][N/8] bit matrix
+    auto store_pair_bf16_bits = [&](int m, int j, const float (&v)[4], const float (&w)[4]) __attribute__((always_inline)) {
+        const uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
+        const uint32_t q0 = pack_bf16x2(w[0], w[1]), q1 = pack_bf16x2(w[2], w[3]);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(p0, q0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(p1, q1, false, false);
+        const int n = n0 + wn * TN + (j + (lg & 1)) * 16 + (lg >> 1) * 8;
+        if (m < p.M && n < p.N) {
+            const uint32_t w0 = s0[0], w1 = s1[0], w2 = s0[1], w3 = s1[1];
+            st16(reinterpret_cast<bf16_t*>(Cbase) + (size_t)m * p.ldc + n, make_uint4(w0, w1, w2, w3));
+            auto nz = [](uint32_t x) { return ((x & 0x7fffu) ? 1u : 0u) | ((x & 0x7fff0000u) ? 2u : 0u); };
+            reinterpret_cast<uint8_t*>(p.emit_xw)[(size_t)m * p.ldr + (n >> 3)] = (uint8_t)(nz(w0) | (nz(w1) << 2) | (nz(w2) << 4) | (nz(w3) << 6));
+        }
+    };
     if (!p.bias && !p.relu && !p.gate && !p.drop_thr && !aux_f32) {
         // plain epilogue (QKV / cross-K/V / lm_head projections, every dgrad without gate, every weight gradient): straight-line
         // scale + pack + store; keeps ~100 option-testing instructions per fragment off the tail of ~70 % of the launches
@@ -965,6 +989,8 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                                     float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Cbase) + (size_t)m * p.ldc + n);
                                     t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
                                 }
+                            } else if (p.ldg < 0) {          // (kernel-uniform) one byte of sign bits: this lane's four are nibble lg & 1
+                                t.x = __uint_as_float((uint32_t)reinterpret_cast<const uint8_t*>(p.gate)[(size_t)m * (size_t)(-p.ldg) + (n >> 3)]);
                             } else {
                                 uint2 g2 = *reinterpret_cast<const uint2*>(p.gate + (size_t)m * p.ldg + n);
                                 t.x = __uint_as_float(g2.x); t.y = __uint_as_float(g2.y);
@@ -1000,11 +1026,17 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                     }
                 }
                 if constexpr (kGate) {
-                    uint32_t gw[2] = {__float_as_uint(aux[ii][j].x), __float_as_uint(aux[ii][j].y)};
+                    if (p.ldg < 0) {
+                        const uint32_t nib = __float_as_uint(aux[ii][j].x) >> ((lg & 1) * 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        bf16_t h = (bf16_t)((gw[r >> 1] >> ((r & 1) * 16)) & 0xffffu);
-                        v[r] = (bf16_to_f32(h) > 0.f) ? v[r] * p.gate_scale : 0.f;
+                        for (int r = 0; r < 4; ++r) v[r] = ((nib >> r) & 1u) ? v[r] * p.gate_scale : 0.f;
+                    } else {
+                        uint32_t gw[2] = {__float_as_uint(aux[ii][j].x), __float_as_uint(aux[ii][j].y)};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            bf16_t h = (bf16_t)((gw[r >> 1] >> ((r & 1) * 16)) & 0xffffu);
+                            v[r] = (bf16_to_f32(h) > 0.f) ? v[r] * p.gate_scale : 0.f;
+                        }
                     }
                 }
                 if constexpr (kDrop) {
@@ -1067,6 +1099,9 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                         float v[4], w[4];
                         finish(ii, j, m, v);
                         finish(ii, j + 1, m, w);
+                        if constexpr (kRelu && !kGen) {
+                            if (p.emit_xw) { store_pair_bf16_bits(m, j, v, w); continue; }      // (kernel-uniform: the bit matrix)
+                        }
                         store_pair_bf16(m, j, v, w);
                     }
                 }

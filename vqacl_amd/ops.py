@@ -23,7 +23,8 @@ def _need(t, dtype=None):
 
 def gemm(A, B, M, N, K, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, alpha=1.0, bias=None, relu=False,
          resid=None, gate=None, gate_scale=1.0, drop_p=0.0, drop_seed=0, accum=False, split_k=1, tile=(0, 0),
-         lda=None, ldb=None, ldc=None, batch=1, batch_strides=(0, 0, 0), emit=None, norm=None, tuning=None):
+         lda=None, ldb=None, ldc=None, batch=1, batch_strides=(0, 0, 0), emit=None, norm=None, tuning=None, relu_bits_out=None,
+         gate_bits=None):
     """C[M,N] = epi(alpha * sum_k A[m,k] B[n,k]); A,B bf16 2-D tensors, k-major flags as in vlt5_gemm_desc.
     tuning: a vlt5_tuning record (_lib.make_tuning) for the launch's policy switches.
     emit = (w_norm f32 [N], xw bf16 [M,N], partials f32 [M,32]): producer side of a folded T5 RMS norm -- returns (out, nparts);
@@ -38,6 +39,10 @@ def gemm(A, B, M, N, K, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=Fal
         g.norm_partials, g.norm_nparts, g.norm_d, g.norm_eps, g.norm_rstd_out = ptr(norm[0]), norm[1], norm[2], norm[3], ptr(norm[4])
     if tuning is not None:
         g.tuning = C.pointer(tuning)
+    if relu_bits_out is not None:          # uint8 [M, >= N/8]: the ReLU sign bits of the stored values (vlt5_gemm_desc.relu_bits_out)
+        g.relu_bits_out, g.ld_bits = ptr(relu_bits_out), relu_bits_out.stride(0)
+    if gate_bits is not None:              # ... and the same bits as the gate of a hidden-gradient GEMM, instead of `gate`
+        g.gate_bits, g.ld_bits = ptr(gate_bits), gate_bits.stride(0)
     check(lib().vlt5_gemm_bf16(C.byref(g), stream_ptr()), "vlt5_gemm_bf16")
     if emit is not None:
         return out, g.emit_nparts
