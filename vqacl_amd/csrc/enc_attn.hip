@@ -162,10 +162,10 @@ __device__ __forceinline__ void qkv_attn_fwd_body(QkvAttnArgs p, unsigned long l
     {
         const int lpr = p.d >> 6;
         const long long nlines = 3LL * inner * lpr, i = (long long)blockIdx.x * FNT + tid;
-        if (i < nlines) {
-            const bf16_t* a = p.wqkv + (size_t)(i / lpr) * p.d + (size_t)(i % lpr) * 64;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(touch_sink) : "v"(a));
-        }
+        // (unconditional -- lanes without a line of their own re-request the first: no control-flow merge, no copy of the register the
+        //  load has not landed in yet; gemm_kernel.h)
+        const bf16_t* a = i < nlines ? p.wqkv + (size_t)(i / lpr) * p.d + (size_t)(i % lpr) * 64 : p.wqkv;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(touch_sink) : "v"(a));
     }
 #pragma unroll
     for (int pc = 0; pc < LPT; ++pc) piece(0, 0, pc);

@@ -588,37 +588,35 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
 #ifndef GEMM_TOUCH_B
 #define GEMM_TOUCH_B 2
 #endif
-    unsigned touch_sink2 = 0, touch_sink3 = 0;
-    unsigned touch_sink = 0;                        // destination of the asynchronous touch load: must stay allocated until it has landed
+    // The request is a 4-byte LDS-DMA load into a scratch word of LDS behind the stages (one word per lane: launch_one reserves NT * 4
+    // bytes) -- NOT a load into a register: a register destination is written asynchronously, long after the asm statement, and the
+    // compiler, which does not know that, is free to copy the "value" and hand the register to somebody else.  Rounds 2-5 kept such a
+    // register "allocated" by using it at the end of the kernel; in round 6 a second request site made the compiler merge two of them
+    // through a copy (and, in the instantiations that spill, spill one), and the late write clobbered an address register: a memory
+    // fault.  An LDS destination nobody reads has no such hazard.  Issued as assembly (invisible to the compiler's wait-count pass:
+    // the builtin form could make it wait for the request in front of the first fragment read); the main loop's counted waits cover
+    // it -- it is the oldest request in the queue.  tools/check_touch_isa.py scans for register-destination requests that remain.
     if constexpr (GEMM_TOUCH_B && !AKM) {
         const int rows_b = BKM ? p.K : p.N, lpr = (BKM ? p.N : p.K) >> 6;          // 64 bf16 = 128 bytes per line
         const long long nlines = (long long)rows_b * lpr;
         const long long nthreads = (long long)gridDim.x * gridDim.y * NT;
         const long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * NT + tid;
-        (void)nthreads;
-        if (blockIdx.z == 0 && i < nlines) {       // one line per lane (a panel larger than that is only partly requested)
-            const bf16_t* a = p.B + (size_t)(i / lpr) * p.ldb + (size_t)(i % lpr) * 64;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(touch_sink) : "v"(a));
-        }
+        char* const tdst = smem + NSTAGE * STAGE_BYTES + (tid & ~63) * 4;
+        auto touch = [&](const void* src) __attribute__((always_inline)) {
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)tdst);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(src) : "memory");
+        };
+        if (blockIdx.z == 0 && i < nlines)         // one line of the weight panel per lane (a panel larger than that is only partly requested)
+            touch(p.B + (size_t)(i / lpr) * p.ldb + (size_t)(i % lpr) * 64);
 #if GEMM_TOUCH_B >= 2
-        if (p.gate && p.ldg < 0) {                 // ReLU sign bits: 1/16 of the bytes, one line per lane covers them
+        if (p.gate && p.ldg < 0) {                 // ReLU sign bits ([M][-ldg] bytes): 1/16 of the activation's bytes, one line per lane covers them
             const long long ng = ((long long)p.M * (-p.ldg) + 127) >> 7;
-            if (i < ng) {
-                const char* a = reinterpret_cast<const char*>(p.gate) + (size_t)i * 128;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(touch_sink2) : "v"(a));
-            }
-        } else if (p.gate) {                       // the saved activation the epilogue gates by: as cold as the weights, 6x their size
+            if (i < ng) touch(reinterpret_cast<const char*>(p.gate) + (size_t)i * 128);
+        } else if (p.gate) {                       // the saved bf16 activation the epilogue gates by: as cold as the weights, 6x their size
             const int lprg = p.N >> 6;
-            const long long ng = (long long)p.M * lprg;
-            if (i < ng) {
-                const bf16_t* a = p.gate + (size_t)(i / lprg) * p.ldg + (size_t)(i % lprg) * 64;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(touch_sink2) : "v"(a));
-            }
-            if (i + nthreads < ng) {
-                const long long i2 = i + nthreads;
-                const bf16_t* a = p.gate + (size_t)(i2 / lprg) * p.ldg + (size_t)(i2 % lprg) * 64;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(touch_sink3) : "v"(a));
-            }
+            const long long ng = (long long)p.M * lprg, i2 = i + nthreads;
+            if (i < ng) touch(p.gate + (size_t)(i / lprg) * p.ldg + (size_t)(i % lprg) * 64);
+            if (i2 < ng) touch(p.gate + (size_t)(i2 / lprg) * p.ldg + (size_t)(i2 % lprg) * 64);
         }
 #endif
     }
@@ -832,7 +830,6 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
         compute(stage);
     }
 
-    if constexpr (GEMM_TOUCH_B && !AKM) asm volatile("" ::"v"(touch_sink), "v"(touch_sink2), "v"(touch_sink3));     // (alive through the main loop; its waits have covered the load)
     TL(3);
     // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4 -----------
     // Two phases.  (1) ALL auxiliary operands of the wave's tile (residual / C-for-accumulate, or the gate, and the bias) are
@@ -1170,7 +1167,7 @@ namespace vlt5gemm {
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
 int launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
     constexpr int NT_ = WM * WN * 64;
-    constexpr size_t lds = (size_t)NS * ((BM * 8 + NT_ - 1) / NT_ + (BN * 8 + NT_ - 1) / NT_) * NT_ * 16 + (GEMM_L2PF ? NT_ * 4 : 0);
+    constexpr size_t lds = (size_t)NS * ((BM * 8 + NT_ - 1) / NT_ + (BN * 8 + NT_ - 1) / NT_) * NT_ * 16 + NT_ * 4;     // + one scratch word per lane: the destination of the panel-touch requests (and of GEMM_L2PF's)
     static std::atomic<unsigned long long> optin{0};        // > 64 KB of dynamic LDS needs an explicit opt-in, per kernel and device
     if (int rc = vlt5_lds_optin(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WM, WN, AKM, BKM, NS>), (int)lds, optin)) return rc;
 #ifdef GEMM_TIMELINE
