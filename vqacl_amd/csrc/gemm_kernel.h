@@ -986,8 +986,26 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                                     float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Cbase) + (size_t)m * p.ldc + n);
                                     t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
                                 }
-                            } else if (p.ldg < 0) {          // (kernel-uniform) one byte of sign bits: this lane's four are nibble lg & 1
-                                t.x = __uint_as_float((uint32_t)reinterpret_cast<const uint8_t*>(p.gate)[(size_t)m * (size_t)(-p.ldg) + (n >> 3)]);
+                            } else if (p.ldg < 0) {          // (kernel-uniform) sign bits: the wave tile's TN bits of row m in ONE load per row
+                                if (j == 0) {                    // block (fragment 0 carries them): a quarter of the per-fragment requests
+                                    const uint8_t* q = reinterpret_cast<const uint8_t*>(p.gate) + (size_t)m * (size_t)(-p.ldg) + ((n0 + wn * TN) >> 3);
+                                    if constexpr (TN == 64) {
+                                        if (n0 + wn * TN + 64 <= p.N) {
+                                            const uint2 b2 = *reinterpret_cast<const uint2*>(q);
+                                            t.x = __uint_as_float(b2.x); t.y = __uint_as_float(b2.y);
+                                        } else {                 // (a ragged last column tile: byte by byte, zero beyond N)
+                                            uint32_t lo = 0, hi = 0;
+                                            for (int b = 0; b < 8; ++b)
+                                                if (n0 + wn * TN + b * 8 < p.N) { if (b < 4) lo |= (uint32_t)q[b] << (8 * b); else hi |= (uint32_t)q[b] << (8 * (b - 4)); }
+                                            t.x = __uint_as_float(lo); t.y = __uint_as_float(hi);
+                                        }
+                                    } else {
+                                        uint32_t lo = 0;
+                                        for (int b = 0; b < TN / 8; ++b)
+                                            if (n0 + wn * TN + b * 8 < p.N) lo |= (uint32_t)q[b] << (8 * b);
+                                        t.x = __uint_as_float(lo);
+                                    }
+                                }
                             } else {
                                 uint2 g2 = *reinterpret_cast<const uint2*>(p.gate + (size_t)m * p.ldg + n);
                                 t.x = __uint_as_float(g2.x); t.y = __uint_as_float(g2.y);
@@ -1024,7 +1042,9 @@ __device__ __forceinline__ void gemm_body(GemmArgs p) {
                 }
                 if constexpr (kGate) {
                     if (p.ldg < 0) {
-                        const uint32_t nib = __float_as_uint(aux[ii][j].x) >> ((lg & 1) * 4);
+                        // byte j*2 + (lg >> 1) of the row block's bits (fragment 0's aux), nibble lg & 1
+                        const uint32_t word = __float_as_uint((j * 2 >= 4) ? aux[ii][0].y : aux[ii][0].x);
+                        const uint32_t nib = word >> ((((j * 2) & 3) + (lg >> 1)) * 8 + (lg & 1) * 4);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = ((nib >> r) & 1u) ? v[r] * p.gate_scale : 0.f;
                     } else {
