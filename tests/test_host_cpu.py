@@ -305,3 +305,15 @@ def test_moment_accumulator_of_the_dropout_comparison():
     assert torch.allclose(m.half[0]["a"], st[0::2].sum(0), atol=1e-12) and torch.allclose(m.half[1]["a"], st[1::2].sum(0), atol=1e-12)
     assert abs(m.var_sum("loss") - float(torch.stack([x.sum() for x in xs]).double().var(unbiased=True))) < 1e-9
     assert abs(T._cos(st[0], st[0] * 3.0) - 1.0) < 1e-12
+
+
+def test_no_kernel_reuses_the_register_of_an_asynchronous_touch_request():
+    """tools/check_touch_isa.py over the generated gfx950 ISA (hipcc -S, no GPU): a panel-touch request with a REGISTER destination
+    (enc_attn.hip; the GEMM kernels' go to LDS since round 6) lands asynchronously -- no instruction may write that register before the
+    next counted vmcnt wait.  Round 6 found exactly this as a memory fault after an unrelated edit moved the register allocation."""
+    import subprocess
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_touch_isa.py")], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-1000:]
+    assert "touch requests in" in res.stdout and ", 0 written before a counted wait" in res.stdout, res.stdout[-500:]
+    n_req = int(res.stdout.strip().splitlines()[-1].split()[0])
+    assert n_req >= 1, "the checker found no request at all: its pattern no longer matches the sources"

@@ -12,7 +12,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "vqacl_amd", "csrc")
-FILES = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and (f.startswith("gemm_t") or f in ("enc_attn.hip", "dec_attn.hip"))]
+# translation units that can contain such a request: sources with an inline-asm `global_load_dword %0` themselves, or including a header that has one
+PAT = "global_load_dword %0"
+_hdrs = [h for h in os.listdir(CSRC) if h.endswith(".h") and PAT in open(os.path.join(CSRC, h)).read()]
+FILES = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and
+         (PAT in open(os.path.join(CSRC, f)).read() or any(f'#include "{h}"' in open(os.path.join(CSRC, f)).read() for h in _hdrs))]
 dst_re = re.compile(r"^\s+(\S+)\s+(v\d+|v\[\d+:\d+\])\b")
 
 
@@ -23,10 +27,17 @@ def regs(tok):
     return {int(tok[1:])}
 
 
+def isa_of(f):
+    return subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{CSRC}", "-S", "--cuda-device-only",
+                           os.path.join(CSRC, f), "-o", "-"] + sys.argv[1:], capture_output=True, text=True).stdout.splitlines()
+
+
+from concurrent.futures import ThreadPoolExecutor  # noqa: E402
+with ThreadPoolExecutor(max_workers=8) as pool:
+    listings = dict(zip(FILES, pool.map(isa_of, FILES)))
 bad = total = 0
 for f in FILES:
-    asm = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{CSRC}", "-S", "--cuda-device-only",
-                          os.path.join(CSRC, f), "-o", "-"] + sys.argv[1:], capture_output=True, text=True).stdout.splitlines()
+    asm = listings[f]
     kernel, in_asm = None, False
     pending = {}                                     # register -> line number of its request
     for n, line in enumerate(asm, 1):
